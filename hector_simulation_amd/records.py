@@ -1,0 +1,69 @@
+"""Packed per-instance input record of the batched MPC solver (host and device share this layout).
+
+One record = everything ``update_problem_data`` receives for one MPC tick
+(reference: ConvexMPC/convexMPC_interface.h:19-37 ``update_data_t``; extents SURVEY.md section 8b), narrowed to
+float32 exactly as ``update_problem_data`` does (convexMPC_interface.cpp:83-103), laid out contiguously so that one
+workgroup fetches its instance with a single coalesced burst:
+
+    float32 index   field
+    0..2            p            body position (world)
+    3..5            v            body velocity (world)
+    6..9            q            orientation quaternion (w, x, y, z)
+    10..12          w            angular velocity (world)
+    13..18          r            foot positions relative to the body, r[2*axis + leg]
+    19..28          joint_angles left leg q0..q4, right leg q0..q4
+    29              yaw          (carried for interface fidelity; unused by solve_mpc)
+    30..41          weights      Q diagonal
+    42..53          Alpha_K      R diagonal
+    54..54+12h-1    traj         reference trajectory, 12 floats per horizon step
+    then 2h bytes   gait         gait[2*step + leg], 1 = stance
+
+Record stride = (54 + 12h)*4 + 2h rounded up to 16 bytes (720 B at h = 10; 716 B of payload).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+N_FIXED = 54
+OFF = dict(p=0, v=3, q=6, w=10, r=13, joint_angles=19, yaw=29, weights=30, Alpha_K=42, traj=54)
+LEN = dict(p=3, v=3, q=4, w=3, r=6, joint_angles=10, yaw=1, weights=12, Alpha_K=12)
+
+
+def payload_bytes(horizon: int) -> int:
+    return (N_FIXED + 12 * horizon) * 4 + 2 * horizon
+
+
+def record_stride(horizon: int) -> int:
+    return (payload_bytes(horizon) + 15) // 16 * 16
+
+
+def pack_records(fields: dict, horizon: int) -> np.ndarray:
+    """fields: dict of arrays with leading batch dim (p,v,q,w,r,joint_angles,yaw,weights,Alpha_K,traj,gait).
+
+    Values are narrowed double->float32 / int->uint8 here, which is the narrowing the reference performs at its
+    C boundary.  Returns a uint8 array [batch, stride].
+    """
+    b = int(np.asarray(fields["p"]).shape[0])
+    stride = record_stride(horizon)
+    rec = np.zeros((b, stride), dtype=np.uint8)
+    f32 = rec[:, : (N_FIXED + 12 * horizon) * 4].view(np.float32)
+    for k, n in LEN.items():
+        a = np.asarray(fields[k], dtype=np.float64).reshape(b, n)
+        f32[:, OFF[k] : OFF[k] + n] = a.astype(np.float32)
+    tr = np.asarray(fields["traj"], dtype=np.float64).reshape(b, -1)[:, : 12 * horizon]
+    f32[:, OFF["traj"] : OFF["traj"] + 12 * horizon] = tr.astype(np.float32)
+    g = np.asarray(fields["gait"]).reshape(b, -1)[:, : 2 * horizon]
+    goff = (N_FIXED + 12 * horizon) * 4
+    rec[:, goff : goff + 2 * horizon] = g.astype(np.uint8)
+    return rec
+
+
+def unpack_records(rec: np.ndarray, horizon: int) -> dict:
+    rec = np.ascontiguousarray(rec)
+    b = rec.shape[0]
+    f32 = rec[:, : (N_FIXED + 12 * horizon) * 4].view(np.float32)
+    out = {k: f32[:, OFF[k] : OFF[k] + n].copy() for k, n in LEN.items()}
+    out["traj"] = f32[:, OFF["traj"] : OFF["traj"] + 12 * horizon].copy()
+    goff = (N_FIXED + 12 * horizon) * 4
+    out["gait"] = rec[:, goff : goff + 2 * horizon].copy()
+    return out

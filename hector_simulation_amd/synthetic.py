@@ -1,0 +1,116 @@
+"""Synthetic MPC-tick inputs for the BASELINE.json configs (distribution: SURVEY.md section 8d).
+
+Everything here restates what the reference's caller builds before it crosses the C boundary
+(ConvexMPC/ConvexMPCLocomotion.cpp:283-406: Q/alpha at :321-322, the 10-step reference trajectory at :351-406,
+foot vectors r[i] = pFoot[i%2][i/2] - position[i/2] at :313-316) and the gait tables of
+ConvexMPC/GaitGenerator.cpp:85-103 (``Gait(10,(0,5),(5,5))`` walking, ``Gait(10,(0,0),(10,10))`` standing,
+ConvexMPCLocomotion.cpp:16-17).  RNG = numpy.random.default_rng(seed).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+Q_WEIGHTS = np.array([100, 100, 250, 200, 200, 300, 1, 1, 1, 1, 1, 1], dtype=np.float64)
+ALPHA = np.array([1e-4, 1e-4, 5e-4, 1e-4, 1e-4, 5e-4, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2], dtype=np.float64)
+DT_MPC = 0.001 * 40  # FSMState_Walking.cpp:5
+F_MAX = 500.0  # ConvexMPCLocomotion.cpp:410
+NOMINAL_HEIGHT = 0.55
+
+
+def mpc_gait(horizon: int, offsets, durations, iteration: int, n_iter: int | None = None) -> np.ndarray:
+    """GaitGenerator.cpp:85-103 for one phase ``iteration``; returns int table [2*horizon], [2*i+leg]."""
+    n_iter = horizon if n_iter is None else n_iter
+    t = np.zeros(2 * horizon, dtype=np.int32)
+    for i in range(horizon):
+        it = (i + iteration) % n_iter
+        for j in range(2):
+            prog = it - offsets[j]
+            if prog < 0:
+                prog += n_iter
+            t[2 * i + j] = 1 if prog < durations[j] else 0
+    return t
+
+
+def quat_from_rpy(roll, pitch, yaw):
+    cr, sr = np.cos(roll / 2), np.sin(roll / 2)
+    cp, sp = np.cos(pitch / 2), np.sin(pitch / 2)
+    cy, sy = np.cos(yaw / 2), np.sin(yaw / 2)
+    return np.stack(
+        [cr * cp * cy + sr * sp * sy, sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy],
+        axis=-1,
+    )
+
+
+def make_batch(batch: int, horizon: int = 10, gait: str = "walking", seed: int = 0, randomize: bool = True,
+               phase: int | str = 0, yaw_rate_cmd: bool = False) -> dict:
+    """Returns the field dict ``records.pack_records`` accepts (float64 / int32 arrays, leading dim = batch).
+
+    gait: "standing" (both feet in stance every step), "walking" (reference walking gait, single support),
+          "single" (one leg in stance for the whole horizon; the h=20 stress config),
+          "mixed" (walking offsets with 70 % duty -> double-support phases).
+    phase: int (fixed gait iteration) or "random".
+    """
+    rng = np.random.default_rng(seed)
+    b, h = batch, horizon
+    z = lambda *s: np.zeros((b,) + s)
+    u = (lambda lo, hi, *s: rng.uniform(lo, hi, (b,) + s)) if randomize else (lambda lo, hi, *s: np.zeros((b,) + s))
+    rpy = np.stack([u(-0.1, 0.1), u(-0.1, 0.1), u(-0.1, 0.1)], -1)
+    p = np.stack([u(-0.02, 0.02), u(-0.02, 0.02), NOMINAL_HEIGHT + u(-0.03, 0.03)], -1)
+    v = u(-0.3, 0.3, 3)
+    w = u(-0.5, 0.5, 3)
+    q = quat_from_rpy(rpy[:, 0], rpy[:, 1], rpy[:, 2])
+    foot = z(2, 3)  # [leg][axis], world frame relative to body
+    foot[:, 0, 1], foot[:, 1, 1] = 0.06, -0.06
+    foot[:, :, 0] += u(-0.1, 0.1, 2)
+    foot[:, :, 1] += u(-0.03, 0.03, 2)
+    foot[:, :, 2] = -p[:, 2:3]
+    r = np.stack([foot[:, i % 2, i // 2] for i in range(6)], -1)  # r[2*axis+leg]
+    joints = u(-0.15, 0.15, 10)
+    vx_cmd = u(-0.5, 0.5)
+    yaw_rate = u(-0.3, 0.3) if yaw_rate_cmd else z()
+    # reference trajectory (ConvexMPCLocomotion.cpp:351-406); xStart/yStart = current xy (desired within clamp)
+    traj = z(h, 12)
+    traj[:, :, 3], traj[:, :, 4], traj[:, :, 5] = p[:, 0:1], p[:, 1:2], NOMINAL_HEIGHT
+    traj[:, :, 8] = yaw_rate[:, None]
+    traj[:, :, 9] = vx_cmd[:, None]
+    traj[:, 0, 0:3] = rpy
+    traj[:, 0, 3:6] = p
+    for i in range(1, h):
+        traj[:, i, 3] = p[:, 0] + i * DT_MPC * vx_cmd
+        if yaw_rate_cmd:
+            traj[:, i, 2] = rpy[:, 2] + i * DT_MPC * yaw_rate
+    # gait tables
+    if isinstance(phase, str):
+        ph = rng.integers(0, h, size=b)
+    else:
+        ph = np.full(b, int(phase))
+    half = h // 2
+    tables = {}
+    g = np.zeros((b, 2 * h), dtype=np.int32)
+    for k in range(b):
+        key = int(ph[k])
+        if key not in tables:
+            if gait == "standing":
+                tables[key] = mpc_gait(h, (0, 0), (h, h), key)
+            elif gait == "walking":
+                tables[key] = mpc_gait(h, (0, half), (half, h - half), key)
+            elif gait == "single":
+                tables[key] = np.tile(np.array([1, 0] if key % 2 == 0 else [0, 1], dtype=np.int32), h)
+            elif gait == "mixed":
+                dur = (7 * h + 9) // 10
+                tables[key] = mpc_gait(h, (0, half), (dur, dur), key)
+            else:
+                raise ValueError(gait)
+        g[k] = tables[key]
+    return dict(p=p, v=v, q=q, w=w, r=r, joint_angles=joints, yaw=rpy[:, 2], weights=np.tile(Q_WEIGHTS, (b, 1)),
+                Alpha_K=np.tile(ALPHA, (b, 1)), traj=traj.reshape(b, 12 * h), gait=g)
+
+
+CONFIGS = {
+    # BASELINE.json configs -> generator arguments (seed = config index)
+    "cfg1_stand_single": dict(batch=1, horizon=10, gait="standing", seed=1, randomize=False),
+    "cfg2_walk_1024": dict(batch=1024, horizon=10, gait="walking", seed=2, phase=0),
+    "cfg3_walk_sweep_65536": dict(batch=65536, horizon=10, gait="walking", seed=3, phase="random"),
+    "cfg4_h20_single_4096": dict(batch=4096, horizon=20, gait="single", seed=4, phase="random"),
+    "metric_2contact_1024": dict(batch=1024, horizon=10, gait="standing", seed=6),
+}

@@ -1,0 +1,112 @@
+/*
+ * hmpc_oracle.h -- CPU ORACLE for the HECTOR convex-MPC QP path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the reference's algorithm
+ *   (Hector_ROS_Simulation/hector_control/ConvexMPC/SolverMPC.cpp:65-89,120-131,133-193,302-342,371-738,
+ *    RobotState.cpp:9-53, convexMPC_interface.cpp:42-110)
+ * used ONLY by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker.
+ * The product (hector_simulation_amd/) never includes, links or calls anything in oracle/.
+ *
+ * PARITY STATUS: the reference ships no tests, golden vectors or fixtures for this path,
+ * and its fp32 assembly runs inside Eigen3, which is not vendored and not installed here -> the ASSEMBLY half
+ * is "parity unpinned" against the reference's own tests.  The SOLVER half is pinned: the QP is solved by the
+ * reference's own vendored qpOASES 3.2.0 compiled unmodified into oracle/_ref/ (see oracle/Makefile).
+ *
+ * Pinned arithmetic ("HMPC-A1"): IEEE binary32, round-to-nearest-even, no implicit
+ * contraction; every matrix contraction is a k-ascending fmaf chain started at +0; trigonometry is evaluated
+ * by the deterministic binary64 routines in this file and rounded once to binary32.
+ */
+#ifndef HMPC_ORACLE_H
+#define HMPC_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_HORIZON 36 /* K_MAX_GAIT_SEGMENTS, convexMPC_interface.h:3 */
+
+/* POD inputs, same fields as update_data_t / problem_setup (convexMPC_interface.h:11-37). */
+typedef struct {
+  float p[3], v[3], q[4], w[3], r[6], joint_angles[10], yaw, weights[12];
+  float traj[12 * ORC_MAX_HORIZON];
+  float Alpha_K[12];
+  unsigned char gait[2 * ORC_MAX_HORIZON];
+} orc_update_t;
+
+typedef struct {
+  float dt, mu, f_max;
+  int horizon;
+} orc_setup_t;
+
+/* Everything the reference forms before calling qpOASES, in the reference's own (unreduced) indexing. */
+typedef struct {
+  int horizon;
+  float qj[10];        /* offset + fmod'ed joint angles, SolverMPC.cpp:374-393 */
+  float R[9];          /* body rotation, RobotState.cpp:30 */
+  float rpy[3];        /* SolverMPC.cpp:333-342 */
+  float x0[13];        /* SolverMPC.cpp:420 */
+  float Acd[169];      /* I + dt*A_ct, row-major */
+  float Bcd[156];      /* dt*B_ct, row-major 13x12 */
+  float Rfoot[2][9];   /* SolverMPC.cpp:426-433 */
+  float Fc[16 * 12];   /* F_control, SolverMPC.cpp:511-548 */
+  float *Phi;          /* [h][13][12]  Acd^k * Bcd */
+  float *Apow;         /* [h+1][13][13] Acd^k */
+  float *H;            /* [12h][12h] row-major, exactly symmetric */
+  float *g;            /* [12h] */
+  float *lb, *ub;      /* [16h] */
+} orc_qp_t;
+
+/* Reduced QP exactly as handed to qpOASES (SolverMPC.cpp:589-697), binary64 row-major. */
+typedef struct {
+  int n, m;            /* new_vars, new_cons */
+  int *var_ind;        /* [n] original variable index */
+  int *con_ind;        /* [m] original constraint index */
+  double *H, *g, *A, *lb, *ub;
+} orc_red_t;
+
+orc_qp_t *orc_qp_alloc(int horizon);
+void orc_qp_free(orc_qp_t *);
+orc_red_t *orc_red_alloc(int horizon);
+void orc_red_free(orc_red_t *);
+
+/* deterministic binary64 trig (exported so tests can pin them against libm) */
+void orc_sincos(double x, double *s, double *c);
+double orc_atan2(double y, double x);
+double orc_asin(double v);
+
+/* SolverMPC.cpp:371-577 (assembly) */
+void orc_assemble(const orc_update_t *u, const orc_setup_t *s, orc_qp_t *out);
+/* SolverMPC.cpp:589-697 (swing-leg elimination) */
+void orc_reduce(const orc_qp_t *qp, orc_red_t *red);
+
+/* SolverMPC.cpp:699-732: solve with the reference's vendored qpOASES (oracle/_ref), scatter to q_soln[12h].
+ * returns qpOASES' init() return value (0 = SUCCESSFUL_RETURN); *nwsr receives the working-set changes used;
+ * *obj the optimal objective value 0.5 x'Hx + g'x of the reduced QP.  y_red (may be NULL) receives the n+m duals. */
+int orc_solve_reduced(const orc_red_t *red, double *x_red, double *y_red, int *nwsr, double *obj);
+int orc_solve_mpc(const orc_update_t *u, const orc_setup_t *s, double *q_soln /*[12h]*/, int *nwsr, double *obj,
+                  int *n_red, int *m_red);
+
+/* The reference's legacy C interface (convexMPC_interface.h:39-43), prefixed so both libraries can be loaded. */
+void orc_setup_problem(double dt, int horizon, double mu, double f_max);
+void orc_update_problem_data(double *p, double *v, double *q, double *w, double *r, double *joint_angles, double yaw,
+                             double *weights, double *state_trajectory, double *Alpha_K, int *gait);
+double orc_get_solution(int index);
+
+void orc_set_dense_chain(int on); /* 1: run every cost chain over all 13h rows (test of zero-block neutrality) */
+void orc_unpack_record(const unsigned char *rec, int horizon, orc_update_t *u);
+
+/* Batched CPU baseline over packed records (layout: hector_simulation_amd/records.py; 54+12h floats then 2h gait bytes,
+ * record stride `stride` bytes).  Solves records [first, first+count) and writes 12h doubles each.
+ * Returns the number of instances whose qpOASES status != 0.  t_assemble/t_solve (may be NULL) accumulate seconds. */
+int orc_solve_records(const unsigned char *records, int stride, int first, int count, int horizon, float dt,
+                      float f_max, double *q_soln, int *nwsr_out, double *obj_out, double *t_assemble, double *t_solve);
+
+/* provided by oracle/_ref/libqpoases_ref.so (oracle/qpoases_shim.cpp, built from the reference's own sources) */
+int ref_qpoases_solve(int nV, int nC, const double *H, const double *g, const double *A, const double *lbA,
+                      const double *ubA, int nWSR_max, double *x, double *y, double *obj, int *nWSR_used);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
