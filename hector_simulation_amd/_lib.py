@@ -1,0 +1,81 @@
+"""ctypes loader of libhector_mpc_hip.so.  Fails loudly: there is no CPU / PyTorch fallback for the solve path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+_lib = None
+
+# every symbol include/hector_mpc.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "setup_problem", "update_problem_data", "get_solution", "update_solver_settings", "hmpc_solve_mpc", "solveDenseMPC",
+    "hmpc_get_q_soln", "hmpc_last_status", "hmpc_record_stride", "hmpc_pack_record", "hmpc_create", "hmpc_destroy",
+    "hmpc_upload_records", "hmpc_set_device_records", "hmpc_set_max_reduced_vars", "hmpc_set_device_outputs",
+    "hmpc_solve", "hmpc_download", "hmpc_get_device_outputs", "hmpc_batch", "hmpc_horizon", "hmpc_time_solve",
+    "hmpc_debug_assemble", "hmpc_download_f64", "hmpc_last_hip_error", "hmpc_version",
+]
+
+
+class ProblemSetup(C.Structure):
+    _fields_ = [("dt", C.c_float), ("mu", C.c_float), ("f_max", C.c_float), ("horizon", C.c_int)]
+
+
+class UpdateData(C.Structure):
+    _fields_ = [("p", C.c_float * 3), ("v", C.c_float * 3), ("q", C.c_float * 4), ("w", C.c_float * 3),
+                ("r", C.c_float * 6), ("joint_angles", C.c_float * 10), ("yaw", C.c_float),
+                ("weights", C.c_float * 12), ("traj", C.c_float * (12 * 36)), ("Alpha_K", C.c_float * 12),
+                ("gait", C.c_ubyte * 36), ("hack_pad", C.c_ubyte * 1000), ("max_iterations", C.c_int),
+                ("rho", C.c_double), ("sigma", C.c_double), ("solver_alpha", C.c_double), ("terminate", C.c_double)]
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """Loads (building first if the sources are newer) the native library; raises if it cannot."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build()
+    if not os.path.exists(path):
+        raise RuntimeError("libhector_mpc_hip.so is missing and could not be built; the solver has no fallback path")
+    L = C.CDLL(path)
+    vp, ci, cd, cf = C.c_void_p, C.c_int, C.c_double, C.c_float
+    L.setup_problem.argtypes = [cd, ci, cd, cd]
+    L.setup_problem.restype = None
+    L.update_problem_data.argtypes = [vp] * 6 + [cd] + [vp] * 4
+    L.update_problem_data.restype = None
+    L.get_solution.argtypes = [ci]
+    L.get_solution.restype = cd
+    L.update_solver_settings.argtypes = [ci, cd, cd, cd, cd, cd]
+    L.update_solver_settings.restype = None
+    L.hmpc_solve_mpc.argtypes = [C.POINTER(UpdateData), C.POINTER(ProblemSetup)]
+    L.hmpc_solve_mpc.restype = None
+    L.solveDenseMPC.argtypes = [C.POINTER(UpdateData), C.POINTER(ProblemSetup)]
+    L.solveDenseMPC.restype = None
+    L.hmpc_get_q_soln.restype = C.POINTER(cd)
+    L.hmpc_last_status.restype = C.c_uint32
+    L.hmpc_record_stride.argtypes = [ci]
+    L.hmpc_record_stride.restype = C.c_size_t
+    L.hmpc_pack_record.argtypes = [vp, ci] + [vp] * 6 + [cd] + [vp] * 4
+    L.hmpc_create.argtypes = [C.POINTER(vp), C.POINTER(ProblemSetup), ci, ci]
+    L.hmpc_destroy.argtypes = [vp]
+    L.hmpc_upload_records.argtypes = [vp, vp, ci]
+    L.hmpc_set_device_records.argtypes = [vp, vp, ci]
+    L.hmpc_set_max_reduced_vars.argtypes = [vp, ci]
+    L.hmpc_set_device_outputs.argtypes = [vp, vp, vp]
+    L.hmpc_solve.argtypes = [vp, vp]
+    L.hmpc_download.argtypes = [vp, vp, vp]
+    L.hmpc_get_device_outputs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.hmpc_batch.argtypes = [vp]
+    L.hmpc_horizon.argtypes = [vp]
+    L.hmpc_time_solve.argtypes = [vp, vp, ci, C.POINTER(cf)]
+    L.hmpc_debug_assemble.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)] + [vp] * 9
+    L.hmpc_download_f64.argtypes = [vp, vp, vp]
+    L.hmpc_last_hip_error.restype = C.c_char_p
+    L.hmpc_version.restype = C.c_char_p
+    _lib = L
+    return L

@@ -1,0 +1,468 @@
+// hmpc_capi.hip -- host side of libhector_mpc_hip.so: the C ABI of include/hector_mpc.h over the gfx950 kernel.
+//
+// Reference interface this replaces (a maintainer drops the library in place of these translation units):
+//   ConvexMPC/convexMPC_interface.cpp:42-118  setup_problem / update_problem_data / get_solution / update_solver_settings
+//   ConvexMPC/SolverMPC.cpp:94-97, 371-738    get_q_soln / solve_mpc
+// There is NO CPU fallback: without a gfx950 device every entry point fails (HMPC_E_NO_DEVICE) and the legacy
+// entry points print the error and leave the previous solution in place.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hector_mpc.h"
+#include "hmpc_kernel.h"
+
+namespace {
+
+thread_local std::string g_hip_err;
+
+#define HIP_TRY(expr)                                                                                    \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess) {                                                                              \
+      g_hip_err = std::string(#expr) + ": " + hipGetErrorString(_e);                                     \
+      return HMPC_E_HIP;                                                                                 \
+    }                                                                                                    \
+  } while (0)
+
+typedef void (*kernel_fn)(hmpc::KernelArgs);
+
+struct Variant {
+  int nmax, hmax;
+  kernel_fn solve, assemble;
+  size_t smem;
+  int dbg_floats;
+};
+
+template <int NMAX, int HMAX>
+Variant make_variant() {
+  return Variant{NMAX, HMAX, hmpc::hmpc_kernel<NMAX, HMAX, false>, hmpc::hmpc_kernel<NMAX, HMAX, true>,
+                 sizeof(hmpc::Smem<NMAX, HMAX>), hmpc::DbgLayout<NMAX>::TOTAL};
+}
+
+const Variant *variants() {
+  static const Variant v[] = {make_variant<60, 10>(), make_variant<120, 10>(), make_variant<60, 20>(),
+                              make_variant<120, 20>()};
+  return v;
+}
+constexpr int N_VARIANTS = 4;
+
+size_t record_stride(int h) { return (size_t)(((54 + 12 * h) * 4 + 2 * h + 15) / 16 * 16); }
+
+}  // namespace
+
+struct hmpc_handle {
+  problem_setup setup;
+  int max_batch, device, batch;
+  size_t stride;
+  unsigned char *d_records_own;
+  const unsigned char *d_records;
+  float *d_forces_own, *d_forces;
+  uint32_t *d_status_own, *d_status;
+  double *d_x64, *d_obj64;
+  float *d_dbg_f;
+  int *d_dbg_i;
+  int max_stance;  // max reduced variables of the current batch (known only for host-uploaded records; else -1)
+  hipStream_t last_stream;
+  bool attrs_set[N_VARIANTS];
+};
+
+static const Variant &pick_variant(const hmpc_handle *h, int *index) {
+  const Variant *v = variants();
+  const int hz = h->setup.horizon;
+  int best = -1;
+  for (int i = 0; i < N_VARIANTS; ++i) {
+    if (v[i].hmax < hz) continue;
+    if (h->max_stance >= 0 && v[i].nmax < h->max_stance) continue;
+    if (h->max_stance < 0 && v[i].nmax < HMPC_MAX_VARS) continue;
+    if (best < 0 || v[i].smem < v[best].smem) best = i;
+  }
+  if (best < 0) best = N_VARIANTS - 1;  // oversize batches are reported per instance (HMPC_S_TOO_LARGE)
+  if (index) *index = best;
+  return v[best];
+}
+
+static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int dbg_index) {
+  int vi = 0;
+  const Variant &v = pick_variant(h, &vi);
+  kernel_fn fn = assemble_only ? v.assemble : v.solve;
+  if (!h->attrs_set[vi]) {
+    HIP_TRY(hipFuncSetAttribute((const void *)v.solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.smem));
+    HIP_TRY(hipFuncSetAttribute((const void *)v.assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.smem));
+    h->attrs_set[vi] = true;
+  }
+  hmpc::KernelArgs a;
+  a.records = h->d_records;
+  a.stride = (int)h->stride;
+  a.batch = h->batch;
+  a.horizon = h->setup.horizon;
+  a.dt = h->setup.dt;
+  a.f_max = h->setup.f_max;
+  a.forces = h->d_forces;
+  a.status = h->d_status;
+  a.x64 = h->d_x64;
+  a.obj64 = h->d_obj64;
+  a.dbg_index = dbg_index;
+  a.dbg_f = h->d_dbg_f;
+  a.dbg_i = h->d_dbg_i;
+  const int grid = assemble_only ? 1 : h->batch;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(hmpc::NT), v.smem, stream, a);
+  HIP_TRY(hipGetLastError());
+  return HMPC_OK;
+}
+
+extern "C" {
+
+const char *hmpc_last_hip_error(void) { return g_hip_err.c_str(); }
+const char *hmpc_version(void) { return "hector_mpc_hip 0.1 (gfx950)"; }
+
+size_t hmpc_record_stride(int horizon) { return record_stride(horizon); }
+
+int hmpc_pack_record(void *record, int horizon, const double *p, const double *v, const double *q, const double *w,
+                     const double *r, const double *joint_angles, double yaw, const double *weights,
+                     const double *state_trajectory, const double *Alpha_K, const int *gait) {
+  if (!record || !p || !v || !q || !w || !r || !joint_angles || !weights || !state_trajectory || !Alpha_K || !gait)
+    return HMPC_E_ARG;
+  if (horizon < 1 || horizon > HMPC_MAX_HORIZON) return HMPC_E_HORIZON;
+  memset(record, 0, record_stride(horizon));
+  float *f = (float *)record;
+  for (int i = 0; i < 3; ++i) f[0 + i] = (float)p[i], f[3 + i] = (float)v[i], f[10 + i] = (float)w[i];
+  for (int i = 0; i < 4; ++i) f[6 + i] = (float)q[i];
+  for (int i = 0; i < 6; ++i) f[13 + i] = (float)r[i];
+  for (int i = 0; i < 10; ++i) f[19 + i] = (float)joint_angles[i];
+  f[29] = (float)yaw;
+  for (int i = 0; i < 12; ++i) f[30 + i] = (float)weights[i], f[42 + i] = (float)Alpha_K[i];
+  for (int i = 0; i < 12 * horizon; ++i) f[54 + i] = (float)state_trajectory[i];
+  unsigned char *g = (unsigned char *)record + 4 * (54 + 12 * horizon);
+  for (int i = 0; i < 2 * horizon; ++i) g[i] = (unsigned char)gait[i];
+  return HMPC_OK;
+}
+
+int hmpc_create(hmpc_handle **out, const struct problem_setup *setup, int max_batch, int device) {
+  if (!out || !setup || max_batch < 1) return HMPC_E_ARG;
+  if (setup->horizon < 1 || setup->horizon > HMPC_MAX_HORIZON) return HMPC_E_HORIZON;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device >= ndev) {
+    g_hip_err = "no HIP device visible (libhector_mpc_hip has no CPU fallback)";
+    return HMPC_E_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device));
+  hmpc_handle *h = new (std::nothrow) hmpc_handle();
+  if (!h) return HMPC_E_ARG;
+  memset(h, 0, sizeof(*h));
+  h->setup = *setup;
+  h->max_batch = max_batch;
+  h->device = device;
+  h->stride = record_stride(setup->horizon);
+  h->max_stance = -1;
+  const size_t nf = (size_t)max_batch * 12 * setup->horizon;
+  if (hipMalloc(&h->d_records_own, (size_t)max_batch * h->stride) != hipSuccess ||
+      hipMalloc(&h->d_forces_own, nf * sizeof(float)) != hipSuccess ||
+      hipMalloc(&h->d_status_own, (size_t)max_batch * sizeof(uint32_t)) != hipSuccess) {
+    g_hip_err = "hipMalloc failed in hmpc_create";
+    hmpc_destroy(h);
+    return HMPC_E_HIP;
+  }
+  h->d_records = h->d_records_own;
+  h->d_forces = h->d_forces_own;
+  h->d_status = h->d_status_own;
+  *out = h;
+  return HMPC_OK;
+}
+
+int hmpc_destroy(hmpc_handle *h) {
+  if (!h) return HMPC_E_ARG;
+  hipSetDevice(h->device);
+  if (h->d_records_own) hipFree(h->d_records_own);
+  if (h->d_forces_own) hipFree(h->d_forces_own);
+  if (h->d_status_own) hipFree(h->d_status_own);
+  if (h->d_x64) hipFree(h->d_x64);
+  if (h->d_obj64) hipFree(h->d_obj64);
+  if (h->d_dbg_f) hipFree(h->d_dbg_f);
+  if (h->d_dbg_i) hipFree(h->d_dbg_i);
+  delete h;
+  return HMPC_OK;
+}
+
+int hmpc_upload_records(hmpc_handle *h, const void *host_records, int batch) {
+  if (!h || !host_records || batch < 0) return HMPC_E_ARG;
+  if (batch > h->max_batch) return HMPC_E_BATCH;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpy(h->d_records_own, host_records, (size_t)batch * h->stride, hipMemcpyHostToDevice));
+  h->d_records = h->d_records_own;
+  h->batch = batch;
+  // host-side scan of the gait tables: the widest reduced QP in the batch picks the kernel variant (LDS footprint)
+  const int hz = h->setup.horizon;
+  int mx = 0;
+  const unsigned char *rec = (const unsigned char *)host_records;
+  for (int b = 0; b < batch; ++b) {
+    const unsigned char *g = rec + (size_t)b * h->stride + 4 * (54 + 12 * hz);
+    int cnt = 0;
+    for (int i = 0; i < 2 * hz; ++i) {
+      float ub = h->setup.f_max * (float)g[i];
+      if (!(ub < 0.0001 && ub > -.0001)) ++cnt;
+    }
+    if (cnt > mx) mx = cnt;
+  }
+  h->max_stance = 6 * mx;
+  return HMPC_OK;
+}
+
+int hmpc_set_device_records(hmpc_handle *h, const void *device_records, int batch) {
+  if (!h || !device_records || batch < 0) return HMPC_E_ARG;
+  if (batch > h->max_batch) return HMPC_E_BATCH;
+  h->d_records = (const unsigned char *)device_records;
+  h->batch = batch;
+  h->max_stance = -1;
+  return HMPC_OK;
+}
+
+int hmpc_set_max_reduced_vars(hmpc_handle *h, int n_reduced) {
+  if (!h) return HMPC_E_ARG;
+  h->max_stance = n_reduced;
+  return HMPC_OK;
+}
+
+int hmpc_set_device_outputs(hmpc_handle *h, float *device_forces, uint32_t *device_status) {
+  if (!h) return HMPC_E_ARG;
+  h->d_forces = device_forces ? device_forces : h->d_forces_own;
+  h->d_status = device_status ? device_status : h->d_status_own;
+  return HMPC_OK;
+}
+
+int hmpc_solve(hmpc_handle *h, void *stream) {
+  if (!h) return HMPC_E_ARG;
+  if (h->batch == 0) return HMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  h->last_stream = (hipStream_t)stream;
+  return launch(h, (hipStream_t)stream, false, 0);
+}
+
+int hmpc_download(hmpc_handle *h, float *forces, uint32_t *status) {
+  if (!h) return HMPC_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
+  const size_t nf = (size_t)h->batch * 12 * h->setup.horizon;
+  if (forces && nf) HIP_TRY(hipMemcpy(forces, h->d_forces, nf * sizeof(float), hipMemcpyDeviceToHost));
+  if (status && h->batch)
+    HIP_TRY(hipMemcpy(status, h->d_status, (size_t)h->batch * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return HMPC_OK;
+}
+
+int hmpc_get_device_outputs(hmpc_handle *h, float **device_forces, uint32_t **device_status) {
+  if (!h) return HMPC_E_ARG;
+  if (device_forces) *device_forces = h->d_forces;
+  if (device_status) *device_status = h->d_status;
+  return HMPC_OK;
+}
+
+int hmpc_batch(const hmpc_handle *h) { return h ? h->batch : HMPC_E_ARG; }
+int hmpc_horizon(const hmpc_handle *h) { return h ? h->setup.horizon : HMPC_E_ARG; }
+
+int hmpc_time_solve(hmpc_handle *h, void *stream, int reps, float *ms_per_launch) {
+  if (!h || reps < 1 || !ms_per_launch) return HMPC_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipStream_t s = (hipStream_t)stream;
+  h->last_stream = s;
+  HIP_TRY(hipEventRecord(e0, s));
+  for (int i = 0; i < reps; ++i) {
+    int rc = launch(h, s, false, 0);
+    if (rc != HMPC_OK) return rc;
+  }
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *ms_per_launch = ms / (float)reps;
+  return HMPC_OK;
+}
+
+int hmpc_debug_assemble(hmpc_handle *h, int index, int *n, int *m, int *var_ind, float *H, float *g, float *Fc,
+                        float *lb, float *ub, float *x0, float *Acd, float *Bcd) {
+  if (!h || index < 0 || index >= h->batch) return HMPC_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  int vi = 0;
+  const Variant &v = pick_variant(h, &vi);
+  if (!h->d_dbg_f) {
+    HIP_TRY(hipMalloc(&h->d_dbg_f, sizeof(float) * (size_t)hmpc::DbgLayout<HMPC_MAX_VARS>::TOTAL));
+    HIP_TRY(hipMalloc(&h->d_dbg_i, sizeof(int) * (2 + HMPC_MAX_VARS)));
+  }
+  HIP_TRY(hipMemset(h->d_dbg_i, 0, sizeof(int) * (2 + HMPC_MAX_VARS)));
+  int rc = launch(h, 0, true, index);
+  if (rc != HMPC_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<float> hf(v.dbg_floats);
+  std::vector<int> hi(2 + HMPC_MAX_VARS);
+  HIP_TRY(hipMemcpy(hf.data(), h->d_dbg_f, sizeof(float) * hf.size(), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hi.data(), h->d_dbg_i, sizeof(int) * hi.size(), hipMemcpyDeviceToHost));
+  const int nn = hi[0], mm = hi[1], hz = h->setup.horizon;
+  if (n) *n = nn;
+  if (m) *m = mm;
+  if (nn > v.nmax) return HMPC_OK;  // too large: only n, m are meaningful
+  const int NM = v.nmax;
+  const int oG = NM * NM, oFC = oG + NM, oLB = oFC + 192, oUB = oLB + 320, oX0 = oUB + 320, oACD = oX0 + 16,
+            oBCD = oACD + 176;
+  if (var_ind) memcpy(var_ind, hi.data() + 2, sizeof(int) * nn);
+  if (H) memcpy(H, hf.data(), sizeof(float) * (size_t)nn * nn);
+  if (g) memcpy(g, hf.data() + oG, sizeof(float) * nn);
+  if (Fc) memcpy(Fc, hf.data() + oFC, sizeof(float) * 192);
+  if (lb) memcpy(lb, hf.data() + oLB, sizeof(float) * 16 * hz);
+  if (ub) memcpy(ub, hf.data() + oUB, sizeof(float) * 16 * hz);
+  if (x0) memcpy(x0, hf.data() + oX0, sizeof(float) * 13);
+  if (Acd) memcpy(Acd, hf.data() + oACD, sizeof(float) * 169);
+  if (Bcd) memcpy(Bcd, hf.data() + oBCD, sizeof(float) * 156);
+  return HMPC_OK;
+}
+
+int hmpc_download_f64(hmpc_handle *h, double *x, double *obj) {
+  if (!h) return HMPC_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t nf = (size_t)h->max_batch * 12 * h->setup.horizon;
+  if (!h->d_x64) {
+    // first use: allocate and re-run the last batch with the binary64 copy-out enabled
+    HIP_TRY(hipMalloc(&h->d_x64, nf * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->d_obj64, (size_t)h->max_batch * sizeof(double)));
+    int rc = launch(h, h->last_stream, false, 0);
+    if (rc != HMPC_OK) return rc;
+  }
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
+  const size_t nb = (size_t)h->batch * 12 * h->setup.horizon;
+  if (x && nb) HIP_TRY(hipMemcpy(x, h->d_x64, nb * sizeof(double), hipMemcpyDeviceToHost));
+  if (obj && h->batch) HIP_TRY(hipMemcpy(obj, h->d_obj64, (size_t)h->batch * sizeof(double), hipMemcpyDeviceToHost));
+  return HMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The reference's own interface (convexMPC_interface.cpp:42-118): process-global, single-threaded, blocking.
+// ------------------------------------------------------------------------------------------------------------------
+static problem_setup g_setup = {0.f, 0.f, 0.f, 0};
+static update_data_t g_update;
+static hmpc_handle *g_handle = nullptr;
+static double *g_q_soln = nullptr;  // 12*horizon doubles, solver-owned (SolverMPC.cpp:52, :94-97)
+static int g_q_len = 0;
+static int g_has_solved = 0;
+static uint32_t g_last_status = 0;
+static int g_setup_error = 0;
+
+void setup_problem(double dt, int horizon, double mu, double f_max) {
+  g_setup.horizon = horizon;
+  g_setup.f_max = (float)f_max;
+  g_setup.mu = (float)mu;
+  g_setup.dt = (float)dt;
+  g_setup_error = 0;
+  if (horizon < 1 || horizon > HMPC_MAX_HORIZON) {
+    // the reference throws std::runtime_error("horizon is too long!") from c2qp for horizon > 19; we never throw across C
+    fprintf(stderr, "[hector_mpc_hip] setup_problem: horizon %d outside [1,%d]\n", horizon, HMPC_MAX_HORIZON);
+    g_setup_error = HMPC_E_HORIZON;
+    return;
+  }
+  // the reference frees and re-mallocs every buffer on every call (resize_qp_mats); we only rebuild when the
+  // problem shape or scalars change, the observable behaviour (q_soln valid until the next setup) is the same.
+  if (g_handle && (g_handle->setup.horizon != horizon || g_handle->setup.dt != g_setup.dt ||
+                   g_handle->setup.f_max != g_setup.f_max)) {
+    hmpc_destroy(g_handle);
+    g_handle = nullptr;
+  }
+  if (!g_handle) {
+    int rc = hmpc_create(&g_handle, &g_setup, 1, 0);
+    if (rc != HMPC_OK) {
+      fprintf(stderr, "[hector_mpc_hip] setup_problem failed (%d): %s\n", rc, hmpc_last_hip_error());
+      g_handle = nullptr;
+      g_setup_error = rc;
+      return;
+    }
+  }
+  if (g_q_len != 12 * horizon) {
+    free(g_q_soln);
+    g_q_soln = (double *)calloc((size_t)12 * horizon, sizeof(double));
+    g_q_len = 12 * horizon;
+  }
+}
+
+static void solve_global(void) {
+  if (!g_handle || g_setup_error) {
+    fprintf(stderr, "[hector_mpc_hip] solve requested without a valid setup_problem (error %d)\n", g_setup_error);
+    return;
+  }
+  const int hz = g_setup.horizon;
+  std::vector<unsigned char> rec(record_stride(hz), 0);
+  float *f = (float *)rec.data();
+  memcpy(f + 0, g_update.p, 12), memcpy(f + 3, g_update.v, 12), memcpy(f + 6, g_update.q, 16);
+  memcpy(f + 10, g_update.w, 12), memcpy(f + 13, g_update.r, 24), memcpy(f + 19, g_update.joint_angles, 40);
+  f[29] = g_update.yaw;
+  memcpy(f + 30, g_update.weights, 48), memcpy(f + 42, g_update.Alpha_K, 48);
+  memcpy(f + 54, g_update.traj, sizeof(float) * 12 * hz);
+  memcpy(rec.data() + 4 * (54 + 12 * hz), g_update.gait, 2 * hz);
+  std::vector<float> forces(12 * hz);
+  uint32_t st = 0;
+  int rc = hmpc_upload_records(g_handle, rec.data(), 1);
+  if (rc == HMPC_OK) rc = hmpc_solve(g_handle, nullptr);
+  if (rc == HMPC_OK) rc = hmpc_download(g_handle, forces.data(), &st);
+  if (rc != HMPC_OK) {
+    fprintf(stderr, "[hector_mpc_hip] solve failed (%d): %s\n", rc, hmpc_last_hip_error());
+    return;
+  }
+  g_last_status = st;
+  if (HMPC_STATUS_CODE(st) != HMPC_S_OK) printf("failed to solve!\n");  // SolverMPC.cpp:714-715
+  for (int i = 0; i < 12 * hz; ++i) g_q_soln[i] = (double)forces[i];
+  g_has_solved = 1;
+}
+
+void update_problem_data(double *p, double *v, double *q, double *w, double *r, double *joint_angles, double yaw,
+                         double *weights, double *state_trajectory, double *Alpha_K, int *gait) {
+  const int hz = g_setup.horizon;
+  if (hz < 1 || hz > HMPC_MAX_HORIZON) return;
+  for (int i = 0; i < 3; ++i) g_update.p[i] = (float)p[i], g_update.v[i] = (float)v[i], g_update.w[i] = (float)w[i];
+  for (int i = 0; i < 4; ++i) g_update.q[i] = (float)q[i];
+  for (int i = 0; i < 6; ++i) g_update.r[i] = (float)r[i];
+  for (int i = 0; i < 10; ++i) g_update.joint_angles[i] = (float)joint_angles[i];
+  g_update.yaw = (float)yaw;
+  for (int i = 0; i < 12; ++i) g_update.weights[i] = (float)weights[i], g_update.Alpha_K[i] = (float)Alpha_K[i];
+  for (int i = 0; i < 12 * hz; ++i) g_update.traj[i] = (float)state_trajectory[i];
+  for (int i = 0; i < 2 * hz; ++i) g_update.gait[i] = (unsigned char)gait[i];
+  solve_global();
+}
+
+double get_solution(int index) {
+  if (!g_has_solved) return 0.0;  // convexMPC_interface.cpp:107
+  if (index < 0 || index >= g_q_len) return 0.0;
+  return g_q_soln[index];
+}
+
+void update_solver_settings(int max_iter, double rho, double sigma, double solver_alpha, double terminate,
+                            double use_jcqp) {
+  // stored and, as in the reference (convexMPC_interface.cpp:112-118), read by nothing: the active-set solver has no knobs
+  g_update.max_iterations = max_iter;
+  g_update.rho = rho;
+  g_update.sigma = sigma;
+  g_update.solver_alpha = solver_alpha;
+  g_update.terminate = terminate;
+  (void)use_jcqp;
+}
+
+void hmpc_solve_mpc(struct update_data_t *update, struct problem_setup *setup) {
+  if (!update || !setup) return;
+  if (!g_handle || g_setup.horizon != setup->horizon || g_setup.dt != setup->dt || g_setup.f_max != setup->f_max)
+    setup_problem((double)setup->dt, setup->horizon, (double)setup->mu, (double)setup->f_max);
+  if (update != &g_update) g_update = *update;
+  solve_global();
+}
+void solveDenseMPC(struct update_data_t *update, struct problem_setup *setup) { hmpc_solve_mpc(update, setup); }
+double *hmpc_get_q_soln(void) { return g_q_soln; }
+uint32_t hmpc_last_status(void) { return g_last_status; }
+
+}  // extern "C"
+
+// C++-linkage symbols with the reference's exact names (SolverMPC.h:56, :63), for callers that include its header
+void solve_mpc(update_data_t *update, problem_setup *setup) { hmpc_solve_mpc(update, setup); }
+double *get_q_soln() { return hmpc_get_q_soln(); }

@@ -1,0 +1,975 @@
+// hmpc_kernel.h -- the fused assembly + QP-solve kernel (one 256-thread workgroup per MPC instance, gfx950).
+//
+// Replaces, for a whole batch at once, the reference's per-tick CPU path
+//   update_problem_data -> solve_mpc -> qpOASES::QProblem::init
+//   (ConvexMPC/convexMPC_interface.cpp:83-103, ConvexMPC/SolverMPC.cpp:371-738, third_party/qpOASES/src/QProblem.cpp:316).
+//
+// Phases (all state lives in LDS / registers; HBM sees only the ~716 B record in and 12h floats + 1 word out):
+//   A  assembly in binary32 under the HMPC-A1 arithmetic contract (bit-identical to oracle/hmpc_oracle.c):
+//      trig -> scalar algebra -> Acd^k, Phi_k = Acd^k Bcd -> tracking error -> swing elimination tables
+//      -> H = 2(B'SB + alpha) on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 = k-ordered fmaf chain), g.
+//   S  M = H^-1 in binary64 by n symmetric sweeps, matrix held in registers (8x4 tile per thread), one barrier a sweep.
+//   Q  dual active-set (Goldfarb-Idnani in range-space form): Schur inverse E = (N M N')^-1 kept explicitly and
+//      updated by bordering / Schur-complement rank-1 steps, so every iteration is parallel mat-vecs -- no
+//      triangular solves.  Two steps of iterative refinement of the multipliers at the end.
+// LDS layout: one (n x (n+1)) binary64 square holds M in its upper triangle (diagonal included) and E packed in
+// its strict lower triangle (E(i,j), i>=j, at row i+1, column j); assembly scratch and solver vectors share a union.
+#pragma once
+#include <stdint.h>
+
+#include "hmpc_math.h"
+
+namespace hmpc {
+
+constexpr int NT = 256;  // threads per workgroup
+constexpr int NW = NT / 64;
+
+struct KernelArgs {
+  const unsigned char *records;
+  int stride, batch, horizon;
+  float dt, f_max;
+  float *forces;     // [batch][12h]
+  uint32_t *status;  // [batch]
+  double *x64;       // optional [batch][12h]
+  double *obj64;     // optional [batch]
+  // assembly-only debug dump (hmpc_debug_assemble)
+  int dbg_index;
+  float *dbg_f;
+  int *dbg_i;
+};
+
+// offsets (in floats) of the debug dump, shared with the host
+template <int NMAX>
+struct DbgLayout {
+  static constexpr int H = 0, G = NMAX * NMAX, FC = G + NMAX, LB = FC + 192, UB = LB + 16 * 20, X0 = UB + 16 * 20,
+                       ACD = X0 + 16, BCD = ACD + 176, TOTAL = BCD + 160;
+};
+
+enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT = 4 };
+
+template <int NMAX, int HMAX>
+struct Smem {
+  static constexpr int LD = NMAX + 1;
+  static constexpr int NLS = NMAX / 6;
+  static constexpr int MMAX = NLS * 8;
+  static constexpr int RECW = ((54 + 12 * HMAX) * 4 + 2 * HMAX + 15) / 16 * 4;  // record words
+
+  double sq[NMAX * LD];
+  double g[NMAX];
+  double Cn[2][8][6];
+  double ub7[NLS];
+  unsigned char vstep[NMAX], vcomp[NMAX];
+  unsigned char rmap[12 * HMAX];  // original variable -> reduced index (255 = eliminated)
+  unsigned char ls_step[NLS], ls_leg[NLS], ls_vF[NLS], ls_vM[NLS];
+  int n, m, nls, pad0;
+
+  struct Asm {
+    uint32_t rec[RECW];
+    float sc[10][2];
+    float sc234[2][2];
+    float rpy[3];
+    float ypsc[4];  // cy, sy, cp, sp
+    float R[9], Rt[9];
+    float Acd[169], Bcd[156], x0[13], W[13], Fc[192];
+    float Apow[2 * 169];
+    float Phi[HMAX * 156], SPhi[HMAX * 156];
+    float e[13 * HMAX];
+  };
+  struct Sol {
+    double x[NMAX], xu[NMAX], z[NMAX], w[NMAX];
+    double part[NW][NMAX];
+    double piv[2][NMAX];
+    double u[NMAX], d[NMAX], r[NMAX], col[NMAX];
+    double redv[NW];
+    double gamma;
+    int redi[NW];
+    signed char act[MMAX];
+    unsigned char slot[MMAX];
+    unsigned char Wrow[NMAX];
+  };
+  union {
+    Asm a;
+    Sol s;
+  } u;
+};
+
+template <int NMAX, int HMAX>
+__device__ __forceinline__ double &Mref(Smem<NMAX, HMAX> &S, int i, int j) {
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  return S.sq[lo * Smem<NMAX, HMAX>::LD + hi];
+}
+template <int NMAX, int HMAX>
+__device__ __forceinline__ double &Eref(Smem<NMAX, HMAX> &S, int i, int j) {
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  return S.sq[(hi + 1) * Smem<NMAX, HMAX>::LD + lo];
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int mask) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, mask);
+  hi = __shfl_xor(hi, mask);
+  return __hiloint2double(hi, lo);
+}
+
+// workgroup-wide argmin of (val, idx); ties -> lowest idx.  All threads return the same pair.  One barrier inside,
+// and the caller must ensure redv/redi are not still being read from a previous call (a barrier in between).
+template <class SOL>
+__device__ __forceinline__ void block_argmin(SOL &s, double &val, int &idx) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    double ov = shfl_xor_d(val, o);
+    int oi = __shfl_xor(idx, o);
+    bool take = (ov < val) || (ov == val && oi < idx);
+    val = take ? ov : val;
+    idx = take ? oi : idx;
+  }
+  const int tid = threadIdx.x;
+  if ((tid & 63) == 0) {
+    s.redv[tid >> 6] = val;
+    s.redi[tid >> 6] = idx;
+  }
+  __syncthreads();
+  val = s.redv[0];
+  idx = s.redi[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) {
+    double ov = s.redv[w];
+    int oi = s.redi[w];
+    bool take = (ov < val) || (ov == val && oi < idx);
+    val = take ? ov : val;
+    idx = take ? oi : idx;
+  }
+}
+
+// z = M v over the n x n symmetric inverse held in the square's upper triangle.  Wave w takes the j-range quarter w,
+// lane l takes rows l and l+64; partials are combined in a fixed order (deterministic).  Two barriers inside.
+template <int NMAX, int HMAX>
+__device__ __forceinline__ void matvec(Smem<NMAX, HMAX> &S, const double *v, double *z, int n) {
+  constexpr int LD = Smem<NMAX, HMAX>::LD;
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int jq = (n + NW - 1) / NW;
+  const int j0 = wv * jq, j1 = (j0 + jq < n) ? j0 + jq : n;
+#pragma unroll
+  for (int rr = 0; rr < (NMAX + 63) / 64; ++rr) {
+    const int i = ln + 64 * rr;
+    if (i < n) {
+      double acc = 0.0;
+      for (int j = j0; j < j1; ++j) {
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        acc = dfma(S.sq[lo * LD + hi], v[j], acc);
+      }
+      S.u.s.part[wv][i] = acc;
+    }
+  }
+  __syncthreads();
+  if (tid < n) {
+    double a = S.u.s.part[0][tid];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) a += S.u.s.part[w][tid];
+    z[tid] = a;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int NMAX, int HMAX, bool ASM_ONLY>
+__global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
+  using SM = Smem<NMAX, HMAX>;
+  constexpr int LD = SM::LD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  SM &S = *reinterpret_cast<SM *>(smem_raw);
+  auto &A = S.u.a;
+  auto &Q = S.u.s;
+
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int inst = ASM_ONLY ? args.dbg_index : (int)blockIdx.x;
+  const int h = args.horizon;
+  if (inst >= args.batch) return;
+
+  // ---------------- A0: one coalesced burst brings the instance's record into LDS ----------------
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(args.records + (size_t)inst * args.stride);
+    const int nwords = args.stride >> 2;
+    for (int t = tid; t < nwords; t += NT) A.rec[t] = src[t];
+  }
+  __syncthreads();
+  const float *rf = reinterpret_cast<const float *>(A.rec);
+  const unsigned char *gait = reinterpret_cast<const unsigned char *>(A.rec + 54 + 12 * h);
+  // record field offsets (hector_simulation_amd/records.py)
+  const float *in_p = rf + 0, *in_v = rf + 3, *in_q = rf + 6, *in_w = rf + 10, *in_r = rf + 13, *in_ja = rf + 19,
+              *in_wt = rf + 30, *in_al = rf + 42, *in_traj = rf + 54;
+
+  // ---------------- A1: trigonometry, one lane per angle (SolverMPC.cpp:374-393, 333-342, 74-85) ----------------
+  {
+    const double PI = 3.14159265359, PI2 = 2 * PI;
+    auto joint = [&](int i) -> float {
+      float a = in_ja[i];
+      const int k = i % 5;
+      if (k == 2 || k == 4) a = (float)((double)a + 0.3 * PI);
+      if (k == 3) a = (float)((double)a - 0.6 * PI);
+      return (float)fmod((double)a, PI2);
+    };
+    if (tid < 10) {
+      double s, c;
+      det_sincos((double)joint(tid), s, c);
+      A.sc[tid][0] = (float)s;
+      A.sc[tid][1] = (float)c;
+    } else if (tid < 12) {
+      const int b = 5 * (tid - 10);
+      float q234 = (joint(b + 2) + joint(b + 3)) + joint(b + 4);
+      double s, c;
+      det_sincos((double)q234, s, c);
+      A.sc234[tid - 10][0] = (float)s;
+      A.sc234[tid - 10][1] = (float)c;
+    } else if (tid < 15) {
+      const float qw = in_q[0], qx = in_q[1], qy = in_q[2], qz = in_q[3];
+      if (tid == 12) {
+        float n0 = 2.0f * (qw * qx + qy * qz);
+        double d0 = 1.0 - (double)(2.0f * (qx * qx + qy * qy));
+        A.rpy[0] = (float)det_atan2((double)n0, d0);
+      } else if (tid == 13) {
+        float t = qw * qy - qx * qz;
+        double asd = 2.0 * (double)t;
+        if (!(asd < 0.99999)) asd = 0.99999;
+        float as = (float)asd;
+        float pitch = (float)det_asin((double)as);
+        A.rpy[1] = pitch;
+        double s, c;
+        det_sincos((double)pitch, s, c);
+        A.ypsc[2] = (float)c;
+        A.ypsc[3] = (float)s;
+      } else {
+        float n2 = 2.0f * (qw * qz + qx * qy);
+        double d2 = 1.0 - (double)(2.0f * (qy * qy + qz * qz));
+        float yaw = (float)det_atan2((double)n2, d2);
+        A.rpy[2] = yaw;
+        double s, c;
+        det_sincos((double)yaw, s, c);
+        A.ypsc[0] = (float)c;
+        A.ypsc[1] = (float)s;
+      }
+    } else if (tid == 64) {
+      // swing-leg elimination tables (SolverMPC.cpp:589-637): a leg-step survives iff its Fz bound f_max*gait is not ~0
+      int nv = 0, nl = 0;
+      for (int i = 0; i < h; ++i) {
+        float ubL = args.f_max * (float)gait[2 * i], ubR = args.f_max * (float)gait[2 * i + 1];
+        const bool sL = !(ubL < 0.0001 && ubL > -.0001), sR = !(ubR < 0.0001 && ubR > -.0001);
+        const int nst = (int)sL + (int)sR;
+        for (int c = 0; c < 12; ++c) S.rmap[12 * i + c] = 255;
+        if (nv + 6 * nst <= NMAX) {
+          int k = 0;
+          for (int c = 0; c < 12; ++c) {
+            const int leg = (c / 3) & 1;
+            if (leg == 0 ? sL : sR) {
+              S.vstep[nv + k] = (unsigned char)i;
+              S.vcomp[nv + k] = (unsigned char)c;
+              S.rmap[12 * i + c] = (unsigned char)(nv + k);
+              ++k;
+            }
+          }
+          int rank = 0;
+          for (int leg = 0; leg < 2; ++leg)
+            if (leg == 0 ? sL : sR) {
+              S.ls_step[nl] = (unsigned char)i;
+              S.ls_leg[nl] = (unsigned char)leg;
+              S.ls_vF[nl] = (unsigned char)(nv + 3 * rank);
+              S.ls_vM[nl] = (unsigned char)(nv + 3 * nst + 3 * rank);
+              S.ub7[nl] = (double)(leg == 0 ? ubL : ubR);
+              ++nl;
+              ++rank;
+            }
+        }
+        nv += 6 * nst;
+      }
+      S.n = nv;
+      S.nls = nl;
+      S.m = 8 * nl;
+    }
+  }
+  __syncthreads();
+
+  // ---------------- A2: scalar algebra on one lane (RobotState.cpp:17-47, SolverMPC.cpp:65-89,302-331,420-433,488-548)
+  if (tid == 0) {
+    const float qw = in_q[0], qx = in_q[1], qy = in_q[2], qz = in_q[3];
+    float R[9], Rt[9];
+    {
+      float tx = 2.0f * qx, ty = 2.0f * qy, tz = 2.0f * qz;
+      float twx = tx * qw, twy = ty * qw, twz = tz * qw;
+      float txx = tx * qx, txy = ty * qx, txz = tz * qx;
+      float tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+      R[0] = 1.0f - (tyy + tzz);
+      R[1] = txy - twz;
+      R[2] = txz + twy;
+      R[3] = txy + twz;
+      R[4] = 1.0f - (txx + tzz);
+      R[5] = tyz - twx;
+      R[6] = txz - twy;
+      R[7] = tyz + twx;
+      R[8] = 1.0f - (txx + tyy);
+    }
+    float Rbi[9];
+    {
+      const float cy = A.ypsc[0], sy = A.ypsc[1], cp = A.ypsc[2], sp = A.ypsc[3];
+      float Rb[9] = {cy * cp, -sy, 0.0f, sy * cp, cy, 0.0f, -sp, 0.0f, 1.0f};
+      inverse3(Rb, Rbi);
+    }
+    for (int i = 0; i < 3; ++i) {
+      A.x0[i] = A.rpy[i];
+      A.x0[3 + i] = in_p[i];
+      A.x0[6 + i] = in_w[i];
+      A.x0[9 + i] = in_v[i];
+    }
+    A.x0[12] = 9.81f;
+    const float Ib[3] = {0.5413f, 0.5200f, 0.0691f};
+    float RI[9], Iw[9], Iinv[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        RI[i * 3 + k] = R[i * 3 + k] * Ib[k];
+        Rt[k * 3 + i] = R[i * 3 + k];
+      }
+    chain_mm<3, 3, 3>(RI, Rt, Iw);
+    inverse3(Iw, Iinv);
+    for (int i = 0; i < 9; ++i) A.R[i] = R[i], A.Rt[i] = Rt[i];
+
+    // continuous model -> forward Euler (SolverMPC.cpp:312-331, 145-146); mass 9.0 (:423)
+    const float dt = args.dt;
+    for (int i = 0; i < 169; ++i) A.Acd[i] = (i % 14 == 0) ? 1.0f : 0.0f;  // fl(delta + dt*0) = delta
+    for (int i = 0; i < 156; ++i) A.Bcd[i] = 0.0f;                          // fl(dt*0) = 0
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) A.Acd[i * 13 + 6 + j] = 0.0f + dt * Rbi[i * 3 + j];
+    for (int i = 0; i < 3; ++i) A.Acd[(3 + i) * 13 + 9 + i] = 0.0f + dt * 1.0f;
+    A.Acd[11 * 13 + 12] = 0.0f + dt * -1.0f;
+    const float inv_m = 1.0f / 9.0f;
+    for (int leg = 0; leg < 2; ++leg) {
+      const float r0 = in_r[0 + leg], r1 = in_r[2 + leg], r2 = in_r[4 + leg];
+      float cm[9] = {0.0f, -r2, r1, r2, 0.0f, -r0, -r1, r0, 0.0f};
+      float blk[9];
+      chain_mm<3, 3, 3>(Iinv, cm, blk);
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          A.Bcd[(6 + i) * 12 + 3 * leg + j] = dt * blk[i * 3 + j];
+          A.Bcd[(6 + i) * 12 + 6 + 3 * leg + j] = dt * Iinv[i * 3 + j];
+        }
+      for (int i = 0; i < 3; ++i) A.Bcd[(9 + i) * 12 + 3 * leg + i] = dt * inv_m;
+    }
+    for (int s = 0; s < 12; ++s) A.W[s] = in_wt[s];
+    A.W[12] = 0.0f;
+
+    // foot rotations Rz(q0)Rx(q1)Ry(q2)Ry(q3)Ry(q4) and the 16x12 constraint block (SolverMPC.cpp:426-433, 488-548)
+    const float mu = 2.0f, lt = 0.09f, lh = 0.06f;
+    for (int i = 0; i < 192; ++i) A.Fc[i] = 0.0f;
+    for (int leg = 0; leg < 2; ++leg) {
+      const int b = 5 * leg;
+      const float s0 = A.sc[b][0], c0 = A.sc[b][1], s1 = A.sc[b + 1][0], c1 = A.sc[b + 1][1];
+      const float s2 = A.sc[b + 2][0], c2 = A.sc[b + 2][1], s3 = A.sc[b + 3][0], c3 = A.sc[b + 3][1];
+      const float s4 = A.sc[b + 4][0], c4 = A.sc[b + 4][1];
+      const float s234 = A.sc234[leg][0], c234 = A.sc234[leg][1];
+      float a = c0 * s2 + (c2 * s0) * s1;
+      float bb = c0 * c2 - (s0 * s1) * s2;
+      float d = c2 * s0 + (c0 * s1) * s2;
+      float e = s0 * s2 - (c0 * c2) * s1;
+      float ca3 = c3 * a + s3 * bb, sa3 = s3 * a - c3 * bb;
+      float cd3 = c3 * d - s3 * e, sd3 = s3 * d + c3 * e;
+      float Rf[9];
+      Rf[0] = -(s4 * ca3) - c4 * sa3;
+      Rf[1] = -(c1 * s0);
+      Rf[2] = c4 * ca3 - s4 * sa3;
+      Rf[3] = c4 * cd3 - s4 * sd3;
+      Rf[4] = c0 * c1;
+      Rf[5] = c4 * sd3 + s4 * cd3;
+      Rf[6] = -(s234 * c1);
+      Rf[7] = s1;
+      Rf[8] = c234 * c1;
+      float col0[3], col1[3], vlt[3], vlh[3], t0[3], t1[3], flt[3], flh[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        col0[k] = Rf[k * 3 + 0];
+        col1[k] = Rf[k * 3 + 1];
+        vlt[k] = -lt * Rf[k * 3 + 2];
+        vlh[k] = -lh * Rf[k * 3 + 2];
+      }
+      chain_mm<1, 3, 3>(col0, Rt, t0);
+      chain_mm<1, 3, 3>(col1, Rt, t1);
+      chain_mm<1, 3, 3>(vlt, Rt, flt);
+      chain_mm<1, 3, 3>(vlh, Rt, flh);
+      float *row = A.Fc + (8 * leg) * 12;
+      const int cf = 3 * leg, cmo = 6 + 3 * leg;
+      row[0 * 12 + cf + 0] = -mu, row[0 * 12 + cf + 2] = 1.0f;
+      row[1 * 12 + cf + 0] = mu, row[1 * 12 + cf + 2] = 1.0f;
+      row[2 * 12 + cf + 1] = -mu, row[2 * 12 + cf + 2] = 1.0f;
+      row[3 * 12 + cf + 1] = mu, row[3 * 12 + cf + 2] = 1.0f;
+      for (int j = 0; j < 3; ++j) {
+        row[4 * 12 + cmo + j] = t0[j];
+        row[5 * 12 + cf + j] = flt[j];
+        row[5 * 12 + cmo + j] = t1[j];
+        row[6 * 12 + cf + j] = flh[j];
+        row[6 * 12 + cmo + j] = (leg == 0) ? -t1[j] : t1[j];
+      }
+      row[7 * 12 + cf + 2] = 2.0f;
+      // per-leg 8x6 constraint normals in binary64 (columns: F then M of this leg)
+      for (int rr = 0; rr < 8; ++rr)
+        for (int k = 0; k < 3; ++k) {
+          S.Cn[leg][rr][k] = (double)row[rr * 12 + cf + k];
+          S.Cn[leg][rr][3 + k] = (double)row[rr * 12 + cmo + k];
+        }
+    }
+  }
+  // identity power
+  for (int t = tid; t < 169; t += NT) A.Apow[t] = (t % 14 == 0) ? 1.0f : 0.0f;
+  __syncthreads();
+
+  const int n = S.n, m = S.m, nls = S.nls;
+  if (n > NMAX) {  // uniform
+    if (!ASM_ONLY) {
+      for (int t = tid; t < 12 * h; t += NT) args.forces[(size_t)inst * 12 * h + t] = 0.0f;
+      if (tid == 0) args.status[inst] = S_TOO_LARGE;
+    } else if (tid == 0) {
+      args.dbg_i[0] = n;
+      args.dbg_i[1] = m;
+    }
+    return;
+  }
+
+  // ---------------- A3/A4: Acd^k by repeated right-multiplication from the identity (SolverMPC.cpp:148-158), and from each
+  // power as it appears: Phi_k = Acd^k Bcd (:161-178), SPhi = fl(w_s Phi) (B'S first, as B'*S*B evaluates left to right),
+  // tracking error e_i = Acd^(i+1) x0 - X_d (:457-461, :570).  Only two powers are kept (ping-pong).
+  for (int k = 0; k <= h; ++k) {
+    const float *Pk = A.Apow + (k & 1) * 169;
+    float *Pn = A.Apow + ((k + 1) & 1) * 169;
+    for (int t = tid; t < 169 + 156 + 13; t += NT) {
+      if (t < 169) {
+        if (k < h) {
+          const int i = t / 13, j = t % 13;
+          float acc = 0.0f;
+#pragma unroll
+          for (int mm = 0; mm < 13; ++mm) acc = ffma(Pk[i * 13 + mm], A.Acd[mm * 13 + j], acc);
+          Pn[t] = acc;
+        }
+      } else if (t < 325) {
+        if (k < h) {
+          const int rem = t - 169, i = rem / 12, j = rem % 12;
+          float acc = 0.0f;
+#pragma unroll
+          for (int mm = 0; mm < 13; ++mm) acc = ffma(Pk[i * 13 + mm], A.Bcd[mm * 12 + j], acc);
+          A.Phi[k * 156 + rem] = acc;
+          A.SPhi[k * 156 + rem] = A.W[i] * acc;
+        }
+      } else if (k >= 1) {
+        const int s = t - 325, i = k - 1;
+        float acc = 0.0f;
+#pragma unroll
+        for (int mm = 0; mm < 13; ++mm) acc = ffma(Pk[s * 13 + mm], A.x0[mm], acc);
+        const float xd = (s < 12) ? in_traj[12 * i + s] : 0.0f;
+        A.e[13 * i + s] = acc - xd;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---------------- A5: g = 2 (B'S) e and H = 2(B'S B + alpha) (SolverMPC.cpp:569-570) ----------------
+  if (tid < n) {
+    const int a = S.vstep[tid], c = S.vcomp[tid];
+    float acc = 0.0f;
+    for (int i = a; i < h; ++i) {
+      const float *sp = A.SPhi + (i - a) * 156 + c;
+      const float *ep = A.e + 13 * i;
+#pragma unroll
+      for (int s = 0; s < 13; ++s) acc = ffma(sp[s * 12], ep[s], acc);
+    }
+    S.g[tid] = (double)(2.0f * acc);
+  }
+  {
+    // matrix cores: 16x16 output tiles over the reduced variables, K runs over (step i ascending, state row s ascending).
+    // Rows of B_qp above the block diagonal are exact zeros, which are bitwise neutral in an fmaf chain started at +0,
+    // so operands before a variable's own step are fed as 0 and the chain starts at the tile's first live step.
+    // The weight of state row 12 is 0 (SolverMPC.cpp:453) -> that row is neutral too and K = 12 = 3 x k4.
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int nti = (n + 15) >> 4;
+    const int ntiles = nti * (nti + 1) / 2;
+    const int l15 = ln & 15, kq = ln >> 4;
+    for (int idx = wv; idx < ntiles; idx += NW) {
+      int J = 0;
+      while ((J + 1) * (J + 2) / 2 <= idx) ++J;
+      const int I = idx - J * (J + 1) / 2;
+      const int ra = 16 * I + l15, cb = 16 * J + l15;
+      const bool rav = ra < n, cbv = cb < n;
+      const int sa = rav ? S.vstep[ra] : 0, ca = rav ? S.vcomp[ra] : 0;
+      const int sb = cbv ? S.vstep[cb] : 0, cc = cbv ? S.vcomp[cb] : 0;
+      const int istart = S.vstep[16 * J];
+      f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int i = istart; i < h; ++i) {
+        const bool la = rav && i >= sa, lb = cbv && i >= sb;
+        const float *pa = A.SPhi + (la ? (i - sa) * 156 + ca : 0);
+        const float *pb = A.Phi + (lb ? (i - sb) * 156 + cc : 0);
+#pragma unroll
+        for (int k4 = 0; k4 < 3; ++k4) {
+          const int s = 4 * k4 + kq;
+          const float av = la ? pa[s * 12] : 0.0f;
+          const float bv = lb ? pb[s * 12] : 0.0f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int Rr = 16 * I + kq * 4 + rg, Cc = 16 * J + l15;
+        if (Rr <= Cc && Cc < n) {
+          const float al = (Rr == Cc) ? in_al[S.vcomp[Rr]] : 0.0f;
+          const float hv = 2.0f * (acc[rg] + al);
+          S.sq[Rr * LD + Cc] = (double)hv;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  if (ASM_ONLY) {
+    using DL = DbgLayout<NMAX>;
+    float *o = args.dbg_f;
+    if (tid == 0) {
+      args.dbg_i[0] = n;
+      args.dbg_i[1] = m;
+    }
+    for (int t = tid; t < n; t += NT) {
+      args.dbg_i[2 + t] = 12 * S.vstep[t] + S.vcomp[t];
+      o[DL::G + t] = (float)S.g[t];
+    }
+    for (int t = tid; t < n * n; t += NT) {
+      const int i = t / n, j = t % n;
+      o[DL::H + t] = (float)Mref(S, i, j);
+    }
+    for (int t = tid; t < 192; t += NT) o[DL::FC + t] = A.Fc[t];
+    const float big = 5e10f;
+    for (int t = tid; t < 16 * h; t += NT) {
+      const int i = t / 16, rr = t % 8, leg = (t % 16) / 8;
+      float lbv, ubv;
+      if (rr < 4) lbv = 0.0f, ubv = big;
+      else if (rr == 4) lbv = 0.0f, ubv = 0.01f;
+      else if (rr < 7) lbv = -big, ubv = 0.0f;
+      else lbv = 0.0f, ubv = args.f_max * (float)gait[2 * i + leg];
+      o[DL::LB + t] = lbv;
+      o[DL::UB + t] = ubv;
+    }
+    for (int t = tid; t < 13; t += NT) o[DL::X0 + t] = A.x0[t];
+    for (int t = tid; t < 169; t += NT) o[DL::ACD + t] = A.Acd[t];
+    for (int t = tid; t < 156; t += NT) o[DL::BCD + t] = A.Bcd[t];
+    return;
+  }
+
+  // =============================== S: M = H^-1 by symmetric sweeps, matrix in registers ===============================
+  // Thread t owns the TR x TC block (rows i0.., cols j0..) of the full symmetric matrix; the 240 blocks that intersect
+  // the upper triangle are enumerated pairwise by column-block (two column blocks share floor(tc/2)+1 row blocks).
+  // Sweep k:  d = a_kk, p = row k;  a_ij -= p_i p_j / d (i,j != k);  a_kj = p_j/d;  a_kk = -1/d.  After n sweeps a = -H^-1.
+  // The pivot row for sweep k+1 is published to LDS right after sweep k (double buffered) -> one barrier per sweep.
+  constexpr int TR = NMAX / 15, TC = NMAX / 30;
+  static_assert(TR * 15 == NMAX && TC * 30 == NMAX, "NMAX must be a multiple of 30");
+  {
+    int pa = 0;
+    while ((pa + 1) * (pa + 2) <= tid) ++pa;
+    const int rem = tid - pa * (pa + 1);
+    const bool owner = tid < 240;
+    const int tc = 2 * pa + (rem >= pa + 1 ? 1 : 0), tr = rem % (pa + 1);
+    const int i0 = owner ? tr * TR : NMAX, j0 = owner ? tc * TC : NMAX;  // non-owners sit outside the matrix
+    double a[TR][TC];
+#pragma unroll
+    for (int ii = 0; ii < TR; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < TC; ++jj) {
+        const int i = i0 + ii, j = j0 + jj;
+        a[ii][jj] = (i < n && j < n) ? Mref(S, i, j) : 0.0;
+      }
+    // publish pivot row 0
+    if (i0 == 0) {
+#pragma unroll
+      for (int jj = 0; jj < TC; ++jj)
+        if (j0 + jj < n) Q.piv[0][j0 + jj] = a[0][jj];
+    }
+    __syncthreads();  // also orders the tile loads above before M is overwritten below
+    for (int k = 0; k < n; ++k) {
+      const double *pv = Q.piv[k & 1];
+      double *pn = Q.piv[(k + 1) & 1];
+      const double d = pv[k];
+      const double invd = 1.0 / d;
+      double pi[TR], pj[TC], qi[TR];
+#pragma unroll
+      for (int ii = 0; ii < TR; ++ii) {
+        pi[ii] = (i0 + ii < n) ? pv[i0 + ii] : 0.0;
+        qi[ii] = pi[ii] * invd;
+      }
+#pragma unroll
+      for (int jj = 0; jj < TC; ++jj) pj[jj] = (j0 + jj < n) ? pv[j0 + jj] : 0.0;
+#pragma unroll
+      for (int ii = 0; ii < TR; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < TC; ++jj) a[ii][jj] = dfma(-qi[ii], pj[jj], a[ii][jj]);
+      // pivot row / column entries of this block get their closed-form values
+      const int kr = k - i0, kc = k - j0;
+      if (kr >= 0 && kr < TR) {
+#pragma unroll
+        for (int ii = 0; ii < TR; ++ii)
+          if (ii == kr) {
+#pragma unroll
+            for (int jj = 0; jj < TC; ++jj) a[ii][jj] = (jj == kc) ? -invd : pj[jj] * invd;
+          }
+      }
+      if (kc >= 0 && kc < TC) {
+#pragma unroll
+        for (int jj = 0; jj < TC; ++jj)
+          if (jj == kc) {
+#pragma unroll
+            for (int ii = 0; ii < TR; ++ii) a[ii][jj] = (ii == kr) ? -invd : qi[ii];
+          }
+      }
+      // publish row k+1 of the symmetric matrix: (k+1, j>=k+1) from the row owners, (j<k+1, k+1) from the column owners
+      const int k1 = k + 1;
+      if (k1 < n) {
+        const int r1 = k1 - i0, c1 = k1 - j0;
+        if (r1 >= 0 && r1 < TR) {
+#pragma unroll
+          for (int ii = 0; ii < TR; ++ii)
+            if (ii == r1) {
+#pragma unroll
+              for (int jj = 0; jj < TC; ++jj)
+                if (j0 + jj >= k1 && j0 + jj < n) pn[j0 + jj] = a[ii][jj];
+            }
+        }
+        if (c1 >= 0 && c1 < TC) {
+#pragma unroll
+          for (int jj = 0; jj < TC; ++jj)
+            if (jj == c1) {
+#pragma unroll
+              for (int ii = 0; ii < TR; ++ii)
+                if (i0 + ii < k1) pn[i0 + ii] = a[ii][jj];
+            }
+        }
+      }
+      __syncthreads();
+    }
+    // M = -a into the upper triangle (diagonal included)
+#pragma unroll
+    for (int ii = 0; ii < TR; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < TC; ++jj) {
+        const int i = i0 + ii, j = j0 + jj;
+        if (i <= j && j < n) S.sq[i * LD + j] = -a[ii][jj];
+      }
+  }
+  // solver state init
+  for (int t = tid; t < m; t += NT) {
+    Q.act[t] = 0;
+    Q.slot[t] = 0;
+  }
+  if (tid < n) Q.w[tid] = -S.g[tid];
+  __syncthreads();
+  matvec(S, Q.w, Q.xu, n);  // unconstrained minimiser x_u = -M g
+  if (tid < n) Q.x[tid] = Q.xu[tid];
+  __syncthreads();
+
+  // =============================== Q: dual active set (Goldfarb-Idnani, range-space form) ===============================
+  const double INF = __builtin_huge_val();
+  const double FEAS_TOL = 1e-9;
+  int q = 0, iters = 0, code = S_OK;
+  const int itmax = 4 * m + 16;
+
+  // slack of constraint row c on its tighter side; side = +1 lower bound, -1 upper bound
+  auto row_slack = [&](int c, const double *xv, int &side) -> double {
+    const int e = c >> 3, rr = c & 7;
+    const int leg = S.ls_leg[e], vF = S.ls_vF[e], vM = S.ls_vM[e];
+    const double *cn = S.Cn[leg][rr];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s = dfma(cn[k], xv[vF + k], s);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s = dfma(cn[3 + k], xv[vM + k], s);
+    double sl = INF, su = INF;
+    if (rr < 4) {
+      sl = s;
+    } else if (rr == 4) {
+      sl = s;
+      su = ((double)0.01f - s);
+    } else if (rr < 7) {
+      su = -s;
+    } else {
+      sl = s * 1.0;
+      const double ub = S.ub7[e];
+      su = (ub - s) / (ub > 1.0 ? ub : 1.0);  // scaled so that one absolute tolerance serves both sides
+    }
+    side = (sl <= su) ? 1 : -1;
+    return (sl <= su) ? sl : su;
+  };
+
+  for (int pass = 0; pass < 3 && code == S_OK; ++pass) {
+    // ---- main loop ----
+    while (true) {
+      double val = INF;
+      int idx = 0x7fffffff, side = 1;
+      if (tid < m && Q.act[tid] == 0) {
+        val = row_slack(tid, Q.x, side);
+        idx = tid;
+      }
+      int pidx = idx;
+      double pval = val;
+      block_argmin(Q, pval, pidx);
+      if (!(pval < -FEAS_TOL)) break;
+      if (iters >= itmax) {
+        code = S_MAXITER;
+        break;
+      }
+      // pivot constraint p and its signed normal n+ (6 entries on vars vFp.., vMp..)
+      const int p = pidx;
+      const int ep = p >> 3, rp = p & 7, legp = S.ls_leg[ep], vFp = S.ls_vF[ep], vMp = S.ls_vM[ep];
+      int sgi;
+      double sp = row_slack(p, Q.x, sgi);  // every thread recomputes the same value
+      const double ub_p = S.ub7[ep];
+      if (rp == 7 && sgi < 0) sp *= (ub_p > 1.0 ? ub_p : 1.0);  // undo the scaling: true slack ub - s
+      const double sg = (double)sgi;
+      double np[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) np[k] = sg * S.Cn[legp][rp][k];
+      double up = 0.0;
+      bool added = false;
+      while (!added) {
+        ++iters;
+        if (iters > itmax) {
+          code = S_MAXITER;
+          break;
+        }
+        // d_j = n_j' M n+  (36 MACs on the 6x6 sub-block of M), gamma = n+' M n+
+        if (tid <= q) {
+          double nj[6];
+          int vFj, vMj;
+          if (tid < q) {
+            const int c = Q.Wrow[tid], e = c >> 3, rr = c & 7, leg = S.ls_leg[e];
+            vFj = S.ls_vF[e], vMj = S.ls_vM[e];
+            const double sj = (double)Q.act[c];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) nj[k] = sj * S.Cn[leg][rr][k];
+          } else {
+            vFj = vFp, vMj = vMp;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) nj[k] = np[k];
+          }
+          double acc = 0.0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            const int ia = (a < 3) ? vFj + a : vMj + a - 3;
+            double t = 0.0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+              const int ib = (b < 3) ? vFp + b : vMp + b - 3;
+              t = dfma(Mref(S, ia, ib), np[b], t);
+            }
+            acc = dfma(nj[a], t, acc);
+          }
+          if (tid < q) Q.d[tid] = acc;
+          else Q.gamma = acc;
+        }
+        __syncthreads();
+        // r = E d
+        if (tid < q) {
+          double acc = 0.0;
+          for (int i = 0; i < q; ++i) acc = dfma(Eref(S, tid, i), Q.d[i], acc);
+          Q.r[tid] = acc;
+        }
+        __syncthreads();
+        // w = n+ - N_W' r, gathered per leg-step (its 8 rows touch only its own 6 variables)
+        if (tid < nls) {
+          const int e = tid, leg = S.ls_leg[e], vF = S.ls_vF[e], vM = S.ls_vM[e];
+          double acc[6] = {0, 0, 0, 0, 0, 0};
+          for (int rr = 0; rr < 8; ++rr) {
+            const int c = 8 * e + rr;
+            const int ac = Q.act[c];
+            if (ac != 0) {
+              const double coef = -(double)ac * Q.r[Q.slot[c]];
+#pragma unroll
+              for (int k = 0; k < 6; ++k) acc[k] = dfma(coef, S.Cn[leg][rr][k], acc[k]);
+            }
+          }
+          if (e == ep) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] += np[k];
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) Q.w[vF + k] = acc[k], Q.w[vM + k] = acc[3 + k];
+        }
+        __syncthreads();
+        matvec(S, Q.w, Q.z, n);  // primal step direction z = M (n+ - N_W' r)
+        double delta = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) delta = dfma(np[k], Q.z[vFp + k], delta);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) delta = dfma(np[3 + k], Q.z[vMp + k], delta);
+        const double gamma = Q.gamma;
+        // largest dual step keeping u >= 0
+        double t1 = INF;
+        int l = 0x7fffffff;
+        if (tid < q) {
+          const double rj = Q.r[tid];
+          if (rj > 1e-14) {
+            t1 = Q.u[tid] / rj;
+            l = tid;
+          }
+        }
+        block_argmin(Q, t1, l);
+        const bool dep = !(delta > 1e-12 * gamma);
+        const double t2 = dep ? INF : -sp / delta;
+        const double t = (t1 < t2) ? t1 : t2;
+        if (t == INF) {
+          code = S_INFEASIBLE;
+          break;
+        }
+        if (!dep && tid < n) Q.x[tid] = dfma(t, Q.z[tid], Q.x[tid]);
+        if (tid < q) Q.u[tid] = dfma(-t, Q.r[tid], Q.u[tid]);
+        up += t;
+        if (!dep) sp = dfma(t, delta, sp);
+        if (!dep && !(t1 < t2)) {
+          // full step: constraint p joins the working set; bordered update of E
+          const double idl = 1.0 / delta;
+          for (int t2i = tid; t2i < q * (q + 1) / 2; t2i += NT) {
+            int i = 0;
+            while ((i + 1) * (i + 2) / 2 <= t2i) ++i;
+            const int j = t2i - i * (i + 1) / 2;
+            double &ee = S.sq[(i + 1) * LD + j];
+            ee = dfma(Q.r[i] * idl, Q.r[j], ee);
+          }
+          if (tid < q) S.sq[(q + 1) * LD + tid] = -Q.r[tid] * idl;
+          if (tid == q) {
+            S.sq[(q + 1) * LD + q] = idl;
+            Q.u[q] = up;
+            Q.Wrow[q] = (unsigned char)p;
+            Q.act[p] = (signed char)sgi;
+            Q.slot[p] = (unsigned char)q;
+          }
+          ++q;
+          added = true;
+          __syncthreads();
+        } else {
+          // partial (or pure dual) step: constraint in slot l leaves; Schur-complement downdate of E, last slot -> l
+          if (tid < q) Q.col[tid] = Eref(S, tid, l);
+          __syncthreads();
+          const double iel = 1.0 / Q.col[l];
+          for (int t2i = tid; t2i < q * (q + 1) / 2; t2i += NT) {
+            int i = 0;
+            while ((i + 1) * (i + 2) / 2 <= t2i) ++i;
+            const int j = t2i - i * (i + 1) / 2;
+            if (i != l && j != l) {
+              double &ee = S.sq[(i + 1) * LD + j];
+              ee = dfma(-Q.col[i] * iel, Q.col[j], ee);
+            }
+          }
+          __syncthreads();
+          const int last = q - 1;
+          if (l != last) {
+            if (tid < last && tid != l) Eref(S, l, tid) = Eref(S, last, tid);
+            if (tid == l) Eref(S, l, l) = Eref(S, last, last);
+          }
+          if (tid == 0) {
+            const int cl = Q.Wrow[l];
+            Q.act[cl] = 0;
+            if (l != last) {
+              const int cm = Q.Wrow[last];
+              Q.Wrow[l] = (unsigned char)cm;
+              Q.slot[cm] = (unsigned char)l;
+              Q.u[l] = Q.u[last];
+            }
+          }
+          --q;
+          __syncthreads();
+        }
+      }
+      if (code != S_OK) break;
+    }
+    if (code != S_OK || q == 0) break;
+
+    // ---- refinement of the multipliers on the final working set: u += E (b_W - N_W x(u)), x(u) = x_u + M N_W' u ----
+    for (int it = 0; it < 3; ++it) {
+      if (tid < nls) {
+        const int e = tid, leg = S.ls_leg[e], vF = S.ls_vF[e], vM = S.ls_vM[e];
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int rr = 0; rr < 8; ++rr) {
+          const int c = 8 * e + rr;
+          const int ac = Q.act[c];
+          if (ac != 0) {
+            const double coef = (double)ac * Q.u[Q.slot[c]];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] = dfma(coef, S.Cn[leg][rr][k], acc[k]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Q.w[vF + k] = acc[k], Q.w[vM + k] = acc[3 + k];
+      }
+      __syncthreads();
+      matvec(S, Q.w, Q.z, n);
+      if (tid < n) Q.x[tid] = Q.xu[tid] + Q.z[tid];
+      __syncthreads();
+      if (it == 2) break;
+      if (tid < q) {
+        const int c = Q.Wrow[tid], e = c >> 3, rr = c & 7, leg = S.ls_leg[e], vF = S.ls_vF[e], vM = S.ls_vM[e];
+        const double sj = (double)Q.act[c];
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s = dfma(S.Cn[leg][rr][k], Q.x[vF + k], s);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s = dfma(S.Cn[leg][rr][3 + k], Q.x[vM + k], s);
+        double bnd;
+        if (sj > 0) bnd = 0.0;                                   // every finite lower bound is 0
+        else bnd = (rr == 4) ? (double)0.01f : (rr == 7 ? S.ub7[e] : 0.0);
+        Q.d[tid] = sj * (bnd - s);  // b_j - n_j' x with n_j = sj*a_j, b_j = sj*bound
+      }
+      __syncthreads();
+      if (tid < q) {
+        double acc = 0.0;
+        for (int i = 0; i < q; ++i) acc = dfma(Eref(S, tid, i), Q.d[i], acc);
+        Q.r[tid] = acc;
+      }
+      __syncthreads();
+      if (tid < q) Q.u[tid] += Q.r[tid];
+      __syncthreads();
+    }
+    // a refinement that moved x across another constraint sends us back into the main loop (rare)
+  }
+
+  // final KKT check: primal slack and multiplier signs
+  __syncthreads();
+  {
+    double val = INF;
+    int idx = 0x7fffffff, side;
+    if (tid < m && Q.act[tid] == 0) {
+      val = row_slack(tid, Q.x, side);
+      idx = tid;
+    }
+    block_argmin(Q, val, idx);
+    __syncthreads();
+    double umin = INF;
+    int ui = 0x7fffffff;
+    if (tid < q) umin = Q.u[tid], ui = tid;
+    block_argmin(Q, umin, ui);
+    if (code == S_OK && (val < -1e-6 || umin < -1e-6)) code = S_KKT;
+  }
+
+  // ---------------- output: scatter to the reference's 12h layout, eliminated variables exactly 0 (SolverMPC.cpp:720-732)
+  for (int t = tid; t < 12 * h; t += NT) {
+    const int rmp = S.rmap[t];
+    const double xv = (rmp == 255) ? 0.0 : Q.x[rmp];
+    args.forces[(size_t)inst * 12 * h + t] = (float)xv;
+    if (args.x64) args.x64[(size_t)inst * 12 * h + t] = xv;
+  }
+  if (tid == 0) {
+    args.status[inst] = (uint32_t)code | ((uint32_t)(iters & 0xfff) << 8) | ((uint32_t)(q & 0xfff) << 20);
+    if (args.obj64) {
+      // objective through the KKT identity  0.5 x'Hx + g'x = 0.5 g'x + 0.5 u'b_W  (H itself was consumed by the sweeps)
+      double o = 0.0;
+      for (int i = 0; i < n; ++i) o = dfma(0.5 * S.g[i], Q.x[i], o);
+      for (int j = 0; j < q; ++j) {
+        const int c = Q.Wrow[j], rr = c & 7;
+        const double sj = (double)Q.act[c];
+        const double bnd = (sj > 0) ? 0.0 : ((rr == 4) ? (double)0.01f : (rr == 7 ? S.ub7[c >> 3] : 0.0));
+        o = dfma(0.5 * Q.u[j], sj * bnd, o);
+      }
+      args.obj64[inst] = o;
+    }
+  }
+}
+
+}  // namespace hmpc

@@ -1,0 +1,155 @@
+"""Python mirror of the MPC boundary -- same names, argument meaning and error behaviour as the reference's
+``ConvexMPC/convexMPC_interface.h:39-43`` (``setup_problem`` / ``update_problem_data`` / ``get_solution`` /
+``update_solver_settings``) plus the batched handle API of ``include/hector_mpc.h``.
+
+Everything here is a thin ctypes call into ``libhector_mpc_hip.so``; there is no Python/NumPy/PyTorch compute path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, records
+
+STATUS_NAMES = {0: "ok", 1: "max_iter", 2: "infeasible", 3: "too_large", 4: "kkt"}
+
+
+class HmpcError(RuntimeError):
+    pass
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise HmpcError(f"{what} failed with {rc}: {_lib.load().hmpc_last_hip_error().decode()}")
+
+
+# ---------------------------------------------------------------- reference (legacy) interface, process-global
+def setup_problem(dt: float, horizon: int, mu: float, f_max: float) -> None:
+    _lib.load().setup_problem(float(dt), int(horizon), float(mu), float(f_max))
+
+
+def update_problem_data(p, v, q, w, r, joint_angles, yaw, weights, state_trajectory, Alpha_K, gait) -> None:
+    """Blocking: narrows to float, solves on the GPU, leaves the solution for ``get_solution`` (as the reference does)."""
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (p, v, q, w, r, joint_angles)]
+    b = [np.ascontiguousarray(x, dtype=np.float64) for x in (weights, state_trajectory, Alpha_K)]
+    g = np.ascontiguousarray(gait, dtype=np.int32)
+    _lib.load().update_problem_data(*[x.ctypes.data for x in a], float(yaw), *[x.ctypes.data for x in b], g.ctypes.data)
+
+
+def get_solution(index: int) -> float:
+    return float(_lib.load().get_solution(int(index)))
+
+
+def update_solver_settings(max_iter, rho, sigma, solver_alpha, terminate, use_jcqp) -> None:
+    _lib.load().update_solver_settings(int(max_iter), float(rho), float(sigma), float(solver_alpha), float(terminate),
+                                       float(use_jcqp))
+
+
+def last_status() -> int:
+    return int(_lib.load().hmpc_last_status())
+
+
+# ---------------------------------------------------------------- batched handle API
+class BatchedMPC:
+    """One handle = one GPU, one (dt, f_max, horizon) problem shape, up to ``max_batch`` independent MPC instances."""
+
+    def __init__(self, dt: float, horizon: int, f_max: float, max_batch: int, mu: float = 0.25, device: int = 0):
+        self.L = _lib.load()
+        self.horizon, self.max_batch, self.device = int(horizon), int(max_batch), int(device)
+        self.setup = _lib.ProblemSetup(np.float32(dt), np.float32(mu), np.float32(f_max), int(horizon))
+        self.h = C.c_void_p()
+        _check(self.L.hmpc_create(C.byref(self.h), C.byref(self.setup), self.max_batch, self.device), "hmpc_create")
+        self.stride = int(self.L.hmpc_record_stride(self.horizon))
+        self._keep = None
+        self._keep_out = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hmpc_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def batch(self) -> int:
+        return int(self.L.hmpc_batch(self.h))
+
+    def upload(self, recs: np.ndarray) -> None:
+        recs = np.ascontiguousarray(recs, dtype=np.uint8)
+        assert recs.ndim == 2 and recs.shape[1] == self.stride, (recs.shape, self.stride)
+        _check(self.L.hmpc_upload_records(self.h, recs.ctypes.data, recs.shape[0]), "hmpc_upload_records")
+
+    def upload_fields(self, fields: dict) -> None:
+        self.upload(records.pack_records(fields, self.horizon))
+
+    def set_device_records(self, device_ptr: int, batch: int, max_reduced_vars: int = -1, keepalive=None) -> None:
+        self._keep = keepalive
+        _check(self.L.hmpc_set_device_records(self.h, C.c_void_p(device_ptr), int(batch)), "hmpc_set_device_records")
+        _check(self.L.hmpc_set_max_reduced_vars(self.h, int(max_reduced_vars)), "hmpc_set_max_reduced_vars")
+
+    def set_device_outputs(self, forces_ptr: int, status_ptr: int, keepalive=None) -> None:
+        self._keep_out = keepalive
+        _check(self.L.hmpc_set_device_outputs(self.h, C.c_void_p(forces_ptr), C.c_void_p(status_ptr)),
+               "hmpc_set_device_outputs")
+
+    def solve(self, stream: int = 0) -> None:
+        _check(self.L.hmpc_solve(self.h, C.c_void_p(stream)), "hmpc_solve")
+
+    def download(self):
+        b = self.batch
+        forces = np.zeros((b, 12 * self.horizon), dtype=np.float32)
+        status = np.zeros(b, dtype=np.uint32)
+        _check(self.L.hmpc_download(self.h, forces.ctypes.data, status.ctypes.data), "hmpc_download")
+        return forces, status
+
+    def download_f64(self):
+        b = self.batch
+        x = np.zeros((b, 12 * self.horizon), dtype=np.float64)
+        obj = np.zeros(b, dtype=np.float64)
+        _check(self.L.hmpc_download_f64(self.h, x.ctypes.data, obj.ctypes.data), "hmpc_download_f64")
+        return x, obj
+
+    def time_solve(self, reps: int, stream: int = 0) -> float:
+        ms = C.c_float(0)
+        _check(self.L.hmpc_time_solve(self.h, C.c_void_p(stream), int(reps), C.byref(ms)), "hmpc_time_solve")
+        return float(ms.value)
+
+    def debug_assemble(self, index: int) -> dict:
+        """Assembly stage only (same device code the solve kernel runs) -> the reduced QP as the solver sees it."""
+        h = self.horizon
+        n, m = C.c_int(0), C.c_int(0)
+        var_ind = np.zeros(120, dtype=np.int32)
+        H = np.zeros(120 * 120, dtype=np.float32)
+        g = np.zeros(120, dtype=np.float32)
+        Fc = np.zeros(192, dtype=np.float32)
+        lb = np.zeros(16 * h, dtype=np.float32)
+        ub = np.zeros(16 * h, dtype=np.float32)
+        x0 = np.zeros(13, dtype=np.float32)
+        Acd = np.zeros(169, dtype=np.float32)
+        Bcd = np.zeros(156, dtype=np.float32)
+        _check(self.L.hmpc_debug_assemble(self.h, int(index), C.byref(n), C.byref(m), var_ind.ctypes.data,
+                                          H.ctypes.data, g.ctypes.data, Fc.ctypes.data, lb.ctypes.data,
+                                          ub.ctypes.data, x0.ctypes.data, Acd.ctypes.data, Bcd.ctypes.data),
+               "hmpc_debug_assemble")
+        nn = n.value
+        if nn > 120:
+            return dict(n=nn, m=m.value)
+        return dict(n=nn, m=m.value, var_ind=var_ind[:nn].copy(), H=H[: nn * nn].reshape(nn, nn).copy(), g=g[:nn].copy(),
+                    Fc=Fc.reshape(16, 12), lb=lb, ub=ub, x0=x0, Acd=Acd.reshape(13, 13), Bcd=Bcd.reshape(13, 12))
+
+
+def status_code(status: np.ndarray) -> np.ndarray:
+    return (np.asarray(status) & 0xFF).astype(np.int32)
+
+
+def status_iters(status: np.ndarray) -> np.ndarray:
+    return ((np.asarray(status) >> 8) & 0xFFF).astype(np.int32)
+
+
+def status_nactive(status: np.ndarray) -> np.ndarray:
+    return ((np.asarray(status) >> 20) & 0xFFF).astype(np.int32)

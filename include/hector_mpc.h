@@ -1,0 +1,144 @@
+/*
+ * hector_mpc.h -- C ABI of libhector_mpc_hip.so: MI355X (gfx950) batched force-and-moment MPC QP solver for
+ * HECTOR's convex-MPC loop.  Plain pointers and sizes only; no torch / Eigen / C++ types cross this boundary.
+ *
+ * Two surfaces:
+ *  (1) the reference's own interface, byte-for-byte the same signatures, so hector_control links against this
+ *      library instead of its ConvexMPC/convexMPC_interface.cpp + SolverMPC.cpp + qpOASES and nothing else changes:
+ *        setup_problem / update_problem_data / get_solution / update_solver_settings
+ *            -> Hector_ROS_Simulation/hector_control/ConvexMPC/convexMPC_interface.h:39-43
+ *        solve_mpc(update_data_t*, problem_setup*), get_q_soln()   (C++ linkage in the reference)
+ *            -> ConvexMPC/SolverMPC.h:56,63    (exported here additionally as C symbols hmpc_solve_mpc / hmpc_get_q_soln
+ *               and, under the north-star name, solveDenseMPC)
+ *        problem_setup, update_data_t PODs -> ConvexMPC/convexMPC_interface.h:11-37
+ *  (2) a handle-based, re-entrant BATCHED interface (names are ours) over packed records
+ *      (hector_simulation_amd/records.py documents the layout; hmpc_pack_record builds one from the reference's
+ *      argument list).
+ *
+ * Every function returns 0 on success or a negative hmpc_error; nothing throws across this boundary
+ * (the reference throws std::runtime_error for horizon > 19, SolverMPC.cpp:140-143: here setup returns/records
+ * HMPC_E_HORIZON and get_solution keeps returning the previous values).
+ */
+#ifndef HECTOR_MPC_H
+#define HECTOR_MPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define K_MAX_GAIT_SEGMENTS 36 /* convexMPC_interface.h:3 */
+#define HMPC_MAX_HORIZON 20    /* device scratch is sized for this (reference: 10 hard-coded, cap 19) */
+#define HMPC_MAX_VARS 120      /* reduced QP variables (6 per stance leg-step) the LDS-resident solver holds */
+
+/* ---- reference PODs (convexMPC_interface.h:11-37), same field order and types ---- */
+struct problem_setup {
+  float dt;
+  float mu; /* ignored by the reference (mu = 2.0 is hard-coded, SolverMPC.cpp:488); ignored here too */
+  float f_max;
+  int horizon;
+};
+
+struct update_data_t {
+  float p[3];
+  float v[3];
+  float q[4];
+  float w[3];
+  float r[6];
+  float joint_angles[10];
+  float yaw;
+  float weights[12];
+  float traj[12 * K_MAX_GAIT_SEGMENTS];
+  float Alpha_K[12];
+  unsigned char gait[K_MAX_GAIT_SEGMENTS];
+  unsigned char hack_pad[1000];
+  int max_iterations;
+  double rho, sigma, solver_alpha, terminate;
+};
+
+/* ---- (1) reference interface, convexMPC_interface.h:39-43 ---- */
+void setup_problem(double dt, int horizon, double mu, double f_max);
+void update_problem_data(double *p, double *v, double *q, double *w, double *r, double *joint_angles, double yaw,
+                         double *weights, double *state_trajectory, double *Alpha_K, int *gait);
+double get_solution(int index);
+void update_solver_settings(int max_iter, double rho, double sigma, double solver_alpha, double terminate,
+                            double use_jcqp);
+/* SolverMPC.h:56,63 under C names (the C++-linkage solve_mpc/get_q_soln are exported too, see hmpc_capi) */
+void hmpc_solve_mpc(struct update_data_t *update, struct problem_setup *setup);
+void solveDenseMPC(struct update_data_t *update, struct problem_setup *setup);
+double *hmpc_get_q_soln(void);
+/* extra: status word of the last legacy solve (see HMPC_STATUS_*), never part of the reference */
+uint32_t hmpc_last_status(void);
+
+/* ---- (2) batched interface ---- */
+typedef struct hmpc_handle hmpc_handle;
+
+enum hmpc_error {
+  HMPC_OK = 0,
+  HMPC_E_ARG = -1,      /* null pointer / bad size */
+  HMPC_E_HORIZON = -2,  /* horizon < 1 or > HMPC_MAX_HORIZON */
+  HMPC_E_BATCH = -3,    /* batch > max_batch */
+  HMPC_E_HIP = -4,      /* HIP runtime error (hmpc_last_hip_error) */
+  HMPC_E_NO_DEVICE = -5 /* no gfx950 device visible: the library has NO CPU fallback */
+};
+
+/* per-instance status word written by the kernel: bits 0-7 code, 8-19 active-set iterations, 20-31 final |W| */
+#define HMPC_STATUS_CODE(s) ((s) & 0xffu)
+#define HMPC_STATUS_ITERS(s) (((s) >> 8) & 0xfffu)
+#define HMPC_STATUS_NACTIVE(s) (((s) >> 20) & 0xfffu)
+enum hmpc_status_code {
+  HMPC_S_OK = 0,
+  HMPC_S_MAXITER = 1,     /* iteration cap hit (reference analogue: nWSR = 500 exhausted) */
+  HMPC_S_INFEASIBLE = 2,  /* constraints inconsistent */
+  HMPC_S_TOO_LARGE = 3,   /* more than HMPC_MAX_VARS reduced variables (e.g. double support over h > 10) */
+  HMPC_S_KKT = 4          /* final KKT check outside tolerance */
+};
+
+size_t hmpc_record_stride(int horizon);  /* bytes per packed record: (54+12h)*4 + 2h rounded up to 16 */
+/* packs one record from the reference's update_problem_data argument list (double -> float, int -> u8 narrowing
+ * exactly as convexMPC_interface.cpp:83-103) */
+int hmpc_pack_record(void *record, int horizon, const double *p, const double *v, const double *q, const double *w,
+                     const double *r, const double *joint_angles, double yaw, const double *weights,
+                     const double *state_trajectory, const double *Alpha_K, const int *gait);
+
+int hmpc_create(hmpc_handle **out, const struct problem_setup *setup, int max_batch, int device);
+int hmpc_destroy(hmpc_handle *h);
+/* host records -> device (synchronous copy on the handle's stream) */
+int hmpc_upload_records(hmpc_handle *h, const void *host_records, int batch);
+/* use records that already live in HBM (no copy; pointer must stay valid until the solve finishes) */
+int hmpc_set_device_records(hmpc_handle *h, const void *device_records, int batch);
+/* optional: write forces/status into caller-owned device buffers instead of the handle's own */
+int hmpc_set_device_outputs(hmpc_handle *h, float *device_forces, uint32_t *device_status);
+/* asynchronous: enqueue assembly+solve of the current batch on `stream` (a hipStream_t, NULL = default stream) */
+int hmpc_solve(hmpc_handle *h, void *stream);
+/* waits for `stream` work, copies forces [batch][12h] float and status [batch] to host (either may be NULL) */
+int hmpc_download(hmpc_handle *h, float *forces, uint32_t *status);
+/* hint for device-resident records: the widest reduced QP (6 x stance leg-steps) in the batch, or -1 = unknown;
+ * picks the kernel variant (LDS footprint).  hmpc_upload_records derives it from the gait tables itself. */
+int hmpc_set_max_reduced_vars(hmpc_handle *h, int n_reduced);
+int hmpc_get_device_outputs(hmpc_handle *h, float **device_forces, uint32_t **device_status);
+int hmpc_batch(const hmpc_handle *h);
+int hmpc_horizon(const hmpc_handle *h);
+/* average kernel time in ms of `reps` back-to-back launches of the current batch measured with HIP events on
+ * `stream` (used by bench.py for the roofline object) */
+int hmpc_time_solve(hmpc_handle *h, void *stream, int reps, float *ms_per_launch);
+
+/* Parity hook: runs the ASSEMBLY stage only for instance `index` of the current batch (same device code the
+ * solve kernel runs) and returns the reduced QP exactly as the solver sees it: n, m, var_ind[n] (original
+ * variable index, SolverMPC.cpp:644-658), H[n*n] (float, row-major, symmetric), g[n], the 16x12 constraint
+ * block Fc, lb/ub[16h] (unreduced) and x0[13], Acd[169], Bcd[156].  Any output pointer may be NULL. */
+int hmpc_debug_assemble(hmpc_handle *h, int index, int *n, int *m, int *var_ind, float *H, float *g, float *Fc,
+                        float *lb, float *ub, float *x0, float *Acd, float *Bcd);
+/* Parity hook: double-precision primal solution [batch][12h] and per-instance dual objective of the last solve
+ * (debug copy-out; allocates on first use). */
+int hmpc_download_f64(hmpc_handle *h, double *x, double *obj);
+
+const char *hmpc_last_hip_error(void);
+const char *hmpc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

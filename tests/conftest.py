@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU oracle (oracle/): the checker.  Never imported by the product package."""
+    from oracle import oracle_py
+
+    oracle_py.lib()
+    return oracle_py
+
+
+@pytest.fixture(scope="session")
+def gpu_available():
+    import torch
+
+    return torch.cuda.is_available()
