@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC QP solves/sec (horizon=10, 2 contacts) of the HIP path, with roofline and CPU-baseline legs.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (assembly + QP solve, one kernel launch) over one batch of synthetic MPC
+instances whose packed records already live in HBM; for N > 1 every rank owns a contiguous shard of the global batch
+(weak scaling, per-GPU batch fixed) and the step ends with the all_gather (RCCL) of the solved forces.
+Rank 0 prints ONE JSON line.  Workload = the case BASELINE.json's metric string names: randomized 2-contact
+(standing gait) instances, horizon 10 -> 120 x 160 QPs (SURVEY.md section 8d "metric_2contact").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_SOLVE = {10: 1200, 20: 2180}   # (54+12h)*4 + 2h in, 12h*4 + 4 out
+MFLOP_PER_SOLVE = {10: 3.744, 20: 29.952}  # 2*(12h)^2*(13h) dense B'SB contraction
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3
+
+
+def cpu_worker(path: str, horizon: int, first: int, count: int) -> None:
+    """One CPU-baseline process: oracle assembly + the reference's qpOASES on records [first, first+count)."""
+    from hector_simulation_amd import synthetic
+    from oracle import oracle_py
+
+    rec = np.load(path)
+    t0 = time.perf_counter()
+    r = oracle_py.solve_records(rec, horizon, synthetic.DT_MPC, synthetic.F_MAX, first=first, count=count)
+    t1 = time.perf_counter()
+    print(json.dumps(dict(count=count, wall=t1 - t0, t_assemble=r["t_assemble"], t_solve=r["t_solve"],
+                          n_bad=int(r["n_bad"]), nwsr_med=float(np.median(r["nwsr"])), nwsr_max=int(r["nwsr"].max()))))
+
+
+def cpu_baseline(rec: np.ndarray, horizon: int, per_core: int) -> dict:
+    """Reference CPU path timed on the host cores as PROCESSES (qpOASES has a process-global message handler)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    per_core = max(1, min(per_core, rec.shape[0] // cores))
+    total = per_core * cores
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "records.npy")
+        np.save(path, rec[:total])
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(horizon),
+                                   str(c * per_core), str(per_core)], stdout=subprocess.PIPE, text=True)
+                 for c in range(cores)]
+        outs = [p.communicate()[0] for p in procs]
+        wall = time.perf_counter() - t0
+    res = [json.loads(o.strip().splitlines()[-1]) for o in outs]
+    inner = max(r["wall"] for r in res)  # slowest worker, excluding interpreter start-up
+    t_asm = sum(r["t_assemble"] for r in res)
+    t_sol = sum(r["t_solve"] for r in res)
+    return dict(value=total / inner, unit="QP solves/s", cores=cores, kind="port",
+                sample=f"{total} of the bench's 2-contact h={horizon} instances ({per_core}/process x {cores} processes); "
+                       f"oracle C restatement of the fp32 assembly + the reference's own vendored qpOASES 3.2.0 "
+                       f"(oracle/_ref), setToMPC, cold start; prints removed",
+                single_core_value=per_core / max(r["t_assemble"] + r["t_solve"] for r in res),
+                assemble_ms=1e3 * t_asm / total, solve_ms=1e3 * t_sol / total,
+                nwsr_median=float(np.median([r["nwsr_med"] for r in res])), nwsr_max=max(r["nwsr_max"] for r in res),
+                n_failed=sum(r["n_bad"] for r in res), wall_s=wall)
+
+
+def main() -> None:
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
+        return
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8192, help="MPC instances per GPU per step")
+    ap.add_argument("--horizon", type=int, default=10)
+    ap.add_argument("--gait", default="standing", help="standing = the metric's 2-contact case")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-per-core", type=int, default=384)
+    ap.add_argument("--check", type=int, default=32, help="instances checked against the oracle after the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from hector_simulation_amd import interface, records, synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the solve path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    h, B = args.horizon, args.batch
+    # every rank owns the contiguous shard [rank*B, (rank+1)*B) of the global batch (seed offset by rank)
+    fields = synthetic.make_batch(B, h, args.gait, seed=6 + 1000 * rank, phase="random")
+    rec = records.pack_records(fields, h)
+    n_red = 6 * int(np.asarray(fields["gait"]).reshape(B, -1).sum(axis=1).max())
+
+    dev = torch.device("cuda", local_rank)
+    d_rec = torch.from_numpy(rec).to(dev)                      # inputs resident in HBM before the timed region
+    d_forces = torch.zeros((B, 12 * h), dtype=torch.float32, device=dev)
+    d_status = torch.zeros((B,), dtype=torch.int32, device=dev)
+    gathered = torch.zeros((world * B, 12 * h), dtype=torch.float32, device=dev) if world > 1 else None
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, B, device=local_rank)
+    mpc.set_device_records(d_rec.data_ptr(), B, max_reduced_vars=n_red, keepalive=d_rec)
+    mpc.set_device_outputs(d_forces.data_ptr(), d_status.data_ptr(), keepalive=(d_forces, d_status))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        mpc.solve(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, d_forces)   # the path's only exchange: gather of solved forces
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # dominant kernel's own duration: HIP events on the launch stream, kernel launches only (no collective)
+    kernel_ms = mpc.time_solve(max(5, args.steps), stream)
+
+    status = d_status.cpu().numpy().astype(np.uint32)
+    n_fail = int((interface.status_code(status) != 0).sum())
+    iters = interface.status_iters(status)
+
+    if rank == 0:
+        total = world * B * args.steps
+        value = total / elapsed
+        bps = BYTES_PER_SOLVE.get(h, (54 + 12 * h) * 4 + 2 * h + 48 * h + 4)
+        mfl = MFLOP_PER_SOLVE.get(h, 2 * (12 * h) ** 2 * (13 * h) / 1e6)
+        ach_gbs = B * bps / (kernel_ms * 1e-3) / 1e9
+        ach_tf = B * mfl * 1e6 / (kernel_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):  # PMC-measured HBM bytes per solve from the committed rocprofv3 passes
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("horizon") == h and tj.get("gait") == args.gait:
+                    traffic = tj["bytes_per_solve"] * B
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MPC QP solves/sec (horizon=10, 2 contacts)" if (h == 10 and args.gait == "standing")
+                      else f"MPC QP solves/sec (horizon={h}, gait={args.gait})",
+            "value": value, "unit": "QP solves/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 assembly / f64 solve", "data": "synthetic",
+            "config": {"workload": f"{'2-contact standing' if args.gait == 'standing' else args.gait} randomized MPC ticks, "
+                                   f"horizon {h}, reduced QP up to {n_red}x{n_red // 6 * 8}",
+                       "batch_per_gpu": B, "global_batch": world * B, "horizon": h,
+                       "parallelism": f"batch shards x{world}, all_gather of forces" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "hmpc_kernel (fused assembly + QP solve)", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_solve": bps,
+                         "note": "neither HBM nor MFMA binds this path (SURVEY.md 8d): the limiter is the serial "
+                                 "active-set iteration inside one workgroup (LDS/VALU fp64 latency)"},
+            "roofline_mfma": {"bound": "mfma", "achieved": ach_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": ach_tf / MFMA_F32_PEAK_TF, "algorithmic_mflop_per_solve": mfl},
+            "solver": {"failed": n_fail, "iters_median": float(np.median(iters)), "iters_max": int(iters.max()),
+                       "kernel_solves_per_s": B / (kernel_ms * 1e-3)},
+        }
+        if args.check > 0:
+            from oracle import oracle_py  # checker only, after the timed region
+            nchk = min(args.check, B)
+            ref = oracle_py.solve_records(rec, h, synthetic.DT_MPC, synthetic.F_MAX, first=0, count=nchk)
+            f = d_forces[:nchk].cpu().numpy().astype(np.float64)
+            q = ref["q_soln"]
+            err = np.abs(f - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+            out["parity"] = {"checked": nchk, "max_rel_force_err_vs_qpoases": float(err.max()),
+                             "qpoases_failed": int(ref["n_bad"])}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rec, h, args.cpu_per_core)
+        print(json.dumps(out), flush=True)
+    mpc.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
