@@ -93,7 +93,7 @@ def main() -> None:
     import torch
     import torch.distributed as dist
 
-    from hector_simulation_amd import interface, records, synthetic
+    from hector_simulation_amd import interface, records, sharding, synthetic
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -110,6 +110,7 @@ def main() -> None:
 
     h, B = args.horizon, args.batch
     # every rank owns the contiguous shard [rank*B, (rank+1)*B) of the global batch (seed offset by rank)
+    assert sharding.shard_bounds(world * B, world, rank) == (rank * B, (rank + 1) * B)
     fields = synthetic.make_batch(B, h, args.gait, seed=6 + 1000 * rank, phase="random")
     rec = records.pack_records(fields, h)
     n_red = 6 * int(np.asarray(fields["gait"]).reshape(B, -1).sum(axis=1).max())
@@ -118,7 +119,6 @@ def main() -> None:
     d_rec = torch.from_numpy(rec).to(dev)                      # inputs resident in HBM before the timed region
     d_forces = torch.zeros((B, 12 * h), dtype=torch.float32, device=dev)
     d_status = torch.zeros((B,), dtype=torch.int32, device=dev)
-    gathered = torch.zeros((world * B, 12 * h), dtype=torch.float32, device=dev) if world > 1 else None
     mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, B, device=local_rank)
     mpc.set_device_records(d_rec.data_ptr(), B, max_reduced_vars=n_red, keepalive=d_rec)
     mpc.set_device_outputs(d_forces.data_ptr(), d_status.data_ptr(), keepalive=(d_forces, d_status))
@@ -127,7 +127,7 @@ def main() -> None:
     def step():
         mpc.solve(stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, d_forces)   # the path's only exchange: gather of solved forces
+            sharding.gather_forces(d_forces, world * B)   # the path's only exchange: gather of solved forces
 
     for _ in range(args.warmup):
         step()

@@ -14,7 +14,7 @@ EXPORTS = [
     "hmpc_get_q_soln", "hmpc_last_status", "hmpc_record_stride", "hmpc_pack_record", "hmpc_create", "hmpc_destroy",
     "hmpc_upload_records", "hmpc_set_device_records", "hmpc_set_max_reduced_vars", "hmpc_set_device_outputs",
     "hmpc_solve", "hmpc_download", "hmpc_get_device_outputs", "hmpc_batch", "hmpc_horizon", "hmpc_time_solve",
-    "hmpc_debug_assemble", "hmpc_download_f64", "hmpc_last_hip_error", "hmpc_version",
+    "hmpc_debug_assemble", "hmpc_debug_phase_cycles", "hmpc_download_f64", "hmpc_last_hip_error", "hmpc_version",
 ]
 
 
@@ -75,6 +75,7 @@ def load():
     L.hmpc_time_solve.argtypes = [vp, vp, ci, C.POINTER(cf)]
     L.hmpc_debug_assemble.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)] + [vp] * 9
     L.hmpc_download_f64.argtypes = [vp, vp, vp]
+    L.hmpc_debug_phase_cycles.argtypes = [vp, vp]
     L.hmpc_last_hip_error.restype = C.c_char_p
     L.hmpc_version.restype = C.c_char_p
     _lib = L

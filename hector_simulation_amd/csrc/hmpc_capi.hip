@@ -67,6 +67,7 @@ struct hmpc_handle {
   double *d_x64, *d_obj64;
   float *d_dbg_f;
   int *d_dbg_i;
+  long long *d_prof;
   int max_stance;  // max reduced variables of the current batch (known only for host-uploaded records; else -1)
   hipStream_t last_stream;
   bool attrs_set[N_VARIANTS];
@@ -110,6 +111,7 @@ static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int db
   a.dbg_index = dbg_index;
   a.dbg_f = h->d_dbg_f;
   a.dbg_i = h->d_dbg_i;
+  a.prof = h->d_prof;
   const int grid = assemble_only ? 1 : h->batch;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(hmpc::NT), v.smem, stream, a);
   HIP_TRY(hipGetLastError());
@@ -185,6 +187,7 @@ int hmpc_destroy(hmpc_handle *h) {
   if (h->d_obj64) hipFree(h->d_obj64);
   if (h->d_dbg_f) hipFree(h->d_dbg_f);
   if (h->d_dbg_i) hipFree(h->d_dbg_i);
+  if (h->d_prof) hipFree(h->d_prof);
   delete h;
   return HMPC_OK;
 }
@@ -322,6 +325,28 @@ int hmpc_debug_assemble(hmpc_handle *h, int index, int *n, int *m, int *var_ind,
   if (Acd) memcpy(Acd, hf.data() + oACD, sizeof(float) * 169);
   if (Bcd) memcpy(Bcd, hf.data() + oBCD, sizeof(float) * 156);
   return HMPC_OK;
+}
+
+int hmpc_debug_phase_cycles(hmpc_handle *h, long long *cycles /*[batch][16]*/) {
+#ifndef HMPC_PROFILE
+  (void)h;
+  (void)cycles;
+  g_hip_err = "library built without -DHMPC_PROFILE";
+  return HMPC_E_ARG;
+#else
+  if (!h || !cycles) return HMPC_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t nb = (size_t)h->max_batch * hmpc::NPROF * sizeof(long long);
+  if (!h->d_prof) HIP_TRY(hipMalloc(&h->d_prof, nb));
+  HIP_TRY(hipMemset(h->d_prof, 0, nb));
+  int rc = launch(h, h->last_stream, false, 0);
+  if (rc != HMPC_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
+  HIP_TRY(hipMemcpy(cycles, h->d_prof, (size_t)h->batch * hmpc::NPROF * sizeof(long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipFree(h->d_prof));
+  h->d_prof = nullptr;
+  return HMPC_OK;
+#endif
 }
 
 int hmpc_download_f64(hmpc_handle *h, double *x, double *obj) {

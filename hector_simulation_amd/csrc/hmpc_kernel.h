@@ -36,7 +36,19 @@ struct KernelArgs {
   int dbg_index;
   float *dbg_f;
   int *dbg_i;
+  long long *prof;  // optional [batch][HMPC_NPROF] per-phase shader-clock cycles (thread 0's view), profiling builds only
 };
+constexpr int NPROF = 16;
+enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL };
+#ifdef HMPC_PROFILE
+#define PROF_DECL long long _pt = clock64(), _pt0 = _pt; long long _pacc[NPROF] = {0}
+#define PROF_MARK(ph) do { long long _n = clock64(); _pacc[ph] += _n - _pt; _pt = _n; } while (0)
+#define PROF_FLUSH() do { if (threadIdx.x == 0 && args.prof) { _pacc[P_TOTAL] = clock64() - _pt0; for (int _i = 0; _i < NPROF; ++_i) args.prof[(size_t)inst * NPROF + _i] = _pacc[_i]; } } while (0)
+#else
+#define PROF_DECL
+#define PROF_MARK(ph)
+#define PROF_FLUSH()
+#endif
 
 // offsets (in floats) of the debug dump, shared with the host
 template <int NMAX>
@@ -185,6 +197,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
   const int inst = ASM_ONLY ? args.dbg_index : (int)blockIdx.x;
   const int h = args.horizon;
   if (inst >= args.batch) return;
+  PROF_DECL;
 
   // ---------------- A0: one coalesced burst brings the instance's record into LDS ----------------
   {
@@ -468,6 +481,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
     __syncthreads();
   }
 
+  PROF_MARK(P_ASM);
   // ---------------- A5: g = 2 (B'S) e and H = 2(B'S B + alpha) (SolverMPC.cpp:569-570) ----------------
   if (tid < n) {
     const int a = S.vstep[tid], c = S.vcomp[tid];
@@ -524,6 +538,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
   }
   __syncthreads();
 
+  PROF_MARK(P_HG);
   if (ASM_ONLY) {
     using DL = DbgLayout<NMAX>;
     float *o = args.dbg_f;
@@ -655,6 +670,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
         if (i <= j && j < n) S.sq[i * LD + j] = -a[ii][jj];
       }
   }
+  PROF_MARK(P_SWEEP);
   // solver state init
   for (int t = tid; t < m; t += NT) {
     Q.act[t] = 0;
@@ -665,6 +681,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
   matvec(S, Q.w, Q.xu, n);  // unconstrained minimiser x_u = -M g
   if (tid < n) Q.x[tid] = Q.xu[tid];
   __syncthreads();
+  PROF_MARK(P_XU);
 
   // =============================== Q: dual active set (Goldfarb-Idnani, range-space form) ===============================
   const double INF = __builtin_huge_val();
@@ -711,6 +728,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
       int pidx = idx;
       double pval = val;
       block_argmin(Q, pval, pidx);
+      PROF_MARK(P_SEL);
       if (!(pval < -FEAS_TOL)) break;
       if (iters >= itmax) {
         code = S_MAXITER;
@@ -766,6 +784,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
           else Q.gamma = acc;
         }
         __syncthreads();
+        PROF_MARK(P_D);
         // r = E d
         if (tid < q) {
           double acc = 0.0;
@@ -773,6 +792,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
           Q.r[tid] = acc;
         }
         __syncthreads();
+        PROF_MARK(P_ED);
         // w = n+ - N_W' r, gathered per leg-step (its 8 rows touch only its own 6 variables)
         if (tid < nls) {
           const int e = tid, leg = S.ls_leg[e], vF = S.ls_vF[e], vM = S.ls_vM[e];
@@ -794,7 +814,9 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
           for (int k = 0; k < 3; ++k) Q.w[vF + k] = acc[k], Q.w[vM + k] = acc[3 + k];
         }
         __syncthreads();
+        PROF_MARK(P_W);
         matvec(S, Q.w, Q.z, n);  // primal step direction z = M (n+ - N_W' r)
+        PROF_MARK(P_MV);
         double delta = 0.0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) delta = dfma(np[k], Q.z[vFp + k], delta);
@@ -812,6 +834,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
           }
         }
         block_argmin(Q, t1, l);
+        PROF_MARK(P_T1);
         const bool dep = !(delta > 1e-12 * gamma);
         const double t2 = dep ? INF : -sp / delta;
         const double t = (t1 < t2) ? t1 : t2;
@@ -877,6 +900,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
           --q;
           __syncthreads();
         }
+        PROF_MARK(P_UPD);
       }
       if (code != S_OK) break;
     }
@@ -930,6 +954,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
     // a refinement that moved x across another constraint sends us back into the main loop (rare)
   }
 
+  PROF_MARK(P_POLISH);
   // final KKT check: primal slack and multiplier signs
   __syncthreads();
   {
@@ -970,6 +995,8 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
       args.obj64[inst] = o;
     }
   }
+  PROF_MARK(P_FINAL);
+  PROF_FLUSH();
 }
 
 }  // namespace hmpc

@@ -135,6 +135,10 @@ int hmpc_debug_assemble(hmpc_handle *h, int index, int *n, int *m, int *var_ind,
  * (debug copy-out; allocates on first use). */
 int hmpc_download_f64(hmpc_handle *h, double *x, double *obj);
 
+/* Developer hook (only in builds with -DHMPC_PROFILE, scripts/phase_profile.py): per-phase shader-clock cycles of
+ * one more launch of the current batch, [batch][16] (phase ids: hmpc_kernel.h P_*). */
+int hmpc_debug_phase_cycles(hmpc_handle *h, long long *cycles);
+
 const char *hmpc_last_hip_error(void);
 const char *hmpc_version(void);
 
