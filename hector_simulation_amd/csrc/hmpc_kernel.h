@@ -38,8 +38,8 @@ struct KernelArgs {
   int *dbg_i;
   long long *prof;  // optional [batch][HMPC_NPROF] per-phase shader-clock cycles (thread 0's view), profiling builds only
 };
-constexpr int NPROF = 16;
-enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL };
+constexpr int NPROF = 24;
+enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_SW_RD, P_SW_FMA, P_SW_PUB, P_SW_BAR };
 #ifdef HMPC_PROFILE
 #define PROF_DECL long long _pt = clock64(), _pt0 = _pt; long long _pacc[NPROF] = {0}
 #define PROF_MARK(ph) do { long long _n = clock64(); _pacc[ph] += _n - _pt; _pt = _n; } while (0)
@@ -57,11 +57,12 @@ struct DbgLayout {
                        ACD = X0 + 16, BCD = ACD + 176, TOTAL = BCD + 160;
 };
 
-enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT = 4 };
+enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT = 4, S_WORKSET = 5 };
 
 template <int NMAX, int HMAX>
 struct Smem {
-  static constexpr int LD = NMAX + 1;
+  static constexpr int LD = NMAX + 2;   // row stride of the square: 16-B aligned rows, conflict-free row-per-lane reads
+  static constexpr int QMAX = (NMAX >= 120) ? 80 : NMAX;  // working-set capacity (packed Schur inverse)
   static constexpr int NLS = NMAX / 6;
   static constexpr int MMAX = NLS * 8;
   static constexpr int RECW = ((54 + 12 * HMAX) * 4 + 2 * HMAX + 15) / 16 * 4;  // record words
@@ -71,6 +72,7 @@ struct Smem {
   double Cn[2][8][6];
   double ub7[NLS];
   unsigned char vstep[NMAX], vcomp[NMAX];
+  unsigned char vls[NMAX], vk[NMAX];  // variable -> its leg-step, position in it (0-2 force, 3-5 moment)
   unsigned char rmap[12 * HMAX];  // original variable -> reduced index (255 = eliminated)
   unsigned char ls_step[NLS], ls_leg[NLS], ls_vF[NLS], ls_vM[NLS];
   int n, m, nls, pad0;
@@ -88,16 +90,21 @@ struct Smem {
     float e[13 * HMAX];
   };
   struct Sol {
-    double x[NMAX], xu[NMAX], z[NMAX], w[NMAX];
-    double part[NW][NMAX];
-    double piv[2][NMAX];
+    alignas(16) double x[NMAX], xu[NMAX], z[NMAX], w[NMAX];
+    alignas(16) double part[2][NMAX];
+    alignas(16) double piv[2][NMAX];
     double u[NMAX], d[NMAX], r[NMAX], col[NMAX];
     double redv[NW];
     double gamma;
     int redi[NW];
-    signed char act[MMAX];
-    unsigned char slot[MMAX];
+    struct Rec {
+      double val, raw, cn[6];
+      int idx, side, vF, vM;
+    } rec[NW];
+    alignas(8) signed char act[MMAX];
+    alignas(8) unsigned char slot[MMAX];
     unsigned char Wrow[NMAX];
+    double Ep[QMAX * (QMAX + 1) / 2];  // E = (N_W M N_W')^-1, packed lower triangle: E(i,j), i>=j, at i(i+1)/2 + j
   };
   union {
     Asm a;
@@ -105,82 +112,89 @@ struct Smem {
   } u;
 };
 
+// upper-triangle access (assembly output H lives in the upper triangle only)
 template <int NMAX, int HMAX>
-__device__ __forceinline__ double &Mref(Smem<NMAX, HMAX> &S, int i, int j) {
+__device__ __forceinline__ double &Uref(Smem<NMAX, HMAX> &S, int i, int j) {
   const int lo = i < j ? i : j, hi = i < j ? j : i;
   return S.sq[lo * Smem<NMAX, HMAX>::LD + hi];
+}
+// after the sweeps the square holds M = H^-1 in full (both triangles)
+template <int NMAX, int HMAX>
+__device__ __forceinline__ double &Mref(Smem<NMAX, HMAX> &S, int i, int j) {
+  return S.sq[i * Smem<NMAX, HMAX>::LD + j];
 }
 template <int NMAX, int HMAX>
 __device__ __forceinline__ double &Eref(Smem<NMAX, HMAX> &S, int i, int j) {
   const int lo = i < j ? i : j, hi = i < j ? j : i;
-  return S.sq[(hi + 1) * Smem<NMAX, HMAX>::LD + lo];
+  return S.u.s.Ep[hi * (hi + 1) / 2 + lo];
 }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-__device__ __forceinline__ double shfl_xor_d(double v, int mask) {
+// ---- wave-level primitives on binary64 via DPP (no LDS traffic) ----
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl_xor(lo, mask);
-  hi = __shfl_xor(hi, mask);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
-
-// workgroup-wide argmin of (val, idx); ties -> lowest idx.  All threads return the same pair.  One barrier inside,
-// and the caller must ensure redv/redi are not still being read from a previous call (a barrier in between).
-template <class SOL>
-__device__ __forceinline__ void block_argmin(SOL &s, double &val, int &idx) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    double ov = shfl_xor_d(val, o);
-    int oi = __shfl_xor(idx, o);
-    bool take = (ov < val) || (ov == val && oi < idx);
-    val = take ? ov : val;
-    idx = take ? oi : idx;
-  }
-  const int tid = threadIdx.x;
-  if ((tid & 63) == 0) {
-    s.redv[tid >> 6] = val;
-    s.redi[tid >> 6] = idx;
-  }
-  __syncthreads();
-  val = s.redv[0];
-  idx = s.redi[0];
-#pragma unroll
-  for (int w = 1; w < NW; ++w) {
-    double ov = s.redv[w];
-    int oi = s.redi[w];
-    bool take = (ov < val) || (ov == val && oi < idx);
-    val = take ? ov : val;
-    idx = take ? oi : idx;
-  }
+__device__ __forceinline__ double dpp_xor1(double v) { return dpp_move<0xB1>(v); }  // quad_perm [1,0,3,2]
+__device__ __forceinline__ double dpp_xor2(double v) { return dpp_move<0x4E>(v); }  // quad_perm [2,3,0,1]
+__device__ __forceinline__ double dmin(double a, double b) { return b < a ? b : a; }
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// minimum over the 64 lanes, returned in every lane
+__device__ __forceinline__ double wave_min(double v) {
+  v = dmin(v, dpp_move<0xB1>(v));   // lane ^ 1
+  v = dmin(v, dpp_move<0x4E>(v));   // lane ^ 2
+  v = dmin(v, dpp_move<0x141>(v));  // row_half_mirror: joins the two quads of each 8
+  v = dmin(v, dpp_move<0x140>(v));  // row_mirror: joins the two halves of each row of 16
+  const double r0 = readlane_d(v, 0), r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
+  return dmin(dmin(r0, r1), dmin(r2, r3));
 }
 
-// z = M v over the n x n symmetric inverse held in the square's upper triangle.  Wave w takes the j-range quarter w,
-// lane l takes rows l and l+64; partials are combined in a fixed order (deterministic).  Two barriers inside.
+// partial products of z = M v over the full n x n inverse in the square.  Thread t < 2*NMAX: row t % NMAX, j-half
+// t / NMAX; rows are 16-B aligned (LD even) so a lane streams its half row with ds_read_b128 at immediate offsets,
+// the vector is read as broadcast b128.  The two partials of a row are summed by the consumer (zsum) in a fixed
+// order (deterministic).  One barrier inside (after the partials are written).
 template <int NMAX, int HMAX>
-__device__ __forceinline__ void matvec(Smem<NMAX, HMAX> &S, const double *v, double *z, int n) {
+__device__ __forceinline__ void matvec(Smem<NMAX, HMAX> &S, const double *v, int n) {
   constexpr int LD = Smem<NMAX, HMAX>::LD;
-  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-  const int jq = (n + NW - 1) / NW;
-  const int j0 = wv * jq, j1 = (j0 + jq < n) ? j0 + jq : n;
+  constexpr int HALF = NMAX / 2;  // even
+  static_assert(2 * NMAX <= NT && HALF % 2 == 0, "two threads per row");
+  const int tid = threadIdx.x;
+  const int half = tid >= NMAX ? 1 : 0, i = tid - half * NMAX;
+  if (tid < 2 * NMAX && i < n) {
+    const double2 *mrow = reinterpret_cast<const double2 *>(S.sq + i * LD + half * HALF);
+    const double2 *vv = reinterpret_cast<const double2 *>(v + half * HALF);
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    // columns >= n of rows < n of the square, and entries >= n of v, are kept at exact zero (sweep store / solver
+    // init), so the loop runs over the padded width as straight-line code
+    static_assert((HALF / 2) % 2 == 0 || true, "");
 #pragma unroll
-  for (int rr = 0; rr < (NMAX + 63) / 64; ++rr) {
-    const int i = ln + 64 * rr;
-    if (i < n) {
-      double acc = 0.0;
-      for (int j = j0; j < j1; ++j) {
-        const int lo = i < j ? i : j, hi = i < j ? j : i;
-        acc = dfma(S.sq[lo * LD + hi], v[j], acc);
-      }
-      S.u.s.part[wv][i] = acc;
+    for (int c = 0; c + 1 < HALF / 2; c += 2) {
+      const double2 m0 = mrow[c], m1 = mrow[c + 1];
+      const double2 w0 = vv[c], w1 = vv[c + 1];
+      acc0 = dfma(m0.x, w0.x, acc0);
+      acc1 = dfma(m0.y, w0.y, acc1);
+      acc2 = dfma(m1.x, w1.x, acc2);
+      acc3 = dfma(m1.y, w1.y, acc3);
     }
+    if ((HALF / 2) % 2 == 1) {
+      const double2 m0 = mrow[HALF / 2 - 1];
+      const double2 w0 = vv[HALF / 2 - 1];
+      acc0 = dfma(m0.x, w0.x, acc0);
+      acc1 = dfma(m0.y, w0.y, acc1);
+    }
+    S.u.s.part[half][i] = (acc0 + acc1) + (acc2 + acc3);
   }
   __syncthreads();
-  if (tid < n) {
-    double a = S.u.s.part[0][tid];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) a += S.u.s.part[w][tid];
-    z[tid] = a;
-  }
-  __syncthreads();
+}
+template <class SOL>
+__device__ __forceinline__ double zsum(const SOL &s, int i) {
+  return s.part[0][i] + s.part[1][i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
   auto &A = S.u.a;
   auto &Q = S.u.s;
 
-  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int tid = threadIdx.x, wv = uni(tid >> 6), ln = tid & 63;
   const int inst = ASM_ONLY ? args.dbg_index : (int)blockIdx.x;
   const int h = args.horizon;
   if (inst >= args.batch) return;
@@ -288,6 +302,10 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
               S.ls_vF[nl] = (unsigned char)(nv + 3 * rank);
               S.ls_vM[nl] = (unsigned char)(nv + 3 * nst + 3 * rank);
               S.ub7[nl] = (double)(leg == 0 ? ubL : ubR);
+              for (int k = 0; k < 3; ++k) {
+                S.vls[nv + 3 * rank + k] = (unsigned char)nl, S.vk[nv + 3 * rank + k] = (unsigned char)k;
+                S.vls[nv + 3 * nst + 3 * rank + k] = (unsigned char)nl, S.vk[nv + 3 * nst + 3 * rank + k] = (unsigned char)(3 + k);
+              }
               ++nl;
               ++rank;
             }
@@ -433,7 +451,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
   for (int t = tid; t < 169; t += NT) A.Apow[t] = (t % 14 == 0) ? 1.0f : 0.0f;
   __syncthreads();
 
-  const int n = S.n, m = S.m, nls = S.nls;
+  const int n = uni(S.n), m = uni(S.m), nls = uni(S.nls);
   if (n > NMAX) {  // uniform
     if (!ASM_ONLY) {
       for (int t = tid; t < 12 * h; t += NT) args.forces[(size_t)inst * 12 * h + t] = 0.0f;
@@ -552,7 +570,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
     }
     for (int t = tid; t < n * n; t += NT) {
       const int i = t / n, j = t % n;
-      o[DL::H + t] = (float)Mref(S, i, j);
+      o[DL::H + t] = (float)Uref(S, i, j);
     }
     for (int t = tid; t < 192; t += NT) o[DL::FC + t] = A.Fc[t];
     const float big = 5e10f;
@@ -574,177 +592,242 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
 
   // =============================== S: M = H^-1 by symmetric sweeps, matrix in registers ===============================
   // Thread t owns the TR x TC block (rows i0.., cols j0..) of the full symmetric matrix; the 240 blocks that intersect
-  // the upper triangle are enumerated pairwise by column-block (two column blocks share floor(tc/2)+1 row blocks).
-  // Sweep k:  d = a_kk, p = row k;  a_ij -= p_i p_j / d (i,j != k);  a_kj = p_j/d;  a_kk = -1/d.  After n sweeps a = -H^-1.
+  // the upper triangle are enumerated block-row-major (block row tr holds block columns 2tr..29), so the lanes that
+  // own pieces of one matrix row are contiguous.
+  // Sweep k:  d = a_kk, p = row k;  a_ij -= (p_i/d) p_j  (i,j != k);  a_kj = p_j/d;  a_kk = -1/d.  After n sweeps a = -H^-1.
+  // Row k / column k entries take the same fused update with a substituted multiplier (1 - 1/d for row k, d - 1 for
+  // column k: p_j - (1-1/d) p_j = p_j/d), so the inner 8x4 update has no special cases; only a_kk is patched.
   // The pivot row for sweep k+1 is published to LDS right after sweep k (double buffered) -> one barrier per sweep.
   constexpr int TR = NMAX / 15, TC = NMAX / 30;
-  static_assert(TR * 15 == NMAX && TC * 30 == NMAX, "NMAX must be a multiple of 30");
+  static_assert(TR * 15 == NMAX && TC * 30 == NMAX && TR == 2 * TC && TC % 2 == 0, "NMAX must be a multiple of 60");
   {
-    int pa = 0;
-    while ((pa + 1) * (pa + 2) <= tid) ++pa;
-    const int rem = tid - pa * (pa + 1);
+    int tr = 0;
+    while (tr < 14 && (tr + 1) * (30 - tr) <= tid) ++tr;
     const bool owner = tid < 240;
-    const int tc = 2 * pa + (rem >= pa + 1 ? 1 : 0), tr = rem % (pa + 1);
-    const int i0 = owner ? tr * TR : NMAX, j0 = owner ? tc * TC : NMAX;  // non-owners sit outside the matrix
+    const int tc = owner ? 2 * tr + (tid - tr * (31 - tr)) : 0;
+    if (!owner) tr = 0;
+    const int i0 = tr * TR, j0 = tc * TC;
     double a[TR][TC];
 #pragma unroll
     for (int ii = 0; ii < TR; ++ii)
 #pragma unroll
       for (int jj = 0; jj < TC; ++jj) {
         const int i = i0 + ii, j = j0 + jj;
-        a[ii][jj] = (i < n && j < n) ? Mref(S, i, j) : 0.0;
+        a[ii][jj] = (i < n && j < n) ? Uref(S, i, j) : 0.0;
       }
-    // publish pivot row 0
-    if (i0 == 0) {
+    if (tid < NMAX) Q.piv[0][tid] = 0.0, Q.piv[1][tid] = 0.0;
+    __syncthreads();
+    if (owner && i0 == 0) {
 #pragma unroll
       for (int jj = 0; jj < TC; ++jj)
         if (j0 + jj < n) Q.piv[0][j0 + jj] = a[0][jj];
     }
-    __syncthreads();  // also orders the tile loads above before M is overwritten below
-    for (int k = 0; k < n; ++k) {
-      const double *pv = Q.piv[k & 1];
-      double *pn = Q.piv[(k + 1) & 1];
-      const double d = pv[k];
-      const double invd = 1.0 / d;
-      double pi[TR], pj[TC], qi[TR];
+    __syncthreads();
+    const int nkb = (n + TR - 1) / TR;
+    for (int kb = 0; kb < nkb; ++kb) {
+      const bool rowb = owner && (tr == kb);       // my block holds matrix rows kb*TR .. kb*TR+TR-1
+      const bool rown = owner && (tr == kb + 1);   // ... or the next block row (publishes its row 0 at the seam)
 #pragma unroll
-      for (int ii = 0; ii < TR; ++ii) {
-        pi[ii] = (i0 + ii < n) ? pv[i0 + ii] : 0.0;
-        qi[ii] = pi[ii] * invd;
+      for (int kk = 0; kk < TR; ++kk) {
+        const int k = kb * TR + kk;
+        if (k < n) {  // uniform
+          const double *pv = Q.piv[k & 1];
+          double *pn = Q.piv[(k + 1) & 1];
+          const double d = pv[k];
+          double pi[TR], pj[TC];
+#pragma unroll
+          for (int ii = 0; ii < TR; ii += 2) {
+            const double2 t2 = *reinterpret_cast<const double2 *>(pv + i0 + ii);
+            pi[ii] = t2.x, pi[ii + 1] = t2.y;
+          }
+#pragma unroll
+          for (int jj = 0; jj < TC; jj += 2) {
+            const double2 t2 = *reinterpret_cast<const double2 *>(pv + j0 + jj);
+            pj[jj] = t2.x, pj[jj + 1] = t2.y;
+          }
+          double invd = __builtin_amdgcn_rcp(d);  // v_rcp_f64 + two Newton steps (the solver half is not bit-pinned)
+          invd = dfma(dfma(-d, invd, 1.0), invd, invd);
+          invd = dfma(dfma(-d, invd, 1.0), invd, invd);
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int kc = kk % TC;                        // static column index inside the block column of k
+          const bool colb = owner && (tc == 2 * kb + kk / TC);  // my block holds matrix column k
+          double qi[TR];
+#pragma unroll
+          for (int ii = 0; ii < TR; ++ii) qi[ii] = pi[ii] * invd;
+          qi[kk] = rowb ? (1.0 - invd) : qi[kk];
+          pj[kc] = colb ? (d - 1.0) : pj[kc];
+#pragma unroll
+          for (int ii = 0; ii < TR; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < TC; ++jj) a[ii][jj] = dfma(-qi[ii], pj[jj], a[ii][jj]);
+          a[kk][kc] = (rowb && colb) ? -invd : a[kk][kc];
+          // publish row k+1 of the symmetric matrix: (k+1, j>=k+1) from the row owners, (i<k+1, k+1) from the column owners
+          const int k1 = k + 1;
+          if (k1 < n) {
+            if (kk + 1 < TR) {
+              if (rowb) {
+#pragma unroll
+                for (int jj = 0; jj < TC; ++jj)
+                  if (j0 + jj >= k1) pn[j0 + jj] = a[(kk + 1) % TR][jj];
+              }
+            } else {
+              if (rown) {
+#pragma unroll
+                for (int jj = 0; jj < TC; ++jj)
+                  if (j0 + jj >= k1) pn[j0 + jj] = a[0][jj];
+              }
+            }
+            const int kc1 = (kk + 1) % TC;
+            if (owner && tc == (kb * TR + kk + 1) / TC) {
+#pragma unroll
+              for (int ii = 0; ii < TR; ++ii)
+                if (i0 + ii < k1) pn[i0 + ii] = a[ii][kc1];
+            }
+          }
+          __syncthreads();
+        }
       }
-#pragma unroll
-      for (int jj = 0; jj < TC; ++jj) pj[jj] = (j0 + jj < n) ? pv[j0 + jj] : 0.0;
+    }
+    // M = -a, both triangles; entries beyond n (exact zeros) are written too so that padded mat-vec reads are clean
+    if (owner) {
 #pragma unroll
       for (int ii = 0; ii < TR; ++ii)
 #pragma unroll
-        for (int jj = 0; jj < TC; ++jj) a[ii][jj] = dfma(-qi[ii], pj[jj], a[ii][jj]);
-      // pivot row / column entries of this block get their closed-form values
-      const int kr = k - i0, kc = k - j0;
-      if (kr >= 0 && kr < TR) {
-#pragma unroll
-        for (int ii = 0; ii < TR; ++ii)
-          if (ii == kr) {
-#pragma unroll
-            for (int jj = 0; jj < TC; ++jj) a[ii][jj] = (jj == kc) ? -invd : pj[jj] * invd;
+        for (int jj = 0; jj < TC; ++jj) {
+          const int i = i0 + ii, j = j0 + jj;
+          if (i <= j) {
+            S.sq[i * LD + j] = -a[ii][jj];
+            S.sq[j * LD + i] = -a[ii][jj];
           }
-      }
-      if (kc >= 0 && kc < TC) {
-#pragma unroll
-        for (int jj = 0; jj < TC; ++jj)
-          if (jj == kc) {
-#pragma unroll
-            for (int ii = 0; ii < TR; ++ii) a[ii][jj] = (ii == kr) ? -invd : qi[ii];
-          }
-      }
-      // publish row k+1 of the symmetric matrix: (k+1, j>=k+1) from the row owners, (j<k+1, k+1) from the column owners
-      const int k1 = k + 1;
-      if (k1 < n) {
-        const int r1 = k1 - i0, c1 = k1 - j0;
-        if (r1 >= 0 && r1 < TR) {
-#pragma unroll
-          for (int ii = 0; ii < TR; ++ii)
-            if (ii == r1) {
-#pragma unroll
-              for (int jj = 0; jj < TC; ++jj)
-                if (j0 + jj >= k1 && j0 + jj < n) pn[j0 + jj] = a[ii][jj];
-            }
         }
-        if (c1 >= 0 && c1 < TC) {
-#pragma unroll
-          for (int jj = 0; jj < TC; ++jj)
-            if (jj == c1) {
-#pragma unroll
-              for (int ii = 0; ii < TR; ++ii)
-                if (i0 + ii < k1) pn[i0 + ii] = a[ii][jj];
-            }
-        }
-      }
-      __syncthreads();
     }
-    // M = -a into the upper triangle (diagonal included)
-#pragma unroll
-    for (int ii = 0; ii < TR; ++ii)
-#pragma unroll
-      for (int jj = 0; jj < TC; ++jj) {
-        const int i = i0 + ii, j = j0 + jj;
-        if (i <= j && j < n) S.sq[i * LD + j] = -a[ii][jj];
-      }
   }
   PROF_MARK(P_SWEEP);
-  // solver state init
+
+  // =============================== Q: dual active set (Goldfarb-Idnani, range-space form) ===============================
+  // Fixed thread roles, constants held in registers for the whole solve:
+  //   thread c < m  : constraint row c (leg-step c>>3, row c&7): its 6 coefficients, variable offsets, bounds
+  //   thread i < n  : variable i: its leg-step, position in it, and the 8 coefficients of its column
+  const double INF = __builtin_huge_val();
+  const double FEAS_TOL = 1e-9;
+  const bool is_c = tid < m, is_v = tid < n;
+  int c_vF = 0, c_vM = 0;
+  double c_cn[6] = {0, 0, 0, 0, 0, 0}, c_ub = INF, c_scale = 1.0;
+  bool c_hasl = false, c_hasu = false;
+  if (is_c) {
+    const int e = tid >> 3, rr = tid & 7, leg = S.ls_leg[e];
+    c_vF = S.ls_vF[e], c_vM = S.ls_vM[e];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c_cn[k] = S.Cn[leg][rr][k];
+    c_hasl = (rr <= 4) || (rr == 7);  // every finite lower bound is 0 (SolverMPC.cpp:466-482)
+    c_hasu = (rr >= 4);
+    c_ub = (rr == 4) ? (double)0.01f : (rr == 7 ? S.ub7[e] : 0.0);
+    c_scale = (rr == 7 && c_ub > 1.0) ? 1.0 / c_ub : 1.0;  // the Fz cap is O(f_max): compare it on a unit scale
+  }
+  int v_e = 0, v_k = 0;
+  double v_col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (is_v) {
+    v_e = S.vls[tid], v_k = S.vk[tid];
+    const int leg = S.ls_leg[v_e];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) v_col[rr] = S.Cn[leg][rr][v_k];
+  }
   for (int t = tid; t < m; t += NT) {
     Q.act[t] = 0;
     Q.slot[t] = 0;
   }
-  if (tid < n) Q.w[tid] = -S.g[tid];
+  if (tid < NMAX) Q.r[tid] = 0.0;
+  if (tid < NMAX) Q.w[tid] = is_v ? -S.g[tid] : 0.0;  // entries >= n stay exactly 0 for the padded mat-vec
   __syncthreads();
-  matvec(S, Q.w, Q.xu, n);  // unconstrained minimiser x_u = -M g
-  if (tid < n) Q.x[tid] = Q.xu[tid];
+  matvec(S, Q.w, n);  // unconstrained minimiser x_u = -M g
+  if (is_v) {
+    const double xv = zsum(Q, tid);
+    Q.xu[tid] = xv;
+    Q.x[tid] = xv;
+  }
   __syncthreads();
   PROF_MARK(P_XU);
 
-  // =============================== Q: dual active set (Goldfarb-Idnani, range-space form) ===============================
-  const double INF = __builtin_huge_val();
-  const double FEAS_TOL = 1e-9;
   int q = 0, iters = 0, code = S_OK;
   const int itmax = 4 * m + 16;
 
-  // slack of constraint row c on its tighter side; side = +1 lower bound, -1 upper bound
-  auto row_slack = [&](int c, const double *xv, int &side) -> double {
-    const int e = c >> 3, rr = c & 7;
-    const int leg = S.ls_leg[e], vF = S.ls_vF[e], vM = S.ls_vM[e];
-    const double *cn = S.Cn[leg][rr];
+  // slack of this thread's constraint row on its tighter side at xv (unit-scaled); side = +1 lower, -1 upper
+  auto my_slack = [&](const double *xv, int &side, double &raw) -> double {
     double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) s = dfma(cn[k], xv[vF + k], s);
+    for (int k = 0; k < 3; ++k) s = dfma(c_cn[k], xv[c_vF + k], s);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) s = dfma(cn[3 + k], xv[vM + k], s);
-    double sl = INF, su = INF;
-    if (rr < 4) {
-      sl = s;
-    } else if (rr == 4) {
-      sl = s;
-      su = ((double)0.01f - s);
-    } else if (rr < 7) {
-      su = -s;
-    } else {
-      sl = s * 1.0;
-      const double ub = S.ub7[e];
-      su = (ub - s) / (ub > 1.0 ? ub : 1.0);  // scaled so that one absolute tolerance serves both sides
+    for (int k = 0; k < 3; ++k) s = dfma(c_cn[3 + k], xv[c_vM + k], s);
+    const double sl = c_hasl ? s : INF;
+    const double su = c_hasu ? (c_ub - s) : INF;
+    const double ssu = su * c_scale;
+    side = (sl <= ssu) ? 1 : -1;
+    raw = (sl <= ssu) ? sl : su;
+    return (sl <= ssu) ? sl : ssu;
+  };
+  // w_i = sum over the active rows of variable i's leg-step of coef(row) * a_row[i]  (+ extra)
+  auto gather_w = [&](const double *coefv, double sgn, double extra) {
+    if (is_v) {
+      const unsigned long long am = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * v_e]);
+      const unsigned long long sm = *reinterpret_cast<const unsigned long long *>(&Q.slot[8 * v_e]);
+      double acc = extra;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int ac = (int)(signed char)((am >> (8 * rr)) & 0xff);
+        const int sl = (int)((sm >> (8 * rr)) & 0xff);
+        const double cf = coefv[sl];
+        const double coef = (ac == 0) ? 0.0 : ((ac > 0) ? sgn * cf : -sgn * cf);
+        acc = dfma(coef, v_col[rr], acc);
+      }
+      Q.w[tid] = acc;
     }
-    side = (sl <= su) ? 1 : -1;
-    return (sl <= su) ? sl : su;
   };
 
   for (int pass = 0; pass < 3 && code == S_OK; ++pass) {
     // ---- main loop ----
     while (true) {
-      double val = INF;
-      int idx = 0x7fffffff, side = 1;
-      if (tid < m && Q.act[tid] == 0) {
-        val = row_slack(tid, Q.x, side);
-        idx = tid;
+      // (1) most violated constraint; the winning lane of each wave also publishes its constants
+      double val = INF, raw = INF;
+      int side = 1;
+      if (is_c && Q.act[tid] == 0) val = my_slack(Q.x, side, raw);
+      {
+        const double wmin = wave_min(val);
+        const unsigned long long bal = __ballot(val == wmin);
+        const int wl = (int)__ffsll((long long)bal) - 1;
+        if (ln == wl) {
+          auto &rc = Q.rec[wv];
+          rc.val = val;
+          rc.raw = raw;
+          rc.idx = tid;
+          rc.side = side;
+          rc.vF = c_vF;
+          rc.vM = c_vM;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) rc.cn[k] = c_cn[k];
+        }
       }
-      int pidx = idx;
-      double pval = val;
-      block_argmin(Q, pval, pidx);
+      __syncthreads();
+      int wsel = 0;
+      double pval = Q.rec[0].val;
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        const double ov = Q.rec[w].val;
+        if (ov < pval) pval = ov, wsel = w;
+      }
       PROF_MARK(P_SEL);
       if (!(pval < -FEAS_TOL)) break;
       if (iters >= itmax) {
         code = S_MAXITER;
         break;
       }
-      // pivot constraint p and its signed normal n+ (6 entries on vars vFp.., vMp..)
-      const int p = pidx;
-      const int ep = p >> 3, rp = p & 7, legp = S.ls_leg[ep], vFp = S.ls_vF[ep], vMp = S.ls_vM[ep];
-      int sgi;
-      double sp = row_slack(p, Q.x, sgi);  // every thread recomputes the same value
-      const double ub_p = S.ub7[ep];
-      if (rp == 7 && sgi < 0) sp *= (ub_p > 1.0 ? ub_p : 1.0);  // undo the scaling: true slack ub - s
+      const int p = Q.rec[wsel].idx, sgi = Q.rec[wsel].side, vFp = Q.rec[wsel].vF, vMp = Q.rec[wsel].vM;
+      const int ep = p >> 3;
+      double sp = Q.rec[wsel].raw;
       const double sg = (double)sgi;
       double np[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) np[k] = sg * S.Cn[legp][rp][k];
+      for (int k = 0; k < 6; ++k) np[k] = sg * Q.rec[wsel].cn[k];
       double up = 0.0;
       bool added = false;
       while (!added) {
@@ -753,87 +836,78 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
           code = S_MAXITER;
           break;
         }
-        // d_j = n_j' M n+  (36 MACs on the 6x6 sub-block of M), gamma = n+' M n+
-        if (tid <= q) {
-          double nj[6];
-          int vFj, vMj;
-          if (tid < q) {
-            const int c = Q.Wrow[tid], e = c >> 3, rr = c & 7, leg = S.ls_leg[e];
-            vFj = S.ls_vF[e], vMj = S.ls_vM[e];
-            const double sj = (double)Q.act[c];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) nj[k] = sj * S.Cn[leg][rr][k];
-          } else {
-            vFj = vFp, vMj = vMp;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) nj[k] = np[k];
-          }
+        // (2) y = M n+  (n+ has 6 entries: 6 MACs per row)
+        if (is_v) {
           double acc = 0.0;
 #pragma unroll
-          for (int a = 0; a < 6; ++a) {
-            const int ia = (a < 3) ? vFj + a : vMj + a - 3;
-            double t = 0.0;
+          for (int k = 0; k < 3; ++k) acc = dfma(Mref(S, tid, vFp + k), np[k], acc);
 #pragma unroll
-            for (int b = 0; b < 6; ++b) {
-              const int ib = (b < 3) ? vFp + b : vMp + b - 3;
-              t = dfma(Mref(S, ia, ib), np[b], t);
-            }
-            acc = dfma(nj[a], t, acc);
-          }
-          if (tid < q) Q.d[tid] = acc;
-          else Q.gamma = acc;
+          for (int k = 0; k < 3; ++k) acc = dfma(Mref(S, tid, vMp + k), np[3 + k], acc);
+          Q.z[tid] = acc;  // y lives in z until the mat-vec overwrites the partials, not z
+        }
+        __syncthreads();
+        // (3) every constraint thread: a_c' y; active rows scatter d[slot] = sign * a_c' y; row p gives gamma
+        if (is_c) {
+          double dc = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) dc = dfma(c_cn[k], Q.z[c_vF + k], dc);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) dc = dfma(c_cn[3 + k], Q.z[c_vM + k], dc);
+          const int ac = Q.act[tid];
+          if (ac != 0) Q.d[Q.slot[tid]] = (double)ac * dc;
+          if (tid == p) Q.gamma = sg * dc;
         }
         __syncthreads();
         PROF_MARK(P_D);
-        // r = E d
-        if (tid < q) {
+        // (4) r = E d : 4 lanes per row, quad reduction
+        for (int jb = 0; jb < q; jb += NT / 4) {
+          const int j = jb + (tid >> 2), part = tid & 3;
           double acc = 0.0;
-          for (int i = 0; i < q; ++i) acc = dfma(Eref(S, tid, i), Q.d[i], acc);
-          Q.r[tid] = acc;
+          if (j < q) {
+            for (int i = part; i < q; i += 4) acc = dfma(Eref(S, j, i), Q.d[i], acc);
+          }
+          acc += dpp_xor1(acc);
+          acc += dpp_xor2(acc);
+          if (j < q && part == 0) Q.r[j] = acc;
         }
         __syncthreads();
         PROF_MARK(P_ED);
-        // w = n+ - N_W' r, gathered per leg-step (its 8 rows touch only its own 6 variables)
-        if (tid < nls) {
-          const int e = tid, leg = S.ls_leg[e], vF = S.ls_vF[e], vM = S.ls_vM[e];
-          double acc[6] = {0, 0, 0, 0, 0, 0};
-          for (int rr = 0; rr < 8; ++rr) {
-            const int c = 8 * e + rr;
-            const int ac = Q.act[c];
-            if (ac != 0) {
-              const double coef = -(double)ac * Q.r[Q.slot[c]];
-#pragma unroll
-              for (int k = 0; k < 6; ++k) acc[k] = dfma(coef, S.Cn[leg][rr][k], acc[k]);
-            }
-          }
-          if (e == ep) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) acc[k] += np[k];
-          }
-#pragma unroll
-          for (int k = 0; k < 3; ++k) Q.w[vF + k] = acc[k], Q.w[vM + k] = acc[3 + k];
-        }
+        // (5) w = n+ - N_W' r
+        gather_w(Q.r, -1.0, (is_v && v_e == ep) ? np[v_k] : 0.0);
         __syncthreads();
         PROF_MARK(P_W);
-        matvec(S, Q.w, Q.z, n);  // primal step direction z = M (n+ - N_W' r)
+        // (6) z = M w (partials; consumers sum the four j-quarters in a fixed order)
+        matvec(S, Q.w, n);
         PROF_MARK(P_MV);
         double delta = 0.0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) delta = dfma(np[k], Q.z[vFp + k], delta);
+        for (int k = 0; k < 3; ++k) delta = dfma(np[k], zsum(Q, vFp + k), delta);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) delta = dfma(np[3 + k], Q.z[vMp + k], delta);
+        for (int k = 0; k < 3; ++k) delta = dfma(np[3 + k], zsum(Q, vMp + k), delta);
         const double gamma = Q.gamma;
-        // largest dual step keeping u >= 0
+        // (7) largest dual step keeping u >= 0
         double t1 = INF;
-        int l = 0x7fffffff;
         if (tid < q) {
           const double rj = Q.r[tid];
-          if (rj > 1e-14) {
-            t1 = Q.u[tid] / rj;
-            l = tid;
+          if (rj > 1e-14) t1 = Q.u[tid] / rj;
+        }
+        {
+          const double wmin = wave_min(t1);
+          const unsigned long long bal = __ballot(t1 == wmin);
+          const int wl = (int)__ffsll((long long)bal) - 1;
+          if (ln == wl) {
+            Q.redv[wv] = t1;
+            Q.redi[wv] = tid;
           }
         }
-        block_argmin(Q, t1, l);
+        __syncthreads();
+        int l = Q.redi[0];
+        t1 = Q.redv[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+          const double ov = Q.redv[w];
+          if (ov < t1) t1 = ov, l = Q.redi[w];
+        }
         PROF_MARK(P_T1);
         const bool dep = !(delta > 1e-12 * gamma);
         const double t2 = dep ? INF : -sp / delta;
@@ -842,23 +916,32 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
           code = S_INFEASIBLE;
           break;
         }
-        if (!dep && tid < n) Q.x[tid] = dfma(t, Q.z[tid], Q.x[tid]);
+        // (8) step
+        if (!dep && is_v) Q.x[tid] = dfma(t, zsum(Q, tid), Q.x[tid]);
         if (tid < q) Q.u[tid] = dfma(-t, Q.r[tid], Q.u[tid]);
         up += t;
         if (!dep) sp = dfma(t, delta, sp);
+        if (!dep && !(t1 < t2) && q >= SM::QMAX) {
+          code = S_WORKSET;
+          break;
+        }
         if (!dep && !(t1 < t2)) {
-          // full step: constraint p joins the working set; bordered update of E
+          // full step: constraint p joins the working set; bordered update of E (16 x 16 thread tiles of the lower triangle)
           const double idl = 1.0 / delta;
-          for (int t2i = tid; t2i < q * (q + 1) / 2; t2i += NT) {
-            int i = 0;
-            while ((i + 1) * (i + 2) / 2 <= t2i) ++i;
-            const int j = t2i - i * (i + 1) / 2;
-            double &ee = S.sq[(i + 1) * LD + j];
-            ee = dfma(Q.r[i] * idl, Q.r[j], ee);
+          const int ti = tid >> 4, tj = tid & 15;
+          for (int ib = 0; ib < q; ib += 16) {
+            const int i = ib + ti;
+            if (i < q) {
+              const double ri = Q.r[i] * idl;
+              for (int j = tj; j <= i; j += 16) {
+                double &ee = Q.Ep[i * (i + 1) / 2 + j];
+                ee = dfma(ri, Q.r[j], ee);
+              }
+            }
           }
-          if (tid < q) S.sq[(q + 1) * LD + tid] = -Q.r[tid] * idl;
+          if (tid < q) Q.Ep[q * (q + 1) / 2 + tid] = -Q.r[tid] * idl;
           if (tid == q) {
-            S.sq[(q + 1) * LD + q] = idl;
+            Q.Ep[q * (q + 1) / 2 + q] = idl;
             Q.u[q] = up;
             Q.Wrow[q] = (unsigned char)p;
             Q.act[p] = (signed char)sgi;
@@ -868,17 +951,20 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
           added = true;
           __syncthreads();
         } else {
-          // partial (or pure dual) step: constraint in slot l leaves; Schur-complement downdate of E, last slot -> l
-          if (tid < q) Q.col[tid] = Eref(S, tid, l);
-          __syncthreads();
-          const double iel = 1.0 / Q.col[l];
-          for (int t2i = tid; t2i < q * (q + 1) / 2; t2i += NT) {
-            int i = 0;
-            while ((i + 1) * (i + 2) / 2 <= t2i) ++i;
-            const int j = t2i - i * (i + 1) / 2;
-            if (i != l && j != l) {
-              double &ee = S.sq[(i + 1) * LD + j];
-              ee = dfma(-Q.col[i] * iel, Q.col[j], ee);
+          // partial (or pure dual) step: slot l leaves; Schur-complement downdate of E (row/column l are read-only
+          // during the pass, so no staging copy is needed), then the last slot moves into l
+          const double iel = 1.0 / Eref(S, l, l);
+          const int ti = tid >> 4, tj = tid & 15;
+          for (int ib = 0; ib < q; ib += 16) {
+            const int i = ib + ti;
+            if (i < q && i != l) {
+              const double ci = Eref(S, i, l) * iel;
+              for (int j = tj; j <= i; j += 16) {
+                if (j != l) {
+                  double &ee = Q.Ep[i * (i + 1) / 2 + j];
+                  ee = dfma(-ci, Eref(S, j, l), ee);
+                }
+              }
             }
           }
           __syncthreads();
@@ -908,47 +994,35 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
 
     // ---- refinement of the multipliers on the final working set: u += E (b_W - N_W x(u)), x(u) = x_u + M N_W' u ----
     for (int it = 0; it < 3; ++it) {
-      if (tid < nls) {
-        const int e = tid, leg = S.ls_leg[e], vF = S.ls_vF[e], vM = S.ls_vM[e];
-        double acc[6] = {0, 0, 0, 0, 0, 0};
-        for (int rr = 0; rr < 8; ++rr) {
-          const int c = 8 * e + rr;
-          const int ac = Q.act[c];
-          if (ac != 0) {
-            const double coef = (double)ac * Q.u[Q.slot[c]];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) acc[k] = dfma(coef, S.Cn[leg][rr][k], acc[k]);
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) Q.w[vF + k] = acc[k], Q.w[vM + k] = acc[3 + k];
-      }
+      gather_w(Q.u, 1.0, 0.0);
       __syncthreads();
-      matvec(S, Q.w, Q.z, n);
-      if (tid < n) Q.x[tid] = Q.xu[tid] + Q.z[tid];
+      matvec(S, Q.w, n);
+      if (is_v) Q.x[tid] = Q.xu[tid] + zsum(Q, tid);
       __syncthreads();
       if (it == 2) break;
-      if (tid < q) {
-        const int c = Q.Wrow[tid], e = c >> 3, rr = c & 7, leg = S.ls_leg[e], vF = S.ls_vF[e], vM = S.ls_vM[e];
-        const double sj = (double)Q.act[c];
-        double s = 0.0;
+      if (is_c) {
+        const int ac = Q.act[tid];
+        if (ac != 0) {
+          double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) s = dfma(S.Cn[leg][rr][k], Q.x[vF + k], s);
+          for (int k = 0; k < 3; ++k) s = dfma(c_cn[k], Q.x[c_vF + k], s);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) s = dfma(S.Cn[leg][rr][3 + k], Q.x[vM + k], s);
-        double bnd;
-        if (sj > 0) bnd = 0.0;                                   // every finite lower bound is 0
-        else bnd = (rr == 4) ? (double)0.01f : (rr == 7 ? S.ub7[e] : 0.0);
-        Q.d[tid] = sj * (bnd - s);  // b_j - n_j' x with n_j = sj*a_j, b_j = sj*bound
+          for (int k = 0; k < 3; ++k) s = dfma(c_cn[3 + k], Q.x[c_vM + k], s);
+          const double bnd = (ac > 0) ? 0.0 : c_ub;
+          Q.d[Q.slot[tid]] = (double)ac * (bnd - s);  // b_j - n_j' x with n_j = sign*a_j, b_j = sign*bound
+        }
       }
       __syncthreads();
-      if (tid < q) {
+      for (int jb = 0; jb < q; jb += NT / 4) {
+        const int j = jb + (tid >> 2), part = tid & 3;
         double acc = 0.0;
-        for (int i = 0; i < q; ++i) acc = dfma(Eref(S, tid, i), Q.d[i], acc);
-        Q.r[tid] = acc;
+        if (j < q) {
+          for (int i = part; i < q; i += 4) acc = dfma(Eref(S, j, i), Q.d[i], acc);
+        }
+        acc += dpp_xor1(acc);
+        acc += dpp_xor2(acc);
+        if (j < q && part == 0) Q.u[j] += acc;
       }
-      __syncthreads();
-      if (tid < q) Q.u[tid] += Q.r[tid];
       __syncthreads();
     }
     // a refinement that moved x across another constraint sends us back into the main loop (rare)
@@ -958,20 +1032,22 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
   // final KKT check: primal slack and multiplier signs
   __syncthreads();
   {
-    double val = INF;
-    int idx = 0x7fffffff, side;
-    if (tid < m && Q.act[tid] == 0) {
-      val = row_slack(tid, Q.x, side);
-      idx = tid;
-    }
-    block_argmin(Q, val, idx);
+    double val = INF, raw;
+    int side;
+    if (is_c && Q.act[tid] == 0) val = my_slack(Q.x, side, raw);
+    double umin = (tid < q) ? Q.u[tid] : INF;
+    val = wave_min(val);
+    umin = wave_min(umin);
+    if (ln == 0) Q.redv[wv] = val, Q.rec[wv].raw = umin;
     __syncthreads();
-    double umin = INF;
-    int ui = 0x7fffffff;
-    if (tid < q) umin = Q.u[tid], ui = tid;
-    block_argmin(Q, umin, ui);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      val = (Q.redv[w] < val) ? Q.redv[w] : val;
+      umin = (Q.rec[w].raw < umin) ? Q.rec[w].raw : umin;
+    }
     if (code == S_OK && (val < -1e-6 || umin < -1e-6)) code = S_KKT;
   }
+
 
   // ---------------- output: scatter to the reference's 12h layout, eliminated variables exactly 0 (SolverMPC.cpp:720-732)
   for (int t = tid; t < 12 * h; t += NT) {

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib, records
 
-STATUS_NAMES = {0: "ok", 1: "max_iter", 2: "infeasible", 3: "too_large", 4: "kkt"}
+STATUS_NAMES = {0: "ok", 1: "max_iter", 2: "infeasible", 3: "too_large", 4: "kkt", 5: "working_set_full"}
 
 
 class HmpcError(RuntimeError):

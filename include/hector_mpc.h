@@ -93,7 +93,8 @@ enum hmpc_status_code {
   HMPC_S_MAXITER = 1,     /* iteration cap hit (reference analogue: nWSR = 500 exhausted) */
   HMPC_S_INFEASIBLE = 2,  /* constraints inconsistent */
   HMPC_S_TOO_LARGE = 3,   /* more than HMPC_MAX_VARS reduced variables (e.g. double support over h > 10) */
-  HMPC_S_KKT = 4          /* final KKT check outside tolerance */
+  HMPC_S_KKT = 4,         /* final KKT check outside tolerance */
+  HMPC_S_WORKSET = 5      /* more simultaneously active constraints than the on-chip working set holds (80) */
 };
 
 size_t hmpc_record_stride(int horizon);  /* bytes per packed record: (54+12h)*4 + 2h rounded up to 16 */
@@ -136,7 +137,7 @@ int hmpc_debug_assemble(hmpc_handle *h, int index, int *n, int *m, int *var_ind,
 int hmpc_download_f64(hmpc_handle *h, double *x, double *obj);
 
 /* Developer hook (only in builds with -DHMPC_PROFILE, scripts/phase_profile.py): per-phase shader-clock cycles of
- * one more launch of the current batch, [batch][16] (phase ids: hmpc_kernel.h P_*). */
+ * one more launch of the current batch, [batch][24] (phase ids: hmpc_kernel.h P_*). */
 int hmpc_debug_phase_cycles(hmpc_handle *h, long long *cycles);
 
 const char *hmpc_last_hip_error(void);

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from hector_simulation_amd import _lib, build, interface, records, synthetic  # noqa: E402
 
-PH = ["asm", "H+g", "sweep", "xu", "select", "d", "E*d", "w", "matvec", "t1", "update", "polish", "final", "TOTAL"]
+PH = ["asm", "H+g", "sweep", "xu", "select", "d", "E*d", "w", "matvec", "t1", "update", "polish", "final", "TOTAL", "sw:rd", "sw:fma", "sw:pub", "sw:bar"]
 
 
 def main():
@@ -30,7 +30,7 @@ def main():
     mpc.upload(rec)
     mpc.solve()
     _, status = mpc.download()
-    cyc = np.zeros((nb, 16), dtype=np.int64)
+    cyc = np.zeros((nb, 24), dtype=np.int64)
     interface._check(mpc.L.hmpc_debug_phase_cycles(mpc.h, cyc.ctypes.data), "phase_cycles")
     it = interface.status_iters(status)
     mean = cyc.mean(axis=0)
