@@ -158,6 +158,7 @@ def main() -> None:
     status = d_status.cpu().numpy().astype(np.uint32)
     n_fail = int((interface.status_code(status) != 0).sum())
     iters = interface.status_iters(status)
+    nact = interface.status_nactive(status)
 
     if rank == 0:
         total = world * B * args.steps
@@ -193,7 +194,7 @@ def main() -> None:
                                  "active-set iteration inside one workgroup (LDS/VALU fp64 latency)"},
             "roofline_mfma": {"bound": "mfma", "achieved": ach_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                               "frac": ach_tf / MFMA_F32_PEAK_TF, "algorithmic_mflop_per_solve": mfl},
-            "solver": {"failed": n_fail, "iters_median": float(np.median(iters)), "iters_max": int(iters.max()),
+            "solver": {"failed": n_fail, "iters_median": float(np.median(iters)), "iters_max": int(iters.max()), "active_median": float(np.median(nact)), "active_max": int(nact.max()),
                        "kernel_solves_per_s": B / (kernel_ms * 1e-3)},
         }
         if args.check > 0:

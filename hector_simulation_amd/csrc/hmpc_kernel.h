@@ -129,6 +129,8 @@ __device__ __forceinline__ double &Eref(Smem<NMAX, HMAX> &S, int i, int j) {
   return S.u.s.Ep[hi * (hi + 1) / 2 + lo];
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a decision every lane agrees on (computed from broadcast LDS reads), told to the compiler as a scalar
+__device__ __forceinline__ bool ub(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 
 // ---- wave-level primitives on binary64 via DPP (no LDS traffic) ----
 template <int CTRL>
@@ -816,12 +818,13 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
         if (ov < pval) pval = ov, wsel = w;
       }
       PROF_MARK(P_SEL);
-      if (!(pval < -FEAS_TOL)) break;
+      if (ub(!(pval < -FEAS_TOL))) break;
       if (iters >= itmax) {
         code = S_MAXITER;
         break;
       }
-      const int p = Q.rec[wsel].idx, sgi = Q.rec[wsel].side, vFp = Q.rec[wsel].vF, vMp = Q.rec[wsel].vM;
+      wsel = uni(wsel);
+      const int p = uni(Q.rec[wsel].idx), sgi = uni(Q.rec[wsel].side), vFp = uni(Q.rec[wsel].vF), vMp = uni(Q.rec[wsel].vM);
       const int ep = p >> 3;
       double sp = Q.rec[wsel].raw;
       const double sg = (double)sgi;
@@ -836,96 +839,96 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
           code = S_MAXITER;
           break;
         }
-        // (2) y = M n+  (n+ has 6 entries: 6 MACs per row)
-        if (is_v) {
-          double acc = 0.0;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) acc = dfma(Mref(S, tid, vFp + k), np[k], acc);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) acc = dfma(Mref(S, tid, vMp + k), np[3 + k], acc);
-          Q.z[tid] = acc;  // y lives in z until the mat-vec overwrites the partials, not z
-        }
-        __syncthreads();
-        // (3) every constraint thread: a_c' y; active rows scatter d[slot] = sign * a_c' y; row p gives gamma
+        // (2) every constraint thread: a_c' M n+ straight from the 6x6 sub-block of M (36 independent LDS reads);
+        //     active rows scatter d[slot] = sign * a_c' M n+; row p gives gamma = n+' M n+
         if (is_c) {
           double dc = 0.0;
 #pragma unroll
-          for (int k = 0; k < 3; ++k) dc = dfma(c_cn[k], Q.z[c_vF + k], dc);
+          for (int a6 = 0; a6 < 6; ++a6) {
+            const double *mr = S.sq + ((a6 < 3) ? (c_vF + a6) : (c_vM + a6 - 3)) * LD;
+            double t = 0.0;
 #pragma unroll
-          for (int k = 0; k < 3; ++k) dc = dfma(c_cn[3 + k], Q.z[c_vM + k], dc);
+            for (int k = 0; k < 3; ++k) t = dfma(mr[vFp + k], np[k], t);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t = dfma(mr[vMp + k], np[3 + k], t);
+            dc = dfma(c_cn[a6], t, dc);
+          }
           const int ac = Q.act[tid];
           if (ac != 0) Q.d[Q.slot[tid]] = (double)ac * dc;
           if (tid == p) Q.gamma = sg * dc;
         }
         __syncthreads();
         PROF_MARK(P_D);
-        // (4) r = E d : 4 lanes per row, quad reduction
-        for (int jb = 0; jb < q; jb += NT / 4) {
-          const int j = jb + (tid >> 2), part = tid & 3;
-          double acc = 0.0;
-          if (j < q) {
-            for (int i = part; i < q; i += 4) acc = dfma(Eref(S, j, i), Q.d[i], acc);
+        // (3) r = E d : 4 lanes per row, quad reduction; the lane that owns r_j also bids for the dual step length
+        //     t1 = min_j u_j / r_j over r_j > 0 (largest step keeping u >= 0)
+        {
+          double t1c = INF;
+          int t1j = 0;
+          for (int jb = 0; jb < q; jb += NT / 4) {
+            const int j = jb + (tid >> 2), part = tid & 3;
+            double acc = 0.0;
+            if (j < q) {
+              for (int i = part; i < q; i += 4) acc = dfma(Eref(S, j, i), Q.d[i], acc);
+            }
+            acc += dpp_xor1(acc);
+            acc += dpp_xor2(acc);
+            if (j < q && part == 0) {
+              Q.r[j] = acc;
+              if (acc > 1e-14) {
+                const double tj = Q.u[j] / acc;
+                if (tj < t1c) t1c = tj, t1j = j;
+              }
+            }
           }
-          acc += dpp_xor1(acc);
-          acc += dpp_xor2(acc);
-          if (j < q && part == 0) Q.r[j] = acc;
+          const double wmin = wave_min(t1c);
+          const unsigned long long bal = __ballot(t1c == wmin);
+          const int wl = (int)__ffsll((long long)bal) - 1;
+          if (ln == wl) {
+            Q.redv[wv] = t1c;
+            Q.redi[wv] = t1j;
+          }
         }
         __syncthreads();
         PROF_MARK(P_ED);
-        // (5) w = n+ - N_W' r
+        // (4) w = n+ - N_W' r
         gather_w(Q.r, -1.0, (is_v && v_e == ep) ? np[v_k] : 0.0);
         __syncthreads();
         PROF_MARK(P_W);
-        // (6) z = M w (partials; consumers sum the four j-quarters in a fixed order)
+        // (5) z = M w (partials; consumers sum the two j-halves in a fixed order)
         matvec(S, Q.w, n);
         PROF_MARK(P_MV);
+        // (6) step lengths and the step
         double delta = 0.0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) delta = dfma(np[k], zsum(Q, vFp + k), delta);
 #pragma unroll
         for (int k = 0; k < 3; ++k) delta = dfma(np[3 + k], zsum(Q, vMp + k), delta);
         const double gamma = Q.gamma;
-        // (7) largest dual step keeping u >= 0
-        double t1 = INF;
-        if (tid < q) {
-          const double rj = Q.r[tid];
-          if (rj > 1e-14) t1 = Q.u[tid] / rj;
-        }
-        {
-          const double wmin = wave_min(t1);
-          const unsigned long long bal = __ballot(t1 == wmin);
-          const int wl = (int)__ffsll((long long)bal) - 1;
-          if (ln == wl) {
-            Q.redv[wv] = t1;
-            Q.redi[wv] = tid;
-          }
-        }
-        __syncthreads();
         int l = Q.redi[0];
-        t1 = Q.redv[0];
+        double t1 = Q.redv[0];
 #pragma unroll
         for (int w = 1; w < NW; ++w) {
           const double ov = Q.redv[w];
           if (ov < t1) t1 = ov, l = Q.redi[w];
         }
-        PROF_MARK(P_T1);
-        const bool dep = !(delta > 1e-12 * gamma);
+        l = uni(l);
+        const bool dep = ub(!(delta > 1e-12 * gamma));
         const double t2 = dep ? INF : -sp / delta;
         const double t = (t1 < t2) ? t1 : t2;
-        if (t == INF) {
+        if (ub(t == INF)) {
           code = S_INFEASIBLE;
           break;
         }
-        // (8) step
         if (!dep && is_v) Q.x[tid] = dfma(t, zsum(Q, tid), Q.x[tid]);
         if (tid < q) Q.u[tid] = dfma(-t, Q.r[tid], Q.u[tid]);
         up += t;
         if (!dep) sp = dfma(t, delta, sp);
-        if (!dep && !(t1 < t2) && q >= SM::QMAX) {
+        const bool fullstep = ub(!dep && !(t1 < t2));
+        if (fullstep && q >= SM::QMAX) {
           code = S_WORKSET;
           break;
         }
-        if (!dep && !(t1 < t2)) {
+        if (fullstep) {
           // full step: constraint p joins the working set; bordered update of E (16 x 16 thread tiles of the lower triangle)
           const double idl = 1.0 / delta;
           const int ti = tid >> 4, tj = tid & 15;
