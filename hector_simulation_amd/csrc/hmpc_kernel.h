@@ -61,13 +61,11 @@ enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT =
 
 template <int NMAX, int HMAX>
 struct Smem {
-  static constexpr int LD = NMAX + 2;   // row stride of the square: 16-B aligned rows, conflict-free row-per-lane reads
   static constexpr int QMAX = (NMAX >= 120) ? 80 : NMAX;  // working-set capacity (packed Schur inverse)
   static constexpr int NLS = NMAX / 6;
   static constexpr int MMAX = NLS * 8;
   static constexpr int RECW = ((54 + 12 * HMAX) * 4 + 2 * HMAX + 15) / 16 * 4;  // record words
 
-  double sq[NMAX * LD];
   double g[NMAX];
   double Cn[2][8][6];
   double ub7[NLS];
@@ -88,12 +86,14 @@ struct Smem {
     float Apow[2 * 169];
     float Phi[HMAX * 156], SPhi[HMAX * 156];
     float e[13 * HMAX];
+    float Hs[(NMAX / 2) * (NMAX + 1)];  // H, upper triangle, binary32 (exact), rows i and NMAX-1-i folded into one
   };
   struct Sol {
     alignas(16) double x[NMAX], xu[NMAX], z[NMAX], w[NMAX];
-    alignas(16) double part[2][NMAX];
+    alignas(16) double RS[120][NMAX / 15];   // row partials of the in-place mat-vec, one entry per lane pair
+    alignas(16) double CS[240][NMAX / 30];   // mirrored (column) partials, one entry per block
     alignas(16) double piv[2][NMAX];
-    double u[NMAX], d[NMAX], r[NMAX], col[NMAX];
+    double u[NMAX], d[NMAX], r[NMAX];
     double redv[NW];
     double gamma;
     int redi[NW];
@@ -112,16 +112,12 @@ struct Smem {
   } u;
 };
 
-// upper-triangle access (assembly output H lives in the upper triangle only)
-template <int NMAX, int HMAX>
-__device__ __forceinline__ double &Uref(Smem<NMAX, HMAX> &S, int i, int j) {
-  const int lo = i < j ? i : j, hi = i < j ? j : i;
-  return S.sq[lo * Smem<NMAX, HMAX>::LD + hi];
-}
-// after the sweeps the square holds M = H^-1 in full (both triangles)
-template <int NMAX, int HMAX>
-__device__ __forceinline__ double &Mref(Smem<NMAX, HMAX> &S, int i, int j) {
-  return S.sq[i * Smem<NMAX, HMAX>::LD + j];
+// index of H(i,j), i <= j, in the folded upper-triangle staging array: row i (< NMAX/2) and row NMAX-1-i share one
+// storage row of NMAX+1 entries
+template <int NMAX>
+__device__ __forceinline__ int hs_index(int i, int j) {
+  const bool first = 2 * i < NMAX;
+  return (first ? i : NMAX - 1 - i) * (NMAX + 1) + (first ? j - i : j + 1);
 }
 template <int NMAX, int HMAX>
 __device__ __forceinline__ double &Eref(Smem<NMAX, HMAX> &S, int i, int j) {
@@ -157,53 +153,10 @@ __device__ __forceinline__ double wave_min(double v) {
   return dmin(dmin(r0, r1), dmin(r2, r3));
 }
 
-// partial products of z = M v over the full n x n inverse in the square.  Thread t < 2*NMAX: row t % NMAX, j-half
-// t / NMAX; rows are 16-B aligned (LD even) so a lane streams its half row with ds_read_b128 at immediate offsets,
-// the vector is read as broadcast b128.  The two partials of a row are summed by the consumer (zsum) in a fixed
-// order (deterministic).  One barrier inside (after the partials are written).
-template <int NMAX, int HMAX>
-__device__ __forceinline__ void matvec(Smem<NMAX, HMAX> &S, const double *v, int n) {
-  constexpr int LD = Smem<NMAX, HMAX>::LD;
-  constexpr int HALF = NMAX / 2;  // even
-  static_assert(2 * NMAX <= NT && HALF % 2 == 0, "two threads per row");
-  const int tid = threadIdx.x;
-  const int half = tid >= NMAX ? 1 : 0, i = tid - half * NMAX;
-  if (tid < 2 * NMAX && i < n) {
-    const double2 *mrow = reinterpret_cast<const double2 *>(S.sq + i * LD + half * HALF);
-    const double2 *vv = reinterpret_cast<const double2 *>(v + half * HALF);
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    // columns >= n of rows < n of the square, and entries >= n of v, are kept at exact zero (sweep store / solver
-    // init), so the loop runs over the padded width as straight-line code
-    static_assert((HALF / 2) % 2 == 0 || true, "");
-#pragma unroll
-    for (int c = 0; c + 1 < HALF / 2; c += 2) {
-      const double2 m0 = mrow[c], m1 = mrow[c + 1];
-      const double2 w0 = vv[c], w1 = vv[c + 1];
-      acc0 = dfma(m0.x, w0.x, acc0);
-      acc1 = dfma(m0.y, w0.y, acc1);
-      acc2 = dfma(m1.x, w1.x, acc2);
-      acc3 = dfma(m1.y, w1.y, acc3);
-    }
-    if ((HALF / 2) % 2 == 1) {
-      const double2 m0 = mrow[HALF / 2 - 1];
-      const double2 w0 = vv[HALF / 2 - 1];
-      acc0 = dfma(m0.x, w0.x, acc0);
-      acc1 = dfma(m0.y, w0.y, acc1);
-    }
-    S.u.s.part[half][i] = (acc0 + acc1) + (acc2 + acc3);
-  }
-  __syncthreads();
-}
-template <class SOL>
-__device__ __forceinline__ double zsum(const SOL &s, int i) {
-  return s.part[0][i] + s.part[1][i];
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 template <int NMAX, int HMAX, bool ASM_ONLY>
-__global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
+__global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelArgs args) {
   using SM = Smem<NMAX, HMAX>;
-  constexpr int LD = SM::LD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SM &S = *reinterpret_cast<SM *>(smem_raw);
   auto &A = S.u.a;
@@ -551,7 +504,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
         if (Rr <= Cc && Cc < n) {
           const float al = (Rr == Cc) ? in_al[S.vcomp[Rr]] : 0.0f;
           const float hv = 2.0f * (acc[rg] + al);
-          S.sq[Rr * LD + Cc] = (double)hv;
+          A.Hs[hs_index<NMAX>(Rr, Cc)] = hv;
         }
       }
     }
@@ -572,7 +525,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
     }
     for (int t = tid; t < n * n; t += NT) {
       const int i = t / n, j = t % n;
-      o[DL::H + t] = (float)Uref(S, i, j);
+      o[DL::H + t] = A.Hs[hs_index<NMAX>(i < j ? i : j, i < j ? j : i)];
     }
     for (int t = tid; t < 192; t += NT) o[DL::FC + t] = A.Fc[t];
     const float big = 5e10f;
@@ -595,40 +548,46 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
   // =============================== S: M = H^-1 by symmetric sweeps, matrix in registers ===============================
   // Thread t owns the TR x TC block (rows i0.., cols j0..) of the full symmetric matrix; the 240 blocks that intersect
   // the upper triangle are enumerated block-row-major (block row tr holds block columns 2tr..29), so the lanes that
-  // own pieces of one matrix row are contiguous.
+  // own pieces of one matrix row are contiguous and lanes (2k, 2k+1) always share a block row.
   // Sweep k:  d = a_kk, p = row k;  a_ij -= (p_i/d) p_j  (i,j != k);  a_kj = p_j/d;  a_kk = -1/d.  After n sweeps a = -H^-1.
   // Row k / column k entries take the same fused update with a substituted multiplier (1 - 1/d for row k, d - 1 for
   // column k: p_j - (1-1/d) p_j = p_j/d), so the inner 8x4 update has no special cases; only a_kk is patched.
   // The pivot row for sweep k+1 is published to LDS right after sweep k (double buffered) -> one barrier per sweep.
+  // The inverse never leaves the registers: the whole active-set phase multiplies by it in place (rmatvec below), which
+  // keeps the workgroup's LDS footprint at ~53 KB -> three workgroups (12 waves) per CU hide each other's latencies.
   constexpr int TR = NMAX / 15, TC = NMAX / 30;
   static_assert(TR * 15 == NMAX && TC * 30 == NMAX && TR == 2 * TC && TC % 2 == 0, "NMAX must be a multiple of 60");
-  {
-    int tr = 0;
-    while (tr < 14 && (tr + 1) * (30 - tr) <= tid) ++tr;
-    const bool owner = tid < 240;
-    const int tc = owner ? 2 * tr + (tid - tr * (31 - tr)) : 0;
-    if (!owner) tr = 0;
-    const int i0 = tr * TR, j0 = tc * TC;
-    double a[TR][TC];
+  const bool is_v = tid < n;
+  int tr = 0;
+  while (tr < 14 && (tr + 1) * (30 - tr) <= tid) ++tr;
+  const bool owner = tid < 240;
+  const int tc = owner ? 2 * tr + (tid - tr * (31 - tr)) : 0;
+  if (!owner) tr = 0;
+  const int i0 = tr * TR, j0 = tc * TC;
+  const int dgo = tc - 2 * tr;  // 0 or 1: the block straddles the diagonal at row offset dgo*TC; >= 2: strictly above it
+  double a[TR][TC];
 #pragma unroll
-    for (int ii = 0; ii < TR; ++ii)
+  for (int ii = 0; ii < TR; ++ii)
 #pragma unroll
-      for (int jj = 0; jj < TC; ++jj) {
-        const int i = i0 + ii, j = j0 + jj;
-        a[ii][jj] = (i < n && j < n) ? Uref(S, i, j) : 0.0;
-      }
-    if (tid < NMAX) Q.piv[0][tid] = 0.0, Q.piv[1][tid] = 0.0;
-    __syncthreads();
-    if (owner && i0 == 0) {
-#pragma unroll
-      for (int jj = 0; jj < TC; ++jj)
-        if (j0 + jj < n) Q.piv[0][j0 + jj] = a[0][jj];
+    for (int jj = 0; jj < TC; ++jj) {
+      const int i = i0 + ii, j = j0 + jj;
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      a[ii][jj] = (hi < n) ? (double)A.Hs[hs_index<NMAX>(lo, hi)] : 0.0;
     }
-    __syncthreads();
+  __syncthreads();  // every block is loaded before the solver state (which aliases the staging area) is written
+  if (tid < NMAX) Q.piv[0][tid] = 0.0, Q.piv[1][tid] = 0.0;
+  __syncthreads();
+  if (owner && i0 == 0) {
+#pragma unroll
+    for (int jj = 0; jj < TC; ++jj)
+      if (j0 + jj < n) Q.piv[0][j0 + jj] = a[0][jj];
+  }
+  __syncthreads();
+  {
     const int nkb = (n + TR - 1) / TR;
     for (int kb = 0; kb < nkb; ++kb) {
-      const bool rowb = owner && (tr == kb);       // my block holds matrix rows kb*TR .. kb*TR+TR-1
-      const bool rown = owner && (tr == kb + 1);   // ... or the next block row (publishes its row 0 at the seam)
+      const bool rowb = owner && (tr == kb);      // my block holds matrix rows kb*TR .. kb*TR+TR-1
+      const bool rown = owner && (tr == kb + 1);  // ... or the next block row (publishes its row 0 at the seam)
 #pragma unroll
       for (int kk = 0; kk < TR; ++kk) {
         const int k = kb * TR + kk;
@@ -650,9 +609,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
           double invd = __builtin_amdgcn_rcp(d);  // v_rcp_f64 + two Newton steps (the solver half is not bit-pinned)
           invd = dfma(dfma(-d, invd, 1.0), invd, invd);
           invd = dfma(dfma(-d, invd, 1.0), invd, invd);
-          constexpr int dummy = 0;
-          (void)dummy;
-          const int kc = kk % TC;                        // static column index inside the block column of k
+          const int kc = kk % TC;                                // static column index inside the block column of k
           const bool colb = owner && (tc == 2 * kb + kk / TC);  // my block holds matrix column k
           double qi[TR];
 #pragma unroll
@@ -691,29 +648,120 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
         }
       }
     }
-    // M = -a, both triangles; entries beyond n (exact zeros) are written too so that padded mat-vec reads are clean
-    if (owner) {
-#pragma unroll
-      for (int ii = 0; ii < TR; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < TC; ++jj) {
-          const int i = i0 + ii, j = j0 + jj;
-          if (i <= j) {
-            S.sq[i * LD + j] = -a[ii][jj];
-            S.sq[j * LD + i] = -a[ii][jj];
-          }
-        }
-    }
   }
+  // M = -a.  Lower-triangle duplicates inside diagonal blocks are zeroed and the diagonal is kept aside, so the in-place
+  // mat-vec needs no masks: rows use the block as is, the mirrored (column) part subtracts the diagonal term once.
+  double dg[TC];
+#pragma unroll
+  for (int jj = 0; jj < TC; ++jj) dg[jj] = 0.0;
+#pragma unroll
+  for (int ii = 0; ii < TR; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < TC; ++jj) {
+      const int df = ii - jj - dgo * TC;  // i - j for this element (only meaningful when dgo < 2)
+      const bool low = owner ? (dgo < 2 && df > 0) : true;
+      a[ii][jj] = low ? 0.0 : -a[ii][jj];
+      if (dgo < 2 && df == 0) dg[jj] = a[ii][jj];
+    }
   PROF_MARK(P_SWEEP);
 
+  // ---- z = M w out of the register blocks.  Each thread forms the 8 row partials and 4 mirrored column partials of its
+  // block; lane pairs pre-add their row partials (DPP); partials are staged in LDS and row i sums its <= 15 + 15 pieces in
+  // a fixed order (deterministic).  Two barriers.  wi/wj are the vector entries at the block's rows / columns.
+  auto rmv_block = [&](const double (&wi)[TR], const double (&wj)[TC]) {
+    double ra[TR], ca[TC];
+#pragma unroll
+    for (int ii = 0; ii < TR; ++ii) {
+      double s0 = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < TC; ++jj) s0 = dfma(a[ii][jj], wj[jj], s0);
+      ra[ii] = s0;
+    }
+#pragma unroll
+    for (int jj = 0; jj < TC; ++jj) {
+      double s0 = -dg[jj] * wj[jj], s1 = 0.0;
+#pragma unroll
+      for (int ii = 0; ii < TR; ii += 2) {
+        s0 = dfma(a[ii][jj], wi[ii], s0);
+        s1 = dfma(a[ii + 1][jj], wi[ii + 1], s1);
+      }
+      ca[jj] = s0 + s1;
+    }
+#pragma unroll
+    for (int ii = 0; ii < TR; ++ii) ra[ii] += dpp_xor1(ra[ii]);
+    if (owner) {
+      if ((tid & 1) == 0) {
+#pragma unroll
+        for (int ii = 0; ii < TR; ii += 2) *reinterpret_cast<double2 *>(&Q.RS[tid >> 1][ii]) = make_double2(ra[ii], ra[ii + 1]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < TC; jj += 2) *reinterpret_cast<double2 *>(&Q.CS[tid][jj]) = make_double2(ca[jj], ca[jj + 1]);
+    }
+    __syncthreads();
+    if (is_v) {
+      // all loads are issued up front (clamped addresses + selects, no data-dependent trip counts): one LDS round trip
+      const int btr = tid / TR, bi = tid % TR, btc = tid / TC, bj = tid % TC;
+      const int p0 = (btr * (31 - btr)) >> 1, np_ = 15 - btr, nt = (btc >> 1) + 1;
+      double rv[15], cv[15];
+#pragma unroll
+      for (int k = 0; k < 15; ++k) {
+        const int kc = (k < np_) ? k : 0;
+        rv[k] = Q.RS[p0 + kc][bi];
+        const int kt = (k < nt) ? k : 0;
+        cv[k] = Q.CS[kt * (31 - kt) + (btc - 2 * kt)][bj];
+      }
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) {
+        s0 += (k < np_) ? rv[k] : 0.0;
+        s1 += (k < nt) ? cv[k] : 0.0;
+      }
+      Q.z[tid] = s0 + s1;
+    }
+    __syncthreads();
+  };
+  auto rmatvec_dense = [&](const double *w) {
+    double wi[TR], wj[TC];
+#pragma unroll
+    for (int ii = 0; ii < TR; ii += 2) {
+      const double2 t2 = *reinterpret_cast<const double2 *>(w + i0 + ii);
+      wi[ii] = t2.x, wi[ii + 1] = t2.y;
+    }
+#pragma unroll
+    for (int jj = 0; jj < TC; jj += 2) {
+      const double2 t2 = *reinterpret_cast<const double2 *>(w + j0 + jj);
+      wj[jj] = t2.x, wj[jj + 1] = t2.y;
+    }
+    rmv_block(wi, wj);
+  };
+  // vector with six non-zeros npv[0..2] at vF.., npv[3..5] at vM..: built in registers, no LDS round trip
+  auto rmatvec_sparse6 = [&](const double (&npv)[6], int vF, int vM) {
+    double wi[TR], wj[TC];
+#pragma unroll
+    for (int ii = 0; ii < TR; ++ii) {
+      const int dF = i0 + ii - vF, dM = i0 + ii - vM;
+      double v = 0.0;
+      v = (dF == 0) ? npv[0] : v, v = (dF == 1) ? npv[1] : v, v = (dF == 2) ? npv[2] : v;
+      v = (dM == 0) ? npv[3] : v, v = (dM == 1) ? npv[4] : v, v = (dM == 2) ? npv[5] : v;
+      wi[ii] = v;
+    }
+#pragma unroll
+    for (int jj = 0; jj < TC; ++jj) {
+      const int dF = j0 + jj - vF, dM = j0 + jj - vM;
+      double v = 0.0;
+      v = (dF == 0) ? npv[0] : v, v = (dF == 1) ? npv[1] : v, v = (dF == 2) ? npv[2] : v;
+      v = (dM == 0) ? npv[3] : v, v = (dM == 1) ? npv[4] : v, v = (dM == 2) ? npv[5] : v;
+      wj[jj] = v;
+    }
+    rmv_block(wi, wj);
+  };
+
   // =============================== Q: dual active set (Goldfarb-Idnani, range-space form) ===============================
-  // Fixed thread roles, constants held in registers for the whole solve:
-  //   thread c < m  : constraint row c (leg-step c>>3, row c&7): its 6 coefficients, variable offsets, bounds
-  //   thread i < n  : variable i: its leg-step, position in it, and the 8 coefficients of its column
+  // Fixed thread roles: thread c < m = constraint row c (leg-step c>>3, row c&7) with its 6 coefficients, variable
+  // offsets and bounds in registers; thread i < n = variable i.
   const double INF = __builtin_huge_val();
   const double FEAS_TOL = 1e-9;
-  const bool is_c = tid < m, is_v = tid < n;
+  const bool is_c = tid < m;
   int c_vF = 0, c_vM = 0;
   double c_cn[6] = {0, 0, 0, 0, 0, 0}, c_ub = INF, c_scale = 1.0;
   bool c_hasl = false, c_hasu = false;
@@ -727,24 +775,21 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
     c_ub = (rr == 4) ? (double)0.01f : (rr == 7 ? S.ub7[e] : 0.0);
     c_scale = (rr == 7 && c_ub > 1.0) ? 1.0 / c_ub : 1.0;  // the Fz cap is O(f_max): compare it on a unit scale
   }
-  int v_e = 0, v_k = 0;
-  double v_col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int v_e = 0, v_k = 0, v_leg = 0;
   if (is_v) {
     v_e = S.vls[tid], v_k = S.vk[tid];
-    const int leg = S.ls_leg[v_e];
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) v_col[rr] = S.Cn[leg][rr][v_k];
+    v_leg = S.ls_leg[v_e];
   }
   for (int t = tid; t < m; t += NT) {
     Q.act[t] = 0;
     Q.slot[t] = 0;
   }
   if (tid < NMAX) Q.r[tid] = 0.0;
-  if (tid < NMAX) Q.w[tid] = is_v ? -S.g[tid] : 0.0;  // entries >= n stay exactly 0 for the padded mat-vec
+  if (tid < NMAX) Q.w[tid] = is_v ? -S.g[tid] : 0.0;  // entries >= n stay exactly 0
   __syncthreads();
-  matvec(S, Q.w, n);  // unconstrained minimiser x_u = -M g
+  rmatvec_dense(Q.w);  // unconstrained minimiser x_u = -M g
   if (is_v) {
-    const double xv = zsum(Q, tid);
+    const double xv = Q.z[tid];
     Q.xu[tid] = xv;
     Q.x[tid] = xv;
   }
@@ -756,11 +801,12 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
 
   // slack of this thread's constraint row on its tighter side at xv (unit-scaled); side = +1 lower, -1 upper
   auto my_slack = [&](const double *xv, int &side, double &raw) -> double {
-    double s = 0.0;
+    double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) s = dfma(c_cn[k], xv[c_vF + k], s);
+    for (int k = 0; k < 3; ++k) s0 = dfma(c_cn[k], xv[c_vF + k], s0);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) s = dfma(c_cn[3 + k], xv[c_vM + k], s);
+    for (int k = 0; k < 3; ++k) s1 = dfma(c_cn[3 + k], xv[c_vM + k], s1);
+    const double s = s0 + s1;
     const double sl = c_hasl ? s : INF;
     const double su = c_hasu ? (c_ub - s) : INF;
     const double ssu = su * c_scale;
@@ -773,16 +819,18 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
     if (is_v) {
       const unsigned long long am = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * v_e]);
       const unsigned long long sm = *reinterpret_cast<const unsigned long long *>(&Q.slot[8 * v_e]);
-      double acc = extra;
+      double acc0 = extra, acc1 = 0.0;
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
         const int ac = (int)(signed char)((am >> (8 * rr)) & 0xff);
         const int sl = (int)((sm >> (8 * rr)) & 0xff);
         const double cf = coefv[sl];
         const double coef = (ac == 0) ? 0.0 : ((ac > 0) ? sgn * cf : -sgn * cf);
-        acc = dfma(coef, v_col[rr], acc);
+        const double cv = S.Cn[v_leg][rr][v_k];
+        if (rr & 1) acc1 = dfma(coef, cv, acc1);
+        else acc0 = dfma(coef, cv, acc0);
       }
-      Q.w[tid] = acc;
+      Q.w[tid] = acc0 + acc1;
     }
   };
 
@@ -839,20 +887,16 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
           code = S_MAXITER;
           break;
         }
-        // (2) every constraint thread: a_c' M n+ straight from the 6x6 sub-block of M (36 independent LDS reads);
-        //     active rows scatter d[slot] = sign * a_c' M n+; row p gives gamma = n+' M n+
+        // (2) y = M n+ in place (n+ has six non-zeros), then every constraint thread forms a_c' y; active rows scatter
+        //     d[slot] = sign * a_c' y; row p gives gamma = n+' M n+
+        rmatvec_sparse6(np, vFp, vMp);
         if (is_c) {
-          double dc = 0.0;
+          double d0 = 0.0, d1 = 0.0;
 #pragma unroll
-          for (int a6 = 0; a6 < 6; ++a6) {
-            const double *mr = S.sq + ((a6 < 3) ? (c_vF + a6) : (c_vM + a6 - 3)) * LD;
-            double t = 0.0;
+          for (int k = 0; k < 3; ++k) d0 = dfma(c_cn[k], Q.z[c_vF + k], d0);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) t = dfma(mr[vFp + k], np[k], t);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) t = dfma(mr[vMp + k], np[3 + k], t);
-            dc = dfma(c_cn[a6], t, dc);
-          }
+          for (int k = 0; k < 3; ++k) d1 = dfma(c_cn[3 + k], Q.z[c_vM + k], d1);
+          const double dc = d0 + d1;
           const int ac = Q.act[tid];
           if (ac != 0) Q.d[Q.slot[tid]] = (double)ac * dc;
           if (tid == p) Q.gamma = sg * dc;
@@ -868,7 +912,17 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
             const int j = jb + (tid >> 2), part = tid & 3;
             double acc = 0.0;
             if (j < q) {
-              for (int i = part; i < q; i += 4) acc = dfma(Eref(S, j, i), Q.d[i], acc);
+              double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+              for (int i = part; i < q; i += 16) {
+                const int i1 = (i + 4 < q) ? i + 4 : i, i2 = (i + 8 < q) ? i + 8 : i, i3 = (i + 12 < q) ? i + 12 : i;
+                const double e0 = Eref(S, j, i), e1 = Eref(S, j, i1), e2 = Eref(S, j, i2), e3 = Eref(S, j, i3);
+                const double d0 = Q.d[i], d1 = Q.d[i1], d2 = Q.d[i2], d3 = Q.d[i3];
+                a0 = dfma(e0, d0, a0);
+                a1 = (i + 4 < q) ? dfma(e1, d1, a1) : a1;
+                a2 = (i + 8 < q) ? dfma(e2, d2, a2) : a2;
+                a3 = (i + 12 < q) ? dfma(e3, d3, a3) : a3;
+              }
+              acc = (a0 + a1) + (a2 + a3);
             }
             acc += dpp_xor1(acc);
             acc += dpp_xor2(acc);
@@ -894,15 +948,15 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
         gather_w(Q.r, -1.0, (is_v && v_e == ep) ? np[v_k] : 0.0);
         __syncthreads();
         PROF_MARK(P_W);
-        // (5) z = M w (partials; consumers sum the two j-halves in a fixed order)
-        matvec(S, Q.w, n);
+        // (5) z = M w
+        rmatvec_dense(Q.w);
         PROF_MARK(P_MV);
         // (6) step lengths and the step
         double delta = 0.0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) delta = dfma(np[k], zsum(Q, vFp + k), delta);
+        for (int k = 0; k < 3; ++k) delta = dfma(np[k], Q.z[vFp + k], delta);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) delta = dfma(np[3 + k], zsum(Q, vMp + k), delta);
+        for (int k = 0; k < 3; ++k) delta = dfma(np[3 + k], Q.z[vMp + k], delta);
         const double gamma = Q.gamma;
         int l = Q.redi[0];
         double t1 = Q.redv[0];
@@ -919,7 +973,7 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
           code = S_INFEASIBLE;
           break;
         }
-        if (!dep && is_v) Q.x[tid] = dfma(t, zsum(Q, tid), Q.x[tid]);
+        if (!dep && is_v) Q.x[tid] = dfma(t, Q.z[tid], Q.x[tid]);
         if (tid < q) Q.u[tid] = dfma(-t, Q.r[tid], Q.u[tid]);
         up += t;
         if (!dep) sp = dfma(t, delta, sp);
@@ -999,8 +1053,8 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
     for (int it = 0; it < 3; ++it) {
       gather_w(Q.u, 1.0, 0.0);
       __syncthreads();
-      matvec(S, Q.w, n);
-      if (is_v) Q.x[tid] = Q.xu[tid] + zsum(Q, tid);
+      rmatvec_dense(Q.w);
+      if (is_v) Q.x[tid] = Q.xu[tid] + Q.z[tid];
       __syncthreads();
       if (it == 2) break;
       if (is_c) {
@@ -1020,7 +1074,15 @@ __global__ __launch_bounds__(NT) void hmpc_kernel(KernelArgs args) {
         const int j = jb + (tid >> 2), part = tid & 3;
         double acc = 0.0;
         if (j < q) {
-          for (int i = part; i < q; i += 4) acc = dfma(Eref(S, j, i), Q.d[i], acc);
+          double a0 = 0.0, a1 = 0.0;
+          for (int i = part; i < q; i += 8) {
+            const int i1 = (i + 4 < q) ? i + 4 : i;
+            const double e0 = Eref(S, j, i), e1 = Eref(S, j, i1);
+            const double d0 = Q.d[i], d1 = Q.d[i1];
+            a0 = dfma(e0, d0, a0);
+            a1 = (i + 4 < q) ? dfma(e1, d1, a1) : a1;
+          }
+          acc = a0 + a1;
         }
         acc += dpp_xor1(acc);
         acc += dpp_xor2(acc);
