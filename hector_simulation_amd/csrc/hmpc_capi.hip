@@ -33,21 +33,23 @@ thread_local std::string g_hip_err;
 typedef void (*kernel_fn)(hmpc::KernelArgs);
 
 struct Variant {
-  int nmax, hmax;
+  int nmax, hmax, nt;
   kernel_fn solve, assemble;
   size_t smem;
   int dbg_floats;
 };
 
-template <int NMAX, int HMAX>
+// NMAX = reduced variables held on chip (6 per stance leg-step); 120 -> 256-thread workgroups (210 register blocks),
+// 60 (single support over h <= 10) -> 128-thread workgroups (55 blocks)
+template <int NMAX, int HMAX, int NT>
 Variant make_variant() {
-  return Variant{NMAX, HMAX, hmpc::hmpc_kernel<NMAX, HMAX, false>, hmpc::hmpc_kernel<NMAX, HMAX, true>,
-                 sizeof(hmpc::Smem<NMAX, HMAX>), hmpc::DbgLayout<NMAX>::TOTAL};
+  return Variant{NMAX, HMAX, NT, hmpc::hmpc_kernel<NMAX, HMAX, NT, false>, hmpc::hmpc_kernel<NMAX, HMAX, NT, true>,
+                 sizeof(hmpc::Smem<NMAX, HMAX, NT>), hmpc::DbgLayout<NMAX>::TOTAL};
 }
 
 const Variant *variants() {
-  static const Variant v[] = {make_variant<60, 10>(), make_variant<120, 10>(), make_variant<60, 20>(),
-                              make_variant<120, 20>()};
+  static const Variant v[] = {make_variant<60, 10, 128>(), make_variant<120, 10, 256>(), make_variant<60, 20, 128>(),
+                              make_variant<120, 20, 256>()};
   return v;
 }
 constexpr int N_VARIANTS = 4;
@@ -68,6 +70,7 @@ struct hmpc_handle {
   float *d_dbg_f;
   int *d_dbg_i;
   long long *d_prof;
+  int warm;        // block warm start of the working set (default on)
   int max_stance;  // max reduced variables of the current batch (known only for host-uploaded records; else -1)
   hipStream_t last_stream;
   bool attrs_set[N_VARIANTS];
@@ -112,8 +115,9 @@ static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int db
   a.dbg_f = h->d_dbg_f;
   a.dbg_i = h->d_dbg_i;
   a.prof = h->d_prof;
+  a.warm = h->warm;
   const int grid = assemble_only ? 1 : h->batch;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(hmpc::NT), v.smem, stream, a);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(v.nt), v.smem, stream, a);
   HIP_TRY(hipGetLastError());
   return HMPC_OK;
 }
@@ -162,6 +166,7 @@ int hmpc_create(hmpc_handle **out, const struct problem_setup *setup, int max_ba
   h->device = device;
   h->stride = record_stride(setup->horizon);
   h->max_stance = -1;
+  h->warm = 1;
   const size_t nf = (size_t)max_batch * 12 * setup->horizon;
   if (hipMalloc(&h->d_records_own, (size_t)max_batch * h->stride) != hipSuccess ||
       hipMalloc(&h->d_forces_own, nf * sizeof(float)) != hipSuccess ||
@@ -228,6 +233,12 @@ int hmpc_set_device_records(hmpc_handle *h, const void *device_records, int batc
 int hmpc_set_max_reduced_vars(hmpc_handle *h, int n_reduced) {
   if (!h) return HMPC_E_ARG;
   h->max_stance = n_reduced;
+  return HMPC_OK;
+}
+
+int hmpc_set_warm_start(hmpc_handle *h, int on) {
+  if (!h) return HMPC_E_ARG;
+  h->warm = on ? 1 : 0;
   return HMPC_OK;
 }
 

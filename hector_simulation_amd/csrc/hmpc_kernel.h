@@ -1,28 +1,29 @@
-// hmpc_kernel.h -- the fused assembly + QP-solve kernel (one 256-thread workgroup per MPC instance, gfx950).
+// hmpc_kernel.h -- the fused assembly + QP-solve kernel (one workgroup per MPC instance, gfx950).
 //
 // Replaces, for a whole batch at once, the reference's per-tick CPU path
 //   update_problem_data -> solve_mpc -> qpOASES::QProblem::init
 //   (ConvexMPC/convexMPC_interface.cpp:83-103, ConvexMPC/SolverMPC.cpp:371-738, third_party/qpOASES/src/QProblem.cpp:316).
 //
 // Phases (all state lives in LDS / registers; HBM sees only the ~716 B record in and 12h floats + 1 word out):
-//   A  assembly in binary32 under the HMPC-A1 arithmetic contract (bit-identical to oracle/hmpc_oracle.c):
+//   A  assembly in binary32 under the HMPC-A1 arithmetic contract (bit-identical to the CPU oracle):
 //      trig -> scalar algebra -> Acd^k, Phi_k = Acd^k Bcd -> tracking error -> swing elimination tables
 //      -> H = 2(B'SB + alpha) on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 = k-ordered fmaf chain), g.
-//   S  M = H^-1 in binary64 by n symmetric sweeps, matrix held in registers (8x4 tile per thread), one barrier a sweep.
-//   Q  dual active-set (Goldfarb-Idnani in range-space form): Schur inverse E = (N M N')^-1 kept explicitly and
-//      updated by bordering / Schur-complement rank-1 steps, so every iteration is parallel mat-vecs -- no
-//      triangular solves.  Two steps of iterative refinement of the multipliers at the end.
-// LDS layout: one (n x (n+1)) binary64 square holds M in its upper triangle (diagonal included) and E packed in
-// its strict lower triangle (E(i,j), i>=j, at row i+1, column j); assembly scratch and solver vectors share a union.
+//   S  M = H^-1 in binary64 by n symmetric sweeps.  The matrix lives in REGISTERS for the rest of the kernel: the
+//      reduced variables are ordered leg-step by leg-step ([F(3), M(3)] per stance leg-step), and thread t owns the
+//      6x6 block M(e,e') between two leg-steps (e <= e'): 210 blocks for 20 leg-steps.
+//   W  block warm start: every moment / line-contact row (rows 4-6 of a leg-step's 8) violated at the unconstrained
+//      minimiser enters the working set at once.  Their Schur matrix N M N' is formed block-locally (a row touches one
+//      leg-step, so n_i' M n_j needs only the 6x6 block its owner already holds), inverted in LDS, and rows whose
+//      multiplier comes out negative are removed again -> a valid Goldfarb-Idnani state, ~20 iterations saved.
+//   Q  dual active set (Goldfarb-Idnani, range-space form) from that state: Schur inverse E = (N M N')^-1 kept
+//      explicitly (bordering / Schur-complement downdates: no triangular solves), M applied in place from the register
+//      blocks with a fixed-order staged reduction (deterministic).  Two refinement steps of the multipliers at the end.
 #pragma once
 #include <stdint.h>
 
 #include "hmpc_math.h"
 
 namespace hmpc {
-
-constexpr int NT = 256;  // threads per workgroup
-constexpr int NW = NT / 64;
 
 struct KernelArgs {
   const unsigned char *records;
@@ -36,10 +37,11 @@ struct KernelArgs {
   int dbg_index;
   float *dbg_f;
   int *dbg_i;
-  long long *prof;  // optional [batch][HMPC_NPROF] per-phase shader-clock cycles (thread 0's view), profiling builds only
+  long long *prof;  // optional [batch][NPROF] per-phase shader-clock cycles (thread 0's view), profiling builds only
+  int warm;         // 1: block warm start of the working set (default), 0: cold start as the reference does
 };
 constexpr int NPROF = 24;
-enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_SW_RD, P_SW_FMA, P_SW_PUB, P_SW_BAR };
+enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK };
 #ifdef HMPC_PROFILE
 #define PROF_DECL long long _pt = clock64(), _pt0 = _pt; long long _pacc[NPROF] = {0}
 #define PROF_MARK(ph) do { long long _n = clock64(); _pacc[ph] += _n - _pt; _pt = _n; } while (0)
@@ -59,20 +61,23 @@ struct DbgLayout {
 
 enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT = 4, S_WORKSET = 5 };
 
-template <int NMAX, int HMAX>
+constexpr int GS = 6;  // variables per stance leg-step: force (3) then moment (3)
+
+template <int NMAX, int HMAX, int NT>
 struct Smem {
+  static constexpr int NG = NMAX / GS;   // leg-steps (blocks per matrix side)
+  static constexpr int MMAX = NG * 8;    // constraint rows
+  static constexpr int NW = NT / 64;
   static constexpr int QMAX = (NMAX >= 120) ? 80 : NMAX;  // working-set capacity (packed Schur inverse)
-  static constexpr int NLS = NMAX / 6;
-  static constexpr int MMAX = NLS * 8;
   static constexpr int RECW = ((54 + 12 * HMAX) * 4 + 2 * HMAX + 15) / 16 * 4;  // record words
 
-  double g[NMAX];
-  double Cn[2][8][6];
-  double ub7[NLS];
-  unsigned char vstep[NMAX], vcomp[NMAX];
-  unsigned char vls[NMAX], vk[NMAX];  // variable -> its leg-step, position in it (0-2 force, 3-5 moment)
-  unsigned char rmap[12 * HMAX];  // original variable -> reduced index (255 = eliminated)
-  unsigned char ls_step[NLS], ls_leg[NLS], ls_vF[NLS], ls_vM[NLS];
+  double g[NMAX];        // gradient, sweep order
+  double Cn[2][8][6];    // per-leg constraint normals (columns: F then M of that leg)
+  double ub7[NG];        // Fz cap f_max*gait of each stance leg-step
+  unsigned char vstep[NMAX], vcomp[NMAX];  // reference-order reduced variable -> horizon step, component (0..11)
+  unsigned char o2s[NMAX], s2o[NMAX];      // reference order <-> sweep order (leg-step major)
+  unsigned char rmap[12 * HMAX];           // original variable 12*step+comp -> sweep index (255 = eliminated)
+  unsigned char ls_leg[NG];
   int n, m, nls, pad0;
 
   struct Asm {
@@ -81,26 +86,26 @@ struct Smem {
     float sc234[2][2];
     float rpy[3];
     float ypsc[4];  // cy, sy, cp, sp
-    float R[9], Rt[9];
     float Acd[169], Bcd[156], x0[13], W[13], Fc[192];
     float Apow[2 * 169];
     float Phi[HMAX * 156], SPhi[HMAX * 156];
     float e[13 * HMAX];
     float Hs[(NMAX / 2) * (NMAX + 1)];  // H, upper triangle, binary32 (exact), rows i and NMAX-1-i folded into one
   };
+  struct Rec {
+    double val, raw, cn[6];
+    int idx, side, pad1, pad2;
+  };
   struct Sol {
     alignas(16) double x[NMAX], xu[NMAX], z[NMAX], w[NMAX];
-    alignas(16) double RS[120][NMAX / 15];   // row partials of the in-place mat-vec, one entry per lane pair
-    alignas(16) double CS[240][NMAX / 30];   // mirrored (column) partials, one entry per block
+    alignas(16) double ST[NG][NMAX];  // staged partials of the in-place mat-vec: ST[source leg-step][variable]
     alignas(16) double piv[2][NMAX];
-    double u[NMAX], d[NMAX], r[NMAX];
-    double redv[NW];
+    double u[NMAX], d[NMAX], r[NMAX], col[NMAX];
+    double redv[NW], redw[NW];
     double gamma;
     int redi[NW];
-    struct Rec {
-      double val, raw, cn[6];
-      int idx, side, vF, vM;
-    } rec[NW];
+    int wcount[NW];
+    Rec rec[NW];
     alignas(8) signed char act[MMAX];
     alignas(8) unsigned char slot[MMAX];
     unsigned char Wrow[NMAX];
@@ -119,8 +124,8 @@ __device__ __forceinline__ int hs_index(int i, int j) {
   const bool first = 2 * i < NMAX;
   return (first ? i : NMAX - 1 - i) * (NMAX + 1) + (first ? j - i : j + 1);
 }
-template <int NMAX, int HMAX>
-__device__ __forceinline__ double &Eref(Smem<NMAX, HMAX> &S, int i, int j) {
+template <class SM>
+__device__ __forceinline__ double &Eref(SM &S, int i, int j) {
   const int lo = i < j ? i : j, hi = i < j ? j : i;
   return S.u.s.Ep[hi * (hi + 1) / 2 + lo];
 }
@@ -153,10 +158,33 @@ __device__ __forceinline__ double wave_min(double v) {
   return dmin(dmin(r0, r1), dmin(r2, r3));
 }
 
+// body rotation from the quaternion (RobotState.cpp:17-30; Eigen toRotationMatrix closed form) and its transpose
+__device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
+  const float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+  float tx = 2.0f * qx, ty = 2.0f * qy, tz = 2.0f * qz;
+  float twx = tx * qw, twy = ty * qw, twz = tz * qw;
+  float txx = tx * qx, txy = ty * qx, txz = tz * qx;
+  float tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  R[0] = 1.0f - (tyy + tzz);
+  R[1] = txy - twz;
+  R[2] = txz + twy;
+  R[3] = txy + twz;
+  R[4] = 1.0f - (txx + tzz);
+  R[5] = tyz - twx;
+  R[6] = txz - twy;
+  R[7] = tyz + twx;
+  R[8] = 1.0f - (txx + tyy);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Rt[k * 3 + i] = R[i * 3 + k];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-template <int NMAX, int HMAX, bool ASM_ONLY>
-__global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelArgs args) {
-  using SM = Smem<NMAX, HMAX>;
+template <int NMAX, int HMAX, int NT, bool ASM_ONLY>
+__global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
+  using SM = Smem<NMAX, HMAX, NT>;
+  constexpr int NG = SM::NG, NW = SM::NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SM &S = *reinterpret_cast<SM *>(smem_raw);
   auto &A = S.u.a;
@@ -181,7 +209,8 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
   const float *in_p = rf + 0, *in_v = rf + 3, *in_q = rf + 6, *in_w = rf + 10, *in_r = rf + 13, *in_ja = rf + 19,
               *in_wt = rf + 30, *in_al = rf + 42, *in_traj = rf + 54;
 
-  // ---------------- A1: trigonometry, one lane per angle (SolverMPC.cpp:374-393, 333-342, 74-85) ----------------
+  // ---------------- A1: trigonometry, one lane per angle (SolverMPC.cpp:374-393, 333-342, 74-85); a lane of another
+  // wave builds the swing-leg elimination tables meanwhile (SolverMPC.cpp:589-637)
   {
     const double PI = 3.14159265359, PI2 = 2 * PI;
     auto joint = [&](int i) -> float {
@@ -231,41 +260,36 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
         A.ypsc[1] = (float)s;
       }
     } else if (tid == 64) {
-      // swing-leg elimination tables (SolverMPC.cpp:589-637): a leg-step survives iff its Fz bound f_max*gait is not ~0
+      // a leg-step survives iff its Fz bound f_max*gait is not ~0.  Two orders of the surviving variables:
+      //  reference order (ascending original index, SolverMPC.cpp:644-658): used to build H, g bit-identically;
+      //  sweep order (leg-step major, [F(3), M(3)] each): used by the solver, 6x6 blocks = leg-step pairs.
       int nv = 0, nl = 0;
       for (int i = 0; i < h; ++i) {
         float ubL = args.f_max * (float)gait[2 * i], ubR = args.f_max * (float)gait[2 * i + 1];
         const bool sL = !(ubL < 0.0001 && ubL > -.0001), sR = !(ubR < 0.0001 && ubR > -.0001);
         const int nst = (int)sL + (int)sR;
         for (int c = 0; c < 12; ++c) S.rmap[12 * i + c] = 255;
-        if (nv + 6 * nst <= NMAX) {
-          int k = 0;
-          for (int c = 0; c < 12; ++c) {
-            const int leg = (c / 3) & 1;
-            if (leg == 0 ? sL : sR) {
-              S.vstep[nv + k] = (unsigned char)i;
-              S.vcomp[nv + k] = (unsigned char)c;
-              S.rmap[12 * i + c] = (unsigned char)(nv + k);
-              ++k;
-            }
-          }
+        if (nl + nst <= NG) {
           int rank = 0;
           for (int leg = 0; leg < 2; ++leg)
             if (leg == 0 ? sL : sR) {
-              S.ls_step[nl] = (unsigned char)i;
-              S.ls_leg[nl] = (unsigned char)leg;
-              S.ls_vF[nl] = (unsigned char)(nv + 3 * rank);
-              S.ls_vM[nl] = (unsigned char)(nv + 3 * nst + 3 * rank);
-              S.ub7[nl] = (double)(leg == 0 ? ubL : ubR);
+              const int e = nl + rank;
+              S.ls_leg[e] = (unsigned char)leg;
+              S.ub7[e] = (double)(leg == 0 ? ubL : ubR);
               for (int k = 0; k < 3; ++k) {
-                S.vls[nv + 3 * rank + k] = (unsigned char)nl, S.vk[nv + 3 * rank + k] = (unsigned char)k;
-                S.vls[nv + 3 * nst + 3 * rank + k] = (unsigned char)nl, S.vk[nv + 3 * nst + 3 * rank + k] = (unsigned char)(3 + k);
+                const int oF = nv + 3 * rank + k, oM = nv + 3 * nst + 3 * rank + k;
+                S.vstep[oF] = (unsigned char)i, S.vcomp[oF] = (unsigned char)(3 * leg + k);
+                S.vstep[oM] = (unsigned char)i, S.vcomp[oM] = (unsigned char)(6 + 3 * leg + k);
+                S.o2s[oF] = (unsigned char)(GS * e + k), S.s2o[GS * e + k] = (unsigned char)oF;
+                S.o2s[oM] = (unsigned char)(GS * e + 3 + k), S.s2o[GS * e + 3 + k] = (unsigned char)oM;
+                S.rmap[12 * i + 3 * leg + k] = (unsigned char)(GS * e + k);
+                S.rmap[12 * i + 6 + 3 * leg + k] = (unsigned char)(GS * e + 3 + k);
               }
-              ++nl;
               ++rank;
             }
         }
         nv += 6 * nst;
+        nl += nst;
       }
       S.n = nv;
       S.nls = nl;
@@ -274,25 +298,11 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
   }
   __syncthreads();
 
-  // ---------------- A2: scalar algebra on one lane (RobotState.cpp:17-47, SolverMPC.cpp:65-89,302-331,420-433,488-548)
+  // ---------------- A2: scalar algebra (RobotState.cpp:17-47, SolverMPC.cpp:65-89,302-331,420-433,488-548): body on a
+  // lane of wave 0, one foot per lane of two other waves (different waves, so the three run concurrently)
   if (tid == 0) {
-    const float qw = in_q[0], qx = in_q[1], qy = in_q[2], qz = in_q[3];
     float R[9], Rt[9];
-    {
-      float tx = 2.0f * qx, ty = 2.0f * qy, tz = 2.0f * qz;
-      float twx = tx * qw, twy = ty * qw, twz = tz * qw;
-      float txx = tx * qx, txy = ty * qx, txz = tz * qx;
-      float tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
-      R[0] = 1.0f - (tyy + tzz);
-      R[1] = txy - twz;
-      R[2] = txz + twy;
-      R[3] = txy + twz;
-      R[4] = 1.0f - (txx + tzz);
-      R[5] = tyz - twx;
-      R[6] = txz - twy;
-      R[7] = tyz + twx;
-      R[8] = 1.0f - (txx + tyy);
-    }
+    quat_to_R(in_q, R, Rt);
     float Rbi[9];
     {
       const float cy = A.ypsc[0], sy = A.ypsc[1], cp = A.ypsc[2], sp = A.ypsc[3];
@@ -311,13 +321,9 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        RI[i * 3 + k] = R[i * 3 + k] * Ib[k];
-        Rt[k * 3 + i] = R[i * 3 + k];
-      }
+      for (int k = 0; k < 3; ++k) RI[i * 3 + k] = R[i * 3 + k] * Ib[k];
     chain_mm<3, 3, 3>(RI, Rt, Iw);
     inverse3(Iw, Iinv);
-    for (int i = 0; i < 9; ++i) A.R[i] = R[i], A.Rt[i] = Rt[i];
 
     // continuous model -> forward Euler (SolverMPC.cpp:312-331, 145-146); mass 9.0 (:423)
     const float dt = args.dt;
@@ -342,11 +348,16 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
     }
     for (int s = 0; s < 12; ++s) A.W[s] = in_wt[s];
     A.W[12] = 0.0f;
-
-    // foot rotations Rz(q0)Rx(q1)Ry(q2)Ry(q3)Ry(q4) and the 16x12 constraint block (SolverMPC.cpp:426-433, 488-548)
-    const float mu = 2.0f, lt = 0.09f, lh = 0.06f;
-    for (int i = 0; i < 192; ++i) A.Fc[i] = 0.0f;
-    for (int leg = 0; leg < 2; ++leg) {
+  }
+  {
+    // foot rotation Rz(q0)Rx(q1)Ry(q2)Ry(q3)Ry(q4) and this leg's 8 rows of the 16x12 constraint block
+    // (SolverMPC.cpp:426-433, 488-548)
+    const int leg_lane0 = (NT >= 256) ? 128 : 64, leg_lane1 = (NT >= 256) ? 192 : 65;
+    if (tid == leg_lane0 || tid == leg_lane1) {
+      const int leg = (tid == leg_lane0) ? 0 : 1;
+      float R[9], Rt[9];
+      quat_to_R(in_q, R, Rt);
+      const float mu = 2.0f, lt = 0.09f, lh = 0.06f;
       const int b = 5 * leg;
       const float s0 = A.sc[b][0], c0 = A.sc[b][1], s1 = A.sc[b + 1][0], c1 = A.sc[b + 1][1];
       const float s2 = A.sc[b + 2][0], c2 = A.sc[b + 2][1], s3 = A.sc[b + 3][0], c3 = A.sc[b + 3][1];
@@ -381,6 +392,7 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
       chain_mm<1, 3, 3>(vlt, Rt, flt);
       chain_mm<1, 3, 3>(vlh, Rt, flh);
       float *row = A.Fc + (8 * leg) * 12;
+      for (int i = 0; i < 96; ++i) row[i] = 0.0f;
       const int cf = 3 * leg, cmo = 6 + 3 * leg;
       row[0 * 12 + cf + 0] = -mu, row[0 * 12 + cf + 2] = 1.0f;
       row[1 * 12 + cf + 0] = mu, row[1 * 12 + cf + 2] = 1.0f;
@@ -406,8 +418,8 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
   for (int t = tid; t < 169; t += NT) A.Apow[t] = (t % 14 == 0) ? 1.0f : 0.0f;
   __syncthreads();
 
-  const int n = uni(S.n), m = uni(S.m), nls = uni(S.nls);
-  if (n > NMAX) {  // uniform
+  const int n = uni(S.n), m = uni(S.m), ng = uni(S.nls);
+  if (ng > NG) {  // uniform
     if (!ASM_ONLY) {
       for (int t = tid; t < 12 * h; t += NT) args.forces[(size_t)inst * 12 * h + t] = 0.0f;
       if (tid == 0) args.status[inst] = S_TOO_LARGE;
@@ -455,7 +467,7 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
   }
 
   PROF_MARK(P_ASM);
-  // ---------------- A5: g = 2 (B'S) e and H = 2(B'S B + alpha) (SolverMPC.cpp:569-570) ----------------
+  // ---------------- A5: g = 2 (B'S) e and H = 2(B'S B + alpha) (SolverMPC.cpp:569-570), indexed in reference order ------
   if (tid < n) {
     const int a = S.vstep[tid], c = S.vcomp[tid];
     float acc = 0.0f;
@@ -465,7 +477,7 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
 #pragma unroll
       for (int s = 0; s < 13; ++s) acc = ffma(sp[s * 12], ep[s], acc);
     }
-    S.g[tid] = (double)(2.0f * acc);
+    S.g[S.o2s[tid]] = (double)(2.0f * acc);
   }
   {
     // matrix cores: 16x16 output tiles over the reduced variables, K runs over (step i ascending, state row s ascending).
@@ -521,7 +533,7 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
     }
     for (int t = tid; t < n; t += NT) {
       args.dbg_i[2 + t] = 12 * S.vstep[t] + S.vcomp[t];
-      o[DL::G + t] = (float)S.g[t];
+      o[DL::G + t] = (float)S.g[S.o2s[t]];
     }
     for (int t = tid; t < n * n; t += NT) {
       const int i = t / n, j = t % n;
@@ -546,248 +558,220 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
   }
 
   // =============================== S: M = H^-1 by symmetric sweeps, matrix in registers ===============================
-  // Thread t owns the TR x TC block (rows i0.., cols j0..) of the full symmetric matrix; the 240 blocks that intersect
-  // the upper triangle are enumerated block-row-major (block row tr holds block columns 2tr..29), so the lanes that
-  // own pieces of one matrix row are contiguous and lanes (2k, 2k+1) always share a block row.
+  // Thread t < NG(NG+1)/2 owns the 6x6 block (e, e'), e <= e', of the symmetric matrix in sweep order (block-row-major).
   // Sweep k:  d = a_kk, p = row k;  a_ij -= (p_i/d) p_j  (i,j != k);  a_kj = p_j/d;  a_kk = -1/d.  After n sweeps a = -H^-1.
   // Row k / column k entries take the same fused update with a substituted multiplier (1 - 1/d for row k, d - 1 for
-  // column k: p_j - (1-1/d) p_j = p_j/d), so the inner 8x4 update has no special cases; only a_kk is patched.
-  // The pivot row for sweep k+1 is published to LDS right after sweep k (double buffered) -> one barrier per sweep.
-  // The inverse never leaves the registers: the whole active-set phase multiplies by it in place (rmatvec below), which
-  // keeps the workgroup's LDS footprint at ~53 KB -> three workgroups (12 waves) per CU hide each other's latencies.
-  constexpr int TR = NMAX / 15, TC = NMAX / 30;
-  static_assert(TR * 15 == NMAX && TC * 30 == NMAX && TR == 2 * TC && TC % 2 == 0, "NMAX must be a multiple of 60");
-  const bool is_v = tid < n;
-  int tr = 0;
-  while (tr < 14 && (tr + 1) * (30 - tr) <= tid) ++tr;
-  const bool owner = tid < 240;
-  const int tc = owner ? 2 * tr + (tid - tr * (31 - tr)) : 0;
-  if (!owner) tr = 0;
-  const int i0 = tr * TR, j0 = tc * TC;
-  const int dgo = tc - 2 * tr;  // 0 or 1: the block straddles the diagonal at row offset dgo*TC; >= 2: strictly above it
-  double a[TR][TC];
+  // column k: p_j - (1-1/d) p_j = p_j/d), so the 6x6 update has no special cases; only a_kk is patched.
+  // The pivot row for sweep k+1 is published to LDS right after sweep k (double buffered) -> one barrier per sweep; the six
+  // sweeps of a leg-step are statically unrolled (static register indices).
+  constexpr int NTILE = NG * (NG + 1) / 2;
+  static_assert(NTILE <= NT && SM::MMAX <= NT && NMAX <= NT, "one thread per block / constraint row / variable");
+  const bool is_v = tid < n, is_c = tid < m;
+  int e0 = 0;
+  while (e0 < NG - 1 && (e0 + 1) * NG - (e0 + 1) * e0 / 2 <= tid) ++e0;
+  const bool owner = tid < NTILE;
+  const int e1 = owner ? e0 + (tid - (e0 * NG - e0 * (e0 - 1) / 2)) : 0;
+  if (!owner) e0 = 0;
+  const bool diag = (e0 == e1);
+  const int i0 = GS * e0, j0 = GS * e1;
+  double a[GS][GS];
 #pragma unroll
-  for (int ii = 0; ii < TR; ++ii)
+  for (int ii = 0; ii < GS; ++ii)
 #pragma unroll
-    for (int jj = 0; jj < TC; ++jj) {
+    for (int jj = 0; jj < GS; ++jj) {
       const int i = i0 + ii, j = j0 + jj;
-      const int lo = i < j ? i : j, hi = i < j ? j : i;
-      a[ii][jj] = (hi < n) ? (double)A.Hs[hs_index<NMAX>(lo, hi)] : 0.0;
+      double v = 0.0;
+      if (i < n && j < n) {
+        const int oi = S.s2o[i], oj = S.s2o[j];
+        v = (double)A.Hs[hs_index<NMAX>(oi < oj ? oi : oj, oi < oj ? oj : oi)];
+      }
+      a[ii][jj] = v;
     }
   __syncthreads();  // every block is loaded before the solver state (which aliases the staging area) is written
   if (tid < NMAX) Q.piv[0][tid] = 0.0, Q.piv[1][tid] = 0.0;
   __syncthreads();
-  if (owner && i0 == 0) {
+  if (owner && e0 == 0) {
 #pragma unroll
-    for (int jj = 0; jj < TC; ++jj)
+    for (int jj = 0; jj < GS; ++jj)
       if (j0 + jj < n) Q.piv[0][j0 + jj] = a[0][jj];
   }
   __syncthreads();
-  {
-    const int nkb = (n + TR - 1) / TR;
-    for (int kb = 0; kb < nkb; ++kb) {
-      const bool rowb = owner && (tr == kb);      // my block holds matrix rows kb*TR .. kb*TR+TR-1
-      const bool rown = owner && (tr == kb + 1);  // ... or the next block row (publishes its row 0 at the seam)
+  for (int kb = 0; kb < ng; ++kb) {
+    const bool rowb = owner && (e0 == kb);      // my block holds matrix rows 6kb..6kb+5
+    const bool colb = owner && (e1 == kb);      // my block holds matrix columns 6kb..6kb+5
+    const bool rown = owner && (e0 == kb + 1);  // next leg-step's row / column blocks (publish at the seam)
+    const bool coln = owner && (e1 == kb + 1);
 #pragma unroll
-      for (int kk = 0; kk < TR; ++kk) {
-        const int k = kb * TR + kk;
-        if (k < n) {  // uniform
-          const double *pv = Q.piv[k & 1];
-          double *pn = Q.piv[(k + 1) & 1];
-          const double d = pv[k];
-          double pi[TR], pj[TC];
+    for (int kk = 0; kk < GS; ++kk) {
+      const int k = kb * GS + kk;
+      const double *pv = Q.piv[k & 1];
+      double *pn = Q.piv[(k + 1) & 1];
+      const double d = pv[k];
+      double pi[GS], pj[GS];
 #pragma unroll
-          for (int ii = 0; ii < TR; ii += 2) {
-            const double2 t2 = *reinterpret_cast<const double2 *>(pv + i0 + ii);
-            pi[ii] = t2.x, pi[ii + 1] = t2.y;
-          }
+      for (int ii = 0; ii < GS; ii += 2) {
+        const double2 t2 = *reinterpret_cast<const double2 *>(pv + i0 + ii);
+        pi[ii] = t2.x, pi[ii + 1] = t2.y;
+      }
 #pragma unroll
-          for (int jj = 0; jj < TC; jj += 2) {
-            const double2 t2 = *reinterpret_cast<const double2 *>(pv + j0 + jj);
-            pj[jj] = t2.x, pj[jj + 1] = t2.y;
-          }
-          double invd = __builtin_amdgcn_rcp(d);  // v_rcp_f64 + two Newton steps (the solver half is not bit-pinned)
-          invd = dfma(dfma(-d, invd, 1.0), invd, invd);
-          invd = dfma(dfma(-d, invd, 1.0), invd, invd);
-          const int kc = kk % TC;                                // static column index inside the block column of k
-          const bool colb = owner && (tc == 2 * kb + kk / TC);  // my block holds matrix column k
-          double qi[TR];
+      for (int jj = 0; jj < GS; jj += 2) {
+        const double2 t2 = *reinterpret_cast<const double2 *>(pv + j0 + jj);
+        pj[jj] = t2.x, pj[jj + 1] = t2.y;
+      }
+      double invd = __builtin_amdgcn_rcp(d);  // v_rcp_f64 + two Newton steps (the solver half is not bit-pinned)
+      invd = dfma(dfma(-d, invd, 1.0), invd, invd);
+      invd = dfma(dfma(-d, invd, 1.0), invd, invd);
+      double qi[GS];
 #pragma unroll
-          for (int ii = 0; ii < TR; ++ii) qi[ii] = pi[ii] * invd;
-          qi[kk] = rowb ? (1.0 - invd) : qi[kk];
-          pj[kc] = colb ? (d - 1.0) : pj[kc];
+      for (int ii = 0; ii < GS; ++ii) qi[ii] = pi[ii] * invd;
+      qi[kk] = rowb ? (1.0 - invd) : qi[kk];
+      pj[kk] = colb ? (d - 1.0) : pj[kk];
 #pragma unroll
-          for (int ii = 0; ii < TR; ++ii)
+      for (int ii = 0; ii < GS; ++ii)
 #pragma unroll
-            for (int jj = 0; jj < TC; ++jj) a[ii][jj] = dfma(-qi[ii], pj[jj], a[ii][jj]);
-          a[kk][kc] = (rowb && colb) ? -invd : a[kk][kc];
-          // publish row k+1 of the symmetric matrix: (k+1, j>=k+1) from the row owners, (i<k+1, k+1) from the column owners
-          const int k1 = k + 1;
-          if (k1 < n) {
-            if (kk + 1 < TR) {
-              if (rowb) {
+        for (int jj = 0; jj < GS; ++jj) a[ii][jj] = dfma(-qi[ii], pj[jj], a[ii][jj]);
+      a[kk][kk] = (rowb && colb) ? -invd : a[kk][kk];
+      // publish row k+1 of the symmetric matrix: (k+1, j >= k+1) from its row blocks, (i < k+1, k+1) from its column blocks
+      if (kk + 1 < GS) {
+        if (rowb) {
 #pragma unroll
-                for (int jj = 0; jj < TC; ++jj)
-                  if (j0 + jj >= k1) pn[j0 + jj] = a[(kk + 1) % TR][jj];
-              }
-            } else {
-              if (rown) {
+          for (int jj = 0; jj < GS; ++jj)
+            if (!diag || jj >= kk + 1) pn[j0 + jj] = a[(kk + 1) % GS][jj];
+        }
+        if (colb) {
 #pragma unroll
-                for (int jj = 0; jj < TC; ++jj)
-                  if (j0 + jj >= k1) pn[j0 + jj] = a[0][jj];
-              }
-            }
-            const int kc1 = (kk + 1) % TC;
-            if (owner && tc == (kb * TR + kk + 1) / TC) {
+          for (int ii = 0; ii < GS; ++ii)
+            if (!diag || ii < kk + 1) pn[i0 + ii] = a[ii][(kk + 1) % GS];
+        }
+      } else if (kb + 1 < ng) {
+        if (rown) {
 #pragma unroll
-              for (int ii = 0; ii < TR; ++ii)
-                if (i0 + ii < k1) pn[i0 + ii] = a[ii][kc1];
-            }
-          }
-          __syncthreads();
+          for (int jj = 0; jj < GS; ++jj) pn[j0 + jj] = a[0][jj];
+        }
+        if (coln && !diag) {
+#pragma unroll
+          for (int ii = 0; ii < GS; ++ii) pn[i0 + ii] = a[ii][0];
         }
       }
+      __syncthreads();
     }
   }
   // M = -a.  Lower-triangle duplicates inside diagonal blocks are zeroed and the diagonal is kept aside, so the in-place
-  // mat-vec needs no masks: rows use the block as is, the mirrored (column) part subtracts the diagonal term once.
-  double dg[TC];
+  // products need no masks: rows use the block as is, the mirrored (column) part subtracts the diagonal term once.
+  double dg[GS];
 #pragma unroll
-  for (int jj = 0; jj < TC; ++jj) dg[jj] = 0.0;
+  for (int jj = 0; jj < GS; ++jj) dg[jj] = 0.0;
 #pragma unroll
-  for (int ii = 0; ii < TR; ++ii)
+  for (int ii = 0; ii < GS; ++ii)
 #pragma unroll
-    for (int jj = 0; jj < TC; ++jj) {
-      const int df = ii - jj - dgo * TC;  // i - j for this element (only meaningful when dgo < 2)
-      const bool low = owner ? (dgo < 2 && df > 0) : true;
+    for (int jj = 0; jj < GS; ++jj) {
+      const bool low = !owner || (diag && ii > jj);
       a[ii][jj] = low ? 0.0 : -a[ii][jj];
-      if (dgo < 2 && df == 0) dg[jj] = a[ii][jj];
+      if (ii == jj) dg[jj] = diag ? a[ii][jj] : 0.0;
     }
   PROF_MARK(P_SWEEP);
 
-  // ---- z = M w out of the register blocks.  Each thread forms the 8 row partials and 4 mirrored column partials of its
-  // block; lane pairs pre-add their row partials (DPP); partials are staged in LDS and row i sums its <= 15 + 15 pieces in
-  // a fixed order (deterministic).  Two barriers.  wi/wj are the vector entries at the block's rows / columns.
-  auto rmv_block = [&](const double (&wi)[TR], const double (&wj)[TC]) {
-    double ra[TR], ca[TC];
+  // ---- products with the register blocks --------------------------------------------------------------------------
+  auto blk_rows = [&](const double (&wj)[GS], double (&ra)[GS]) {  // ra = a * wj        (result on leg-step e0)
 #pragma unroll
-    for (int ii = 0; ii < TR; ++ii) {
-      double s0 = 0.0;
+    for (int ii = 0; ii < GS; ++ii) {
+      double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-      for (int jj = 0; jj < TC; ++jj) s0 = dfma(a[ii][jj], wj[jj], s0);
-      ra[ii] = s0;
+      for (int jj = 0; jj < GS; jj += 2) {
+        s0 = dfma(a[ii][jj], wj[jj], s0);
+        s1 = dfma(a[ii][jj + 1], wj[jj + 1], s1);
+      }
+      ra[ii] = s0 + s1;
     }
+  };
+  auto blk_cols = [&](const double (&wi)[GS], double (&ca)[GS]) {  // ca = a' * wi       (result on leg-step e1)
 #pragma unroll
-    for (int jj = 0; jj < TC; ++jj) {
-      double s0 = -dg[jj] * wj[jj], s1 = 0.0;
+    for (int jj = 0; jj < GS; ++jj) {
+      double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-      for (int ii = 0; ii < TR; ii += 2) {
+      for (int ii = 0; ii < GS; ii += 2) {
         s0 = dfma(a[ii][jj], wi[ii], s0);
         s1 = dfma(a[ii + 1][jj], wi[ii + 1], s1);
       }
       ca[jj] = s0 + s1;
     }
+  };
+  // symmetric diagonal block times a 6-vector (upper triangle stored, lower zeroed, diagonal in dg)
+  auto blk_sym = [&](const double (&w)[GS], double (&out)[GS]) {
+    double ra[GS], ca[GS];
+    blk_rows(w, ra);
+    blk_cols(w, ca);
 #pragma unroll
-    for (int ii = 0; ii < TR; ++ii) ra[ii] += dpp_xor1(ra[ii]);
-    if (owner) {
-      if ((tid & 1) == 0) {
+    for (int k = 0; k < GS; ++k) out[k] = (ra[k] + ca[k]) - dg[k] * w[k];
+  };
+  // z = M w for a dense w in LDS (entries >= n exactly 0).  Every block writes its row partial to ST[e1][vars of e0]
+  // and its mirrored partial to ST[e0][vars of e1]; variable i then sums ST[0..ng-1][i] in index order (deterministic).
+  auto rmatvec = [&](const double *w) {
+    if (owner && e1 < ng) {
+      double wi[GS], wj[GS], ra[GS], ca[GS];
 #pragma unroll
-        for (int ii = 0; ii < TR; ii += 2) *reinterpret_cast<double2 *>(&Q.RS[tid >> 1][ii]) = make_double2(ra[ii], ra[ii + 1]);
+      for (int k = 0; k < GS; k += 2) {
+        const double2 t2 = *reinterpret_cast<const double2 *>(w + i0 + k);
+        const double2 u2 = *reinterpret_cast<const double2 *>(w + j0 + k);
+        wi[k] = t2.x, wi[k + 1] = t2.y, wj[k] = u2.x, wj[k + 1] = u2.y;
       }
+      if (diag) {
+        blk_sym(wj, ra);
 #pragma unroll
-      for (int jj = 0; jj < TC; jj += 2) *reinterpret_cast<double2 *>(&Q.CS[tid][jj]) = make_double2(ca[jj], ca[jj + 1]);
+        for (int k = 0; k < GS; k += 2) *reinterpret_cast<double2 *>(&Q.ST[e0][i0 + k]) = make_double2(ra[k], ra[k + 1]);
+      } else {
+        blk_rows(wj, ra);
+        blk_cols(wi, ca);
+#pragma unroll
+        for (int k = 0; k < GS; k += 2) {
+          *reinterpret_cast<double2 *>(&Q.ST[e1][i0 + k]) = make_double2(ra[k], ra[k + 1]);
+          *reinterpret_cast<double2 *>(&Q.ST[e0][j0 + k]) = make_double2(ca[k], ca[k + 1]);
+        }
+      }
     }
     __syncthreads();
     if (is_v) {
-      // all loads are issued up front (clamped addresses + selects, no data-dependent trip counts): one LDS round trip
-      const int btr = tid / TR, bi = tid % TR, btc = tid / TC, bj = tid % TC;
-      const int p0 = (btr * (31 - btr)) >> 1, np_ = 15 - btr, nt = (btc >> 1) + 1;
-      double rv[15], cv[15];
+      double sv[NG];
 #pragma unroll
-      for (int k = 0; k < 15; ++k) {
-        const int kc = (k < np_) ? k : 0;
-        rv[k] = Q.RS[p0 + kc][bi];
-        const int kt = (k < nt) ? k : 0;
-        cv[k] = Q.CS[kt * (31 - kt) + (btc - 2 * kt)][bj];
-      }
+      for (int s = 0; s < NG; ++s) sv[s] = Q.ST[(s < ng) ? s : 0][tid];
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-      for (int k = 0; k < 15; ++k) {
-        s0 += (k < np_) ? rv[k] : 0.0;
-        s1 += (k < nt) ? cv[k] : 0.0;
+      for (int s = 0; s < NG; s += 2) {
+        s0 += (s < ng) ? sv[s] : 0.0;
+        s1 += (s + 1 < ng) ? sv[s + 1] : 0.0;
       }
       Q.z[tid] = s0 + s1;
     }
     __syncthreads();
   };
-  auto rmatvec_dense = [&](const double *w) {
-    double wi[TR], wj[TC];
-#pragma unroll
-    for (int ii = 0; ii < TR; ii += 2) {
-      const double2 t2 = *reinterpret_cast<const double2 *>(w + i0 + ii);
-      wi[ii] = t2.x, wi[ii + 1] = t2.y;
-    }
-#pragma unroll
-    for (int jj = 0; jj < TC; jj += 2) {
-      const double2 t2 = *reinterpret_cast<const double2 *>(w + j0 + jj);
-      wj[jj] = t2.x, wj[jj + 1] = t2.y;
-    }
-    rmv_block(wi, wj);
-  };
-  // vector with six non-zeros npv[0..2] at vF.., npv[3..5] at vM..: built in registers, no LDS round trip
-  auto rmatvec_sparse6 = [&](const double (&npv)[6], int vF, int vM) {
-    double wi[TR], wj[TC];
-#pragma unroll
-    for (int ii = 0; ii < TR; ++ii) {
-      const int dF = i0 + ii - vF, dM = i0 + ii - vM;
-      double v = 0.0;
-      v = (dF == 0) ? npv[0] : v, v = (dF == 1) ? npv[1] : v, v = (dF == 2) ? npv[2] : v;
-      v = (dM == 0) ? npv[3] : v, v = (dM == 1) ? npv[4] : v, v = (dM == 2) ? npv[5] : v;
-      wi[ii] = v;
-    }
-#pragma unroll
-    for (int jj = 0; jj < TC; ++jj) {
-      const int dF = j0 + jj - vF, dM = j0 + jj - vM;
-      double v = 0.0;
-      v = (dF == 0) ? npv[0] : v, v = (dF == 1) ? npv[1] : v, v = (dF == 2) ? npv[2] : v;
-      v = (dM == 0) ? npv[3] : v, v = (dM == 1) ? npv[4] : v, v = (dM == 2) ? npv[5] : v;
-      wj[jj] = v;
-    }
-    rmv_block(wi, wj);
-  };
 
-  // =============================== Q: dual active set (Goldfarb-Idnani, range-space form) ===============================
-  // Fixed thread roles: thread c < m = constraint row c (leg-step c>>3, row c&7) with its 6 coefficients, variable
-  // offsets and bounds in registers; thread i < n = variable i.
+  // =============================== solver state ===============================
+  // Fixed thread roles: thread c < m = constraint row c (leg-step c>>3, row c&7) with its 6 coefficients and bounds in
+  // registers; thread i < n = variable i (leg-step i/6, position i%6).
   const double INF = __builtin_huge_val();
   const double FEAS_TOL = 1e-9;
-  const bool is_c = tid < m;
-  int c_vF = 0, c_vM = 0;
+  const int c_e = tid >> 3, c_rr = tid & 7;
   double c_cn[6] = {0, 0, 0, 0, 0, 0}, c_ub = INF, c_scale = 1.0;
   bool c_hasl = false, c_hasu = false;
   if (is_c) {
-    const int e = tid >> 3, rr = tid & 7, leg = S.ls_leg[e];
-    c_vF = S.ls_vF[e], c_vM = S.ls_vM[e];
+    const int leg = S.ls_leg[c_e];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) c_cn[k] = S.Cn[leg][rr][k];
-    c_hasl = (rr <= 4) || (rr == 7);  // every finite lower bound is 0 (SolverMPC.cpp:466-482)
-    c_hasu = (rr >= 4);
-    c_ub = (rr == 4) ? (double)0.01f : (rr == 7 ? S.ub7[e] : 0.0);
-    c_scale = (rr == 7 && c_ub > 1.0) ? 1.0 / c_ub : 1.0;  // the Fz cap is O(f_max): compare it on a unit scale
+    for (int k = 0; k < 6; ++k) c_cn[k] = S.Cn[leg][c_rr][k];
+    c_hasl = (c_rr <= 4) || (c_rr == 7);  // every finite lower bound is 0 (SolverMPC.cpp:466-482)
+    c_hasu = (c_rr >= 4);
+    c_ub = (c_rr == 4) ? (double)0.01f : (c_rr == 7 ? S.ub7[c_e] : 0.0);
+    c_scale = (c_rr == 7 && c_ub > 1.0) ? 1.0 / c_ub : 1.0;  // the Fz cap is O(f_max): compare it on a unit scale
   }
-  int v_e = 0, v_k = 0, v_leg = 0;
-  if (is_v) {
-    v_e = S.vls[tid], v_k = S.vk[tid];
-    v_leg = S.ls_leg[v_e];
-  }
-  for (int t = tid; t < m; t += NT) {
+  const int v_e = tid / GS, v_k = tid % GS;
+  const int v_leg = is_v ? S.ls_leg[v_e] : 0;
+  for (int t = tid; t < SM::MMAX; t += NT) {
     Q.act[t] = 0;
     Q.slot[t] = 0;
   }
-  if (tid < NMAX) Q.r[tid] = 0.0;
+  if (tid < NMAX) Q.r[tid] = 0.0, Q.u[tid] = 0.0;
   if (tid < NMAX) Q.w[tid] = is_v ? -S.g[tid] : 0.0;  // entries >= n stay exactly 0
   __syncthreads();
-  rmatvec_dense(Q.w);  // unconstrained minimiser x_u = -M g
+  rmatvec(Q.w);  // unconstrained minimiser x_u = -M g
   if (is_v) {
     const double xv = Q.z[tid];
     Q.xu[tid] = xv;
@@ -802,10 +786,11 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
   // slack of this thread's constraint row on its tighter side at xv (unit-scaled); side = +1 lower, -1 upper
   auto my_slack = [&](const double *xv, int &side, double &raw) -> double {
     double s0 = 0.0, s1 = 0.0;
+    const double *xp = xv + GS * c_e;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) s0 = dfma(c_cn[k], xv[c_vF + k], s0);
+    for (int k = 0; k < 3; ++k) s0 = dfma(c_cn[k], xp[k], s0);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) s1 = dfma(c_cn[3 + k], xv[c_vM + k], s1);
+    for (int k = 0; k < 3; ++k) s1 = dfma(c_cn[3 + k], xp[3 + k], s1);
     const double s = s0 + s1;
     const double sl = c_hasl ? s : INF;
     const double su = c_hasu ? (c_ub - s) : INF;
@@ -833,7 +818,210 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
       Q.w[tid] = acc0 + acc1;
     }
   };
+  // rout[j] (+)= sum_i E(j,i) din[i] for j < q: 4 lanes per row, quad reduction; optional dual ratio test on the result
+  auto e_times = [&](const double *din, double *rout, bool accumulate, double &t1c, int &t1j, bool ratio) {
+    for (int jb = 0; jb < q; jb += NT / 4) {
+      const int j = jb + (tid >> 2), part = tid & 3;
+      double acc = 0.0;
+      if (j < q) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int i = part; i < q; i += 16) {
+          const int i1 = (i + 4 < q) ? i + 4 : i, i2 = (i + 8 < q) ? i + 8 : i, i3 = (i + 12 < q) ? i + 12 : i;
+          const double x0 = Eref(S, j, i), x1 = Eref(S, j, i1), x2 = Eref(S, j, i2), x3 = Eref(S, j, i3);
+          const double d0 = din[i], d1 = din[i1], d2 = din[i2], d3 = din[i3];
+          a0 = dfma(x0, d0, a0);
+          a1 = (i + 4 < q) ? dfma(x1, d1, a1) : a1;
+          a2 = (i + 8 < q) ? dfma(x2, d2, a2) : a2;
+          a3 = (i + 12 < q) ? dfma(x3, d3, a3) : a3;
+        }
+        acc = (a0 + a1) + (a2 + a3);
+      }
+      acc += dpp_xor1(acc);
+      acc += dpp_xor2(acc);
+      if (j < q && part == 0) {
+        if (accumulate) rout[j] += acc;
+        else rout[j] = acc;
+        if (ratio && acc > 1e-14) {
+          const double tj = Q.u[j] / acc;
+          if (tj < t1c) t1c = tj, t1j = j;
+        }
+      }
+    }
+  };
+  // Schur-complement downdate of E when slot l leaves (row/column l are read-only during the pass), then the last slot
+  // moves into l.  Two barriers inside.
+  auto drop_slot = [&](int l) {
+    const double iel = 1.0 / Eref(S, l, l);
+    const int ti = tid >> 4, tj = tid & 15;
+    for (int ib = 0; ib < q; ib += NT / 16) {
+      const int i = ib + ti;
+      if (i < q && i != l) {
+        const double ci = Eref(S, i, l) * iel;
+        for (int j = tj; j <= i; j += 16) {
+          if (j != l) {
+            double &ee = Q.Ep[i * (i + 1) / 2 + j];
+            ee = dfma(-ci, Eref(S, j, l), ee);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int last = q - 1;
+    if (l != last) {
+      if (tid < last && tid != l) Eref(S, l, tid) = Eref(S, last, tid);
+      if (tid == l) Eref(S, l, l) = Eref(S, last, last);
+    }
+    if (tid == 0) {
+      const int cl = Q.Wrow[l];
+      Q.act[cl] = 0;
+      if (l != last) {
+        const int cm = Q.Wrow[last];
+        Q.Wrow[l] = (unsigned char)cm;
+        Q.slot[cm] = (unsigned char)l;
+        Q.u[l] = Q.u[last];
+      }
+    }
+    --q;
+    __syncthreads();
+  };
+  // d[slot] = b_j - n_j' x for the active rows (n_j = sign*a_j, b_j = sign*bound)
+  auto active_residual = [&](const double *xv) {
+    if (is_c) {
+      const int ac = Q.act[tid];
+      if (ac != 0) {
+        double s = 0.0;
+        const double *xp = xv + GS * c_e;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s = dfma(c_cn[k], xp[k], s);
+        const double bnd = (ac > 0) ? 0.0 : c_ub;
+        Q.d[Q.slot[tid]] = (double)ac * (bnd - s);
+      }
+    }
+  };
 
+  // =============================== W: block warm start ===============================
+  if (args.warm) {
+    // (a) rows 4-6 (foot-x moment window, toe and heel line contact) violated at x_u take consecutive slots.  The three
+    //     rows of a leg-step are linearly independent, rows of different leg-steps touch disjoint variables, so the
+    //     Schur matrix of any such set is positive definite.
+    double raw = INF;
+    int side = 1;
+    bool take = false;
+    if (is_c && c_rr >= 4 && c_rr <= 6) take = my_slack(Q.xu, side, raw) < -FEAS_TOL;
+    const unsigned long long bal = __ballot(take);
+    const int below = __popcll(bal & ((1ull << ln) - 1ull));
+    if (ln == 0) Q.wcount[wv] = __popcll(bal);
+    __syncthreads();
+    int base = 0, k0 = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int cw = Q.wcount[w];
+      base += (w < wv) ? cw : 0;
+      k0 += cw;
+    }
+    k0 = uni(k0);
+    if (k0 > SM::QMAX) k0 = SM::QMAX;
+    if (take && base + below < k0) {
+      const int sl = base + below;
+      Q.act[tid] = (signed char)side;
+      Q.slot[tid] = (unsigned char)sl;
+      Q.Wrow[sl] = (unsigned char)tid;
+    }
+    __syncthreads();
+    if (k0 > 0) {
+      // (b) S0(i,j) = n_i' M n_j: rows of leg-steps (e0, e1) meet only in my block
+      if (owner && e1 < ng) {
+        const unsigned long long am0 = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * e0]);
+        const unsigned long long am1 = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * e1]);
+        if (am0 != 0ull && am1 != 0ull) {
+          const int leg0 = S.ls_leg[e0], leg1 = S.ls_leg[e1];
+          for (int r1 = 4; r1 <= 6; ++r1) {
+            const int ac1 = (int)(signed char)((am1 >> (8 * r1)) & 0xff);
+            if (ac1 == 0) continue;
+            double cn1[GS], t6[GS];
+#pragma unroll
+            for (int k = 0; k < GS; ++k) cn1[k] = (double)ac1 * S.Cn[leg1][r1][k];
+            if (diag) blk_sym(cn1, t6);
+            else blk_rows(cn1, t6);
+            const int s1 = Q.slot[8 * e1 + r1];
+            for (int r0 = 4; r0 <= (diag ? r1 : 6); ++r0) {
+              const int ac0 = (int)(signed char)((am0 >> (8 * r0)) & 0xff);
+              if (ac0 == 0) continue;
+              double v = 0.0;
+#pragma unroll
+              for (int k = 0; k < GS; ++k) v = dfma((double)ac0 * S.Cn[leg0][r0][k], t6[k], v);
+              Eref(S, Q.slot[8 * e0 + r0], s1) = v;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // (c) in-place inversion of the k0 x k0 Schur matrix by symmetric sweeps in LDS (two barriers per pivot)
+      for (int s = 0; s < k0; ++s) {
+        if (tid < k0) Q.col[tid] = Eref(S, tid, s);
+        __syncthreads();
+        const double idv = 1.0 / Q.col[s];
+        const int ti = tid >> 4, tj = tid & 15;
+        for (int ib = 0; ib < k0; ib += NT / 16) {
+          const int i = ib + ti;
+          if (i < k0) {
+            const double ci = Q.col[i] * idv;
+            for (int j = tj; j <= i; j += 16) {
+              double &ee = Q.Ep[i * (i + 1) / 2 + j];
+              const double cj = Q.col[j];
+              ee = (i == s) ? ((j == s) ? -idv : cj * idv) : ((j == s) ? ci : dfma(-ci, cj, ee));
+            }
+          }
+        }
+        __syncthreads();
+      }
+      for (int t = tid; t < k0 * (k0 + 1) / 2; t += NT) Q.Ep[t] = -Q.Ep[t];  // sweeps leave -S0^-1
+      q = k0;
+      // (d) multipliers u = E (b - N x_u); rows with a negative multiplier do not belong to the working set: remove the
+      //     most negative one, update E by the Schur complement, repeat
+      active_residual(Q.xu);
+      __syncthreads();
+      while (true) {
+        double dmy = INF;
+        int dj = 0;
+        e_times(Q.d, Q.u, false, dmy, dj, false);
+        __syncthreads();
+        double um = (tid < q) ? Q.u[tid] : INF;
+        const double wmin = wave_min(um);
+        const unsigned long long b2 = __ballot(um == wmin);
+        const int wl = (int)__ffsll((long long)b2) - 1;
+        if (ln == wl) Q.redv[wv] = um, Q.redi[wv] = tid;
+        __syncthreads();
+        int l = Q.redi[0];
+        double umin = Q.redv[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+          const double ov = Q.redv[w];
+          if (ov < umin) umin = ov, l = Q.redi[w];
+        }
+        l = uni(l);
+        if (ub(!(umin < -1e-12))) break;
+        ++iters;
+        // remove slot l: the residual vector follows the slot renumbering
+        const int last = q - 1;
+        __syncthreads();
+        if (tid == 0 && l != last) Q.d[l] = Q.d[last];
+        drop_slot(l);
+        if (q == 0) break;
+      }
+      // (e) x = x_u + M N' u
+      if (q > 0) {
+        gather_w(Q.u, 1.0, 0.0);
+        __syncthreads();
+        rmatvec(Q.w);
+        if (is_v) Q.x[tid] = Q.xu[tid] + Q.z[tid];
+        __syncthreads();
+      }
+    }
+  }
+  PROF_MARK(P_BLOCK);
+
+  // =============================== Q: dual active set (Goldfarb-Idnani, range-space form) ===============================
   for (int pass = 0; pass < 3 && code == S_OK; ++pass) {
     // ---- main loop ----
     while (true) {
@@ -851,8 +1039,6 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
           rc.raw = raw;
           rc.idx = tid;
           rc.side = side;
-          rc.vF = c_vF;
-          rc.vM = c_vM;
 #pragma unroll
           for (int k = 0; k < 6; ++k) rc.cn[k] = c_cn[k];
         }
@@ -872,7 +1058,7 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
         break;
       }
       wsel = uni(wsel);
-      const int p = uni(Q.rec[wsel].idx), sgi = uni(Q.rec[wsel].side), vFp = uni(Q.rec[wsel].vF), vMp = uni(Q.rec[wsel].vM);
+      const int p = uni(Q.rec[wsel].idx), sgi = uni(Q.rec[wsel].side);
       const int ep = p >> 3;
       double sp = Q.rec[wsel].raw;
       const double sg = (double)sgi;
@@ -887,53 +1073,44 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
           code = S_MAXITER;
           break;
         }
-        // (2) y = M n+ in place (n+ has six non-zeros), then every constraint thread forms a_c' y; active rows scatter
-        //     d[slot] = sign * a_c' y; row p gives gamma = n+' M n+
-        rmatvec_sparse6(np, vFp, vMp);
-        if (is_c) {
-          double d0 = 0.0, d1 = 0.0;
+        // (2) d_j = n_j' M n+ for the active rows: the rows of leg-step eo meet n+ (on leg-step ep) only in block
+        //     (min(eo,ep), max(eo,ep)), whose owner forms t = M(eo,ep) n+ once and dots it with each active row;
+        //     the diagonal block also gives gamma = n+' M n+
+        if (owner && e1 < ng && (e0 == ep || e1 == ep)) {
+          double t6[GS];
+          if (diag) blk_sym(np, t6);
+          else if (e1 == ep) blk_rows(np, t6);
+          else blk_cols(np, t6);
+          const int eo = (e0 == ep) ? e1 : e0;
+          const int lego = S.ls_leg[eo];
+          const unsigned long long am = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * eo]);
+          const unsigned long long sm = *reinterpret_cast<const unsigned long long *>(&Q.slot[8 * eo]);
+          if (am != 0ull) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) d0 = dfma(c_cn[k], Q.z[c_vF + k], d0);
+            for (int rr = 0; rr < 8; ++rr) {
+              const int ac = (int)(signed char)((am >> (8 * rr)) & 0xff);
+              if (ac != 0) {
+                double v = 0.0;
 #pragma unroll
-          for (int k = 0; k < 3; ++k) d1 = dfma(c_cn[3 + k], Q.z[c_vM + k], d1);
-          const double dc = d0 + d1;
-          const int ac = Q.act[tid];
-          if (ac != 0) Q.d[Q.slot[tid]] = (double)ac * dc;
-          if (tid == p) Q.gamma = sg * dc;
-        }
-        __syncthreads();
-        PROF_MARK(P_D);
-        // (3) r = E d : 4 lanes per row, quad reduction; the lane that owns r_j also bids for the dual step length
-        //     t1 = min_j u_j / r_j over r_j > 0 (largest step keeping u >= 0)
-        {
-          double t1c = INF;
-          int t1j = 0;
-          for (int jb = 0; jb < q; jb += NT / 4) {
-            const int j = jb + (tid >> 2), part = tid & 3;
-            double acc = 0.0;
-            if (j < q) {
-              double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-              for (int i = part; i < q; i += 16) {
-                const int i1 = (i + 4 < q) ? i + 4 : i, i2 = (i + 8 < q) ? i + 8 : i, i3 = (i + 12 < q) ? i + 12 : i;
-                const double e0 = Eref(S, j, i), e1 = Eref(S, j, i1), e2 = Eref(S, j, i2), e3 = Eref(S, j, i3);
-                const double d0 = Q.d[i], d1 = Q.d[i1], d2 = Q.d[i2], d3 = Q.d[i3];
-                a0 = dfma(e0, d0, a0);
-                a1 = (i + 4 < q) ? dfma(e1, d1, a1) : a1;
-                a2 = (i + 8 < q) ? dfma(e2, d2, a2) : a2;
-                a3 = (i + 12 < q) ? dfma(e3, d3, a3) : a3;
-              }
-              acc = (a0 + a1) + (a2 + a3);
-            }
-            acc += dpp_xor1(acc);
-            acc += dpp_xor2(acc);
-            if (j < q && part == 0) {
-              Q.r[j] = acc;
-              if (acc > 1e-14) {
-                const double tj = Q.u[j] / acc;
-                if (tj < t1c) t1c = tj, t1j = j;
+                for (int k = 0; k < GS; ++k) v = dfma(S.Cn[lego][rr][k], t6[k], v);
+                Q.d[(int)((sm >> (8 * rr)) & 0xff)] = (double)ac * v;
               }
             }
           }
+          if (diag) {
+            double gm = 0.0;
+#pragma unroll
+            for (int k = 0; k < GS; ++k) gm = dfma(np[k], t6[k], gm);
+            Q.gamma = gm;
+          }
+        }
+        __syncthreads();
+        PROF_MARK(P_D);
+        // (3) r = E d; the lane that owns r_j also bids for the dual step length t1 = min_j u_j / r_j over r_j > 0
+        {
+          double t1c = INF;
+          int t1j = 0;
+          e_times(Q.d, Q.r, false, t1c, t1j, true);
           const double wmin = wave_min(t1c);
           const unsigned long long bal = __ballot(t1c == wmin);
           const int wl = (int)__ffsll((long long)bal) - 1;
@@ -949,14 +1126,12 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
         __syncthreads();
         PROF_MARK(P_W);
         // (5) z = M w
-        rmatvec_dense(Q.w);
+        rmatvec(Q.w);
         PROF_MARK(P_MV);
         // (6) step lengths and the step
         double delta = 0.0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) delta = dfma(np[k], Q.z[vFp + k], delta);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) delta = dfma(np[3 + k], Q.z[vMp + k], delta);
+        for (int k = 0; k < 6; ++k) delta = dfma(np[k], Q.z[GS * ep + k], delta);
         const double gamma = Q.gamma;
         int l = Q.redi[0];
         double t1 = Q.redv[0];
@@ -983,10 +1158,10 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
           break;
         }
         if (fullstep) {
-          // full step: constraint p joins the working set; bordered update of E (16 x 16 thread tiles of the lower triangle)
+          // full step: constraint p joins the working set; bordered update of E (16-wide thread tiles of the lower triangle)
           const double idl = 1.0 / delta;
           const int ti = tid >> 4, tj = tid & 15;
-          for (int ib = 0; ib < q; ib += 16) {
+          for (int ib = 0; ib < q; ib += NT / 16) {
             const int i = ib + ti;
             if (i < q) {
               const double ri = Q.r[i] * idl;
@@ -1008,40 +1183,7 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
           added = true;
           __syncthreads();
         } else {
-          // partial (or pure dual) step: slot l leaves; Schur-complement downdate of E (row/column l are read-only
-          // during the pass, so no staging copy is needed), then the last slot moves into l
-          const double iel = 1.0 / Eref(S, l, l);
-          const int ti = tid >> 4, tj = tid & 15;
-          for (int ib = 0; ib < q; ib += 16) {
-            const int i = ib + ti;
-            if (i < q && i != l) {
-              const double ci = Eref(S, i, l) * iel;
-              for (int j = tj; j <= i; j += 16) {
-                if (j != l) {
-                  double &ee = Q.Ep[i * (i + 1) / 2 + j];
-                  ee = dfma(-ci, Eref(S, j, l), ee);
-                }
-              }
-            }
-          }
-          __syncthreads();
-          const int last = q - 1;
-          if (l != last) {
-            if (tid < last && tid != l) Eref(S, l, tid) = Eref(S, last, tid);
-            if (tid == l) Eref(S, l, l) = Eref(S, last, last);
-          }
-          if (tid == 0) {
-            const int cl = Q.Wrow[l];
-            Q.act[cl] = 0;
-            if (l != last) {
-              const int cm = Q.Wrow[last];
-              Q.Wrow[l] = (unsigned char)cm;
-              Q.slot[cm] = (unsigned char)l;
-              Q.u[l] = Q.u[last];
-            }
-          }
-          --q;
-          __syncthreads();
+          drop_slot(l);  // partial (or pure dual) step: slot l leaves
         }
         PROF_MARK(P_UPD);
       }
@@ -1053,41 +1195,15 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
     for (int it = 0; it < 3; ++it) {
       gather_w(Q.u, 1.0, 0.0);
       __syncthreads();
-      rmatvec_dense(Q.w);
+      rmatvec(Q.w);
       if (is_v) Q.x[tid] = Q.xu[tid] + Q.z[tid];
       __syncthreads();
       if (it == 2) break;
-      if (is_c) {
-        const int ac = Q.act[tid];
-        if (ac != 0) {
-          double s = 0.0;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) s = dfma(c_cn[k], Q.x[c_vF + k], s);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) s = dfma(c_cn[3 + k], Q.x[c_vM + k], s);
-          const double bnd = (ac > 0) ? 0.0 : c_ub;
-          Q.d[Q.slot[tid]] = (double)ac * (bnd - s);  // b_j - n_j' x with n_j = sign*a_j, b_j = sign*bound
-        }
-      }
+      active_residual(Q.x);
       __syncthreads();
-      for (int jb = 0; jb < q; jb += NT / 4) {
-        const int j = jb + (tid >> 2), part = tid & 3;
-        double acc = 0.0;
-        if (j < q) {
-          double a0 = 0.0, a1 = 0.0;
-          for (int i = part; i < q; i += 8) {
-            const int i1 = (i + 4 < q) ? i + 4 : i;
-            const double e0 = Eref(S, j, i), e1 = Eref(S, j, i1);
-            const double d0 = Q.d[i], d1 = Q.d[i1];
-            a0 = dfma(e0, d0, a0);
-            a1 = (i + 4 < q) ? dfma(e1, d1, a1) : a1;
-          }
-          acc = a0 + a1;
-        }
-        acc += dpp_xor1(acc);
-        acc += dpp_xor2(acc);
-        if (j < q && part == 0) Q.u[j] += acc;
-      }
+      double dmy = INF;
+      int dj = 0;
+      e_times(Q.d, Q.u, true, dmy, dj, false);
       __syncthreads();
     }
     // a refinement that moved x across another constraint sends us back into the main loop (rare)
@@ -1103,16 +1219,15 @@ __global__ __launch_bounds__(NT, (NMAX >= 120 ? 2 : 3)) void hmpc_kernel(KernelA
     double umin = (tid < q) ? Q.u[tid] : INF;
     val = wave_min(val);
     umin = wave_min(umin);
-    if (ln == 0) Q.redv[wv] = val, Q.rec[wv].raw = umin;
+    if (ln == 0) Q.redv[wv] = val, Q.redw[wv] = umin;
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       val = (Q.redv[w] < val) ? Q.redv[w] : val;
-      umin = (Q.rec[w].raw < umin) ? Q.rec[w].raw : umin;
+      umin = (Q.redw[w] < umin) ? Q.redw[w] : umin;
     }
     if (code == S_OK && (val < -1e-6 || umin < -1e-6)) code = S_KKT;
   }
-
 
   // ---------------- output: scatter to the reference's 12h layout, eliminated variables exactly 0 (SolverMPC.cpp:720-732)
   for (int t = tid; t < 12 * h; t += NT) {

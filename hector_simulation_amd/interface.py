@@ -97,6 +97,9 @@ class BatchedMPC:
         _check(self.L.hmpc_set_device_outputs(self.h, C.c_void_p(forces_ptr), C.c_void_p(status_ptr)),
                "hmpc_set_device_outputs")
 
+    def set_warm_start(self, on: bool) -> None:
+        _check(self.L.hmpc_set_warm_start(self.h, 1 if on else 0), "hmpc_set_warm_start")
+
     def solve(self, stream: int = 0) -> None:
         _check(self.L.hmpc_solve(self.h, C.c_void_p(stream)), "hmpc_solve")
 

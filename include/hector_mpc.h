@@ -119,6 +119,10 @@ int hmpc_download(hmpc_handle *h, float *forces, uint32_t *status);
 /* hint for device-resident records: the widest reduced QP (6 x stance leg-steps) in the batch, or -1 = unknown;
  * picks the kernel variant (LDS footprint).  hmpc_upload_records derives it from the gait tables itself. */
 int hmpc_set_max_reduced_vars(hmpc_handle *h, int n_reduced);
+/* Working-set start of the active-set solver.  on = 1 (default): every moment / line-contact row violated at the
+ * unconstrained minimiser enters at once (block warm start); on = 0: cold start from the empty set, one row per
+ * iteration, as the reference's qpOASES call does.  Same optimum either way (strictly convex QP). */
+int hmpc_set_warm_start(hmpc_handle *h, int on);
 int hmpc_get_device_outputs(hmpc_handle *h, float **device_forces, uint32_t **device_status);
 int hmpc_batch(const hmpc_handle *h);
 int hmpc_horizon(const hmpc_handle *h);

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from hector_simulation_amd import _lib, build, interface, records, synthetic  # noqa: E402
 
-PH = ["asm", "H+g", "sweep", "xu", "select", "d", "E*d", "w", "matvec", "t1", "update", "polish", "final", "TOTAL", "sw:rd", "sw:fma", "sw:pub", "sw:bar"]
+PH = ["asm", "H+g", "sweep", "xu", "select", "d", "E*d", "w", "matvec", "t1", "update", "polish", "final", "TOTAL", "block"]
 
 
 def main():
@@ -36,7 +36,7 @@ def main():
     mean = cyc.mean(axis=0)
     print(f"gait={gait} h={h} batch={nb} iters median {np.median(it)} mean {it.mean():.1f}")
     for i, name in enumerate(PH):
-        print(f"  {name:8s} {mean[i]:12.0f} cycles  {100 * mean[i] / mean[13]:5.1f}%   per-iter {mean[i] / it.mean():9.0f}")
+        print(f"  {name:8s} {mean[i]:12.0f} cycles  {100 * mean[i] / mean[13]:5.1f}%   per-iter {mean[i] / max(it.mean(), 1):9.0f}")
 
 
 if __name__ == "__main__":
