@@ -41,7 +41,7 @@ struct KernelArgs {
   int warm;         // 1: block warm start of the working set (default), 0: cold start as the reference does
 };
 constexpr int NPROF = 24;
-enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK };
+enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A };
 #ifdef HMPC_PROFILE
 #define PROF_DECL long long _pt = clock64(), _pt0 = _pt; long long _pacc[NPROF] = {0}
 #define PROF_MARK(ph) do { long long _n = clock64(); _pacc[ph] += _n - _pt; _pt = _n; } while (0)
@@ -920,7 +920,10 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       k0 += cw;
     }
     k0 = uni(k0);
-    if (k0 > SM::QMAX) k0 = SM::QMAX;
+    constexpr int EPT = 5;  // packed-triangle entries per thread during the Schur inversion
+    constexpr int KBMAX = (NT >= 256) ? 45 : 34;  // KBMAX(KBMAX+1)/2 <= EPT*NT
+    static_assert(KBMAX * (KBMAX + 1) / 2 <= EPT * NT && KBMAX <= SM::QMAX, "block start capacity");
+    if (k0 > KBMAX) k0 = KBMAX;
     if (take && base + below < k0) {
       const int sl = base + below;
       Q.act[tid] = (signed char)side;
@@ -956,27 +959,59 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
         }
       }
       __syncthreads();
-      // (c) in-place inversion of the k0 x k0 Schur matrix by symmetric sweeps in LDS (two barriers per pivot)
-      for (int s = 0; s < k0; ++s) {
-        if (tid < k0) Q.col[tid] = Eref(S, tid, s);
-        __syncthreads();
-        const double idv = 1.0 / Q.col[s];
-        const int ti = tid >> 4, tj = tid & 15;
-        for (int ib = 0; ib < k0; ib += NT / 16) {
-          const int i = ib + ti;
-          if (i < k0) {
-            const double ci = Q.col[i] * idv;
-            for (int j = tj; j <= i; j += 16) {
-              double &ee = Q.Ep[i * (i + 1) / 2 + j];
-              const double cj = Q.col[j];
-              ee = (i == s) ? ((j == s) ? -idv : cj * idv) : ((j == s) ? ci : dfma(-ci, cj, ee));
-            }
+      PROF_MARK(P_B_S0);
+      // (c) inversion of the k0 x k0 Schur matrix by symmetric sweeps with the packed triangle spread over the threads'
+      //     registers (<= EPT entries each); the pivot column for sweep s+1 is published right after sweep s into a
+      //     double-buffered LDS vector -> one barrier per pivot, as in the big sweep
+      {
+        const int npair = k0 * (k0 + 1) / 2;
+        double er[EPT];
+        int ei[EPT], ej[EPT];
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+          const int t = tid + NT * u;
+          int i = 0, j = 0;
+          double v = 0.0;
+          if (t < npair) {
+            i = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while ((i + 1) * (i + 2) / 2 <= t) ++i;
+            while (i * (i + 1) / 2 > t) --i;
+            j = t - i * (i + 1) / 2;
+            v = Q.Ep[t];
+          } else {
+            i = -1, j = -1;
           }
+          er[u] = v, ei[u] = i, ej[u] = j;
         }
+        double *cb0 = Q.col, *cb1 = Q.z;
+#pragma unroll
+        for (int u = 0; u < EPT; ++u)
+          if (ej[u] == 0) cb0[ei[u]] = er[u];
         __syncthreads();
+        for (int s = 0; s < k0; ++s) {
+          const double *cs = (s & 1) ? cb1 : cb0;
+          double *cn = (s & 1) ? cb0 : cb1;
+          const double dv = cs[s];
+          double idv = __builtin_amdgcn_rcp(dv);
+          idv = dfma(dfma(-dv, idv, 1.0), idv, idv);
+          idv = dfma(dfma(-dv, idv, 1.0), idv, idv);
+#pragma unroll
+          for (int u = 0; u < EPT; ++u) {
+            const int i = ei[u], j = ej[u];
+            const double ci = cs[i < 0 ? 0 : i] * idv, cj = cs[j < 0 ? 0 : j];
+            const double upd = dfma(-ci, cj, er[u]);
+            er[u] = (i == s) ? ((j == s) ? -idv : cj * idv) : ((j == s) ? ci : upd);
+            if (j == s + 1) cn[i] = er[u];
+            else if (i == s + 1) cn[j] = er[u];
+          }
+          __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < EPT; ++u)
+          if (ei[u] >= 0) Q.Ep[tid + NT * u] = -er[u];  // the sweeps leave -S0^-1
       }
-      for (int t = tid; t < k0 * (k0 + 1) / 2; t += NT) Q.Ep[t] = -Q.Ep[t];  // sweeps leave -S0^-1
       q = k0;
+      PROF_MARK(P_B_INV);
       // (d) multipliers u = E (b - N x_u); rows with a negative multiplier do not belong to the working set: remove the
       //     most negative one, update E by the Schur complement, repeat
       active_residual(Q.xu);
@@ -1009,6 +1044,7 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
         drop_slot(l);
         if (q == 0) break;
       }
+      PROF_MARK(P_B_DROP);
       // (e) x = x_u + M N' u
       if (q > 0) {
         gather_w(Q.u, 1.0, 0.0);
@@ -1023,6 +1059,7 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
 
   // =============================== Q: dual active set (Goldfarb-Idnani, range-space form) ===============================
   for (int pass = 0; pass < 3 && code == S_OK; ++pass) {
+    const int iters_at_entry = iters;
     // ---- main loop ----
     while (true) {
       // (1) most violated constraint; the winning lane of each wave also publishes its constants
@@ -1043,6 +1080,7 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
           for (int k = 0; k < 6; ++k) rc.cn[k] = c_cn[k];
         }
       }
+      PROF_MARK(P_SEL_A);
       __syncthreads();
       int wsel = 0;
       double pval = Q.rec[0].val;
@@ -1190,6 +1228,7 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       if (code != S_OK) break;
     }
     if (code != S_OK || q == 0) break;
+    if (pass > 0 && iters == iters_at_entry) break;  // the refined point is feasible: done
 
     // ---- refinement of the multipliers on the final working set: u += E (b_W - N_W x(u)), x(u) = x_u + M N_W' u ----
     for (int it = 0; it < 3; ++it) {
