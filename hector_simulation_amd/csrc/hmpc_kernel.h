@@ -99,7 +99,7 @@ struct Smem {
   struct Sol {
     alignas(16) double x[NMAX], xu[NMAX], z[NMAX], w[NMAX];
     alignas(16) double ST[NG][NMAX];  // staged partials of the in-place mat-vec: ST[source leg-step][variable]
-    alignas(16) double piv[2][NMAX];
+    alignas(16) double piv[2][2][NMAX];  // [buffer][pivot row of the pair][column]
     double u[NMAX], d[NMAX], r[NMAX], col[NMAX];
     double redv[NW], redw[NW];
     double gamma;
@@ -588,12 +588,22 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       a[ii][jj] = v;
     }
   __syncthreads();  // every block is loaded before the solver state (which aliases the staging area) is written
-  if (tid < NMAX) Q.piv[0][tid] = 0.0, Q.piv[1][tid] = 0.0;
+  // Pivots are taken two at a time (2x2 block sweeps): with P = {k, k+1}, D = a_PP,
+  //   a_RR -= a_RP D^-1 a_PR,  a_RP <- a_RP D^-1,  a_PR <- D^-1 a_PR,  a_PP <- -D^-1.
+  // Rows/columns in P reuse the generic two-term update with substituted multipliers (I - D^-1 on the row side, D - I on the
+  // column side), so the 6x6 block update has no special cases; only the 2x2 block itself is patched.  Half the barriers.
+  if (tid < NMAX) {
+    Q.piv[0][0][tid] = 0.0, Q.piv[0][1][tid] = 0.0;
+    Q.piv[1][0][tid] = 0.0, Q.piv[1][1][tid] = 0.0;
+  }
   __syncthreads();
   if (owner && e0 == 0) {
 #pragma unroll
-    for (int jj = 0; jj < GS; ++jj)
-      if (j0 + jj < n) Q.piv[0][j0 + jj] = a[0][jj];
+    for (int jj = 0; jj < GS; ++jj) {
+      if (j0 + jj < n) Q.piv[0][0][j0 + jj] = a[0][jj];
+      if (j0 + jj < n && (!diag || jj >= 1)) Q.piv[0][1][j0 + jj] = a[1][jj];
+    }
+    if (diag) Q.piv[0][1][0] = a[0][1];
   }
   __syncthreads();
   for (int kb = 0; kb < ng; ++kb) {
@@ -602,55 +612,75 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
     const bool rown = owner && (e0 == kb + 1);  // next leg-step's row / column blocks (publish at the seam)
     const bool coln = owner && (e1 == kb + 1);
 #pragma unroll
-    for (int kk = 0; kk < GS; ++kk) {
+    for (int kk = 0; kk < GS; kk += 2) {
       const int k = kb * GS + kk;
-      const double *pv = Q.piv[k & 1];
-      double *pn = Q.piv[(k + 1) & 1];
-      const double d = pv[k];
-      double pi[GS], pj[GS];
+      const int buf = ((kb * (GS / 2) + kk / 2) & 1);
+      const double *pv1 = Q.piv[buf][0], *pv2 = Q.piv[buf][1];
+      double *pn1 = Q.piv[buf ^ 1][0], *pn2 = Q.piv[buf ^ 1][1];
+      const double d11 = pv1[k], d12 = pv1[k + 1], d22 = pv2[k + 1];
+      double p1i[GS], p2i[GS], p1j[GS], p2j[GS];
 #pragma unroll
       for (int ii = 0; ii < GS; ii += 2) {
-        const double2 t2 = *reinterpret_cast<const double2 *>(pv + i0 + ii);
-        pi[ii] = t2.x, pi[ii + 1] = t2.y;
+        const double2 t1 = *reinterpret_cast<const double2 *>(pv1 + i0 + ii);
+        const double2 t2 = *reinterpret_cast<const double2 *>(pv2 + i0 + ii);
+        const double2 u1 = *reinterpret_cast<const double2 *>(pv1 + j0 + ii);
+        const double2 u2 = *reinterpret_cast<const double2 *>(pv2 + j0 + ii);
+        p1i[ii] = t1.x, p1i[ii + 1] = t1.y, p2i[ii] = t2.x, p2i[ii + 1] = t2.y;
+        p1j[ii] = u1.x, p1j[ii + 1] = u1.y, p2j[ii] = u2.x, p2j[ii + 1] = u2.y;
       }
+      const double det = dfma(d11, d22, -(d12 * d12));
+      double idet = __builtin_amdgcn_rcp(det);  // v_rcp_f64 + two Newton steps (the solver half is not bit-pinned)
+      idet = dfma(dfma(-det, idet, 1.0), idet, idet);
+      idet = dfma(dfma(-det, idet, 1.0), idet, idet);
+      const double i11 = d22 * idet, i12 = -(d12 * idet), i22 = d11 * idet;  // D^-1
+      double q1[GS], q2[GS];
 #pragma unroll
-      for (int jj = 0; jj < GS; jj += 2) {
-        const double2 t2 = *reinterpret_cast<const double2 *>(pv + j0 + jj);
-        pj[jj] = t2.x, pj[jj + 1] = t2.y;
+      for (int ii = 0; ii < GS; ++ii) {
+        q1[ii] = dfma(p2i[ii], i12, p1i[ii] * i11);
+        q2[ii] = dfma(p2i[ii], i22, p1i[ii] * i12);
       }
-      double invd = __builtin_amdgcn_rcp(d);  // v_rcp_f64 + two Newton steps (the solver half is not bit-pinned)
-      invd = dfma(dfma(-d, invd, 1.0), invd, invd);
-      invd = dfma(dfma(-d, invd, 1.0), invd, invd);
-      double qi[GS];
-#pragma unroll
-      for (int ii = 0; ii < GS; ++ii) qi[ii] = pi[ii] * invd;
-      qi[kk] = rowb ? (1.0 - invd) : qi[kk];
-      pj[kk] = colb ? (d - 1.0) : pj[kk];
+      q1[kk] = rowb ? (1.0 - i11) : q1[kk], q2[kk] = rowb ? -i12 : q2[kk];
+      q1[kk + 1] = rowb ? -i12 : q1[kk + 1], q2[kk + 1] = rowb ? (1.0 - i22) : q2[kk + 1];
+      p1j[kk] = colb ? (d11 - 1.0) : p1j[kk], p2j[kk] = colb ? d12 : p2j[kk];
+      p1j[kk + 1] = colb ? d12 : p1j[kk + 1], p2j[kk + 1] = colb ? (d22 - 1.0) : p2j[kk + 1];
 #pragma unroll
       for (int ii = 0; ii < GS; ++ii)
 #pragma unroll
-        for (int jj = 0; jj < GS; ++jj) a[ii][jj] = dfma(-qi[ii], pj[jj], a[ii][jj]);
-      a[kk][kk] = (rowb && colb) ? -invd : a[kk][kk];
-      // publish row k+1 of the symmetric matrix: (k+1, j >= k+1) from its row blocks, (i < k+1, k+1) from its column blocks
-      if (kk + 1 < GS) {
+        for (int jj = 0; jj < GS; ++jj) a[ii][jj] = dfma(-q2[ii], p2j[jj], dfma(-q1[ii], p1j[jj], a[ii][jj]));
+      if (rowb && colb) {
+        a[kk][kk] = -i11, a[kk][kk + 1] = -i12, a[kk + 1][kk] = -i12, a[kk + 1][kk + 1] = -i22;
+      }
+      // publish rows k+2, k+3 of the symmetric matrix: (r, j >= r) from the row blocks, (i < r, r) from the column blocks
+      if (kk + 2 < GS) {
         if (rowb) {
 #pragma unroll
-          for (int jj = 0; jj < GS; ++jj)
-            if (!diag || jj >= kk + 1) pn[j0 + jj] = a[(kk + 1) % GS][jj];
+          for (int jj = 0; jj < GS; ++jj) {
+            if (!diag || jj >= kk + 2) pn1[j0 + jj] = a[(kk + 2) % GS][jj];
+            if (!diag || jj >= kk + 3) pn2[j0 + jj] = a[(kk + 3) % GS][jj];
+          }
         }
         if (colb) {
 #pragma unroll
-          for (int ii = 0; ii < GS; ++ii)
-            if (!diag || ii < kk + 1) pn[i0 + ii] = a[ii][(kk + 1) % GS];
+          for (int ii = 0; ii < GS; ++ii) {
+            if (!diag || ii < kk + 2) pn1[i0 + ii] = a[ii][(kk + 2) % GS];
+            if (!diag || ii < kk + 3) pn2[i0 + ii] = a[ii][(kk + 3) % GS];
+          }
         }
       } else if (kb + 1 < ng) {
         if (rown) {
 #pragma unroll
-          for (int jj = 0; jj < GS; ++jj) pn[j0 + jj] = a[0][jj];
+          for (int jj = 0; jj < GS; ++jj) {
+            pn1[j0 + jj] = a[0][jj];
+            if (!diag || jj >= 1) pn2[j0 + jj] = a[1][jj];
+          }
+          if (diag) pn2[i0] = a[0][1];
         }
         if (coln && !diag) {
 #pragma unroll
-          for (int ii = 0; ii < GS; ++ii) pn[i0 + ii] = a[ii][0];
+          for (int ii = 0; ii < GS; ++ii) {
+            pn1[i0 + ii] = a[ii][0];
+            pn2[i0 + ii] = a[ii][1];
+          }
         }
       }
       __syncthreads();
@@ -965,6 +995,7 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       //     double-buffered LDS vector -> one barrier per pivot, as in the big sweep
       {
         const int npair = k0 * (k0 + 1) / 2;
+        const int nept = (npair + NT - 1) / NT;
         double er[EPT];
         int ei[EPT], ej[EPT];
 #pragma unroll
@@ -997,12 +1028,14 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
           idv = dfma(dfma(-dv, idv, 1.0), idv, idv);
 #pragma unroll
           for (int u = 0; u < EPT; ++u) {
-            const int i = ei[u], j = ej[u];
-            const double ci = cs[i < 0 ? 0 : i] * idv, cj = cs[j < 0 ? 0 : j];
-            const double upd = dfma(-ci, cj, er[u]);
-            er[u] = (i == s) ? ((j == s) ? -idv : cj * idv) : ((j == s) ? ci : upd);
-            if (j == s + 1) cn[i] = er[u];
-            else if (i == s + 1) cn[j] = er[u];
+            if (u < nept) {  // uniform: only the register slots this k0 actually uses
+              const int i = ei[u], j = ej[u];
+              const double ci = cs[i < 0 ? 0 : i] * idv, cj = cs[j < 0 ? 0 : j];
+              const double upd = dfma(-ci, cj, er[u]);
+              er[u] = (i == s) ? ((j == s) ? -idv : cj * idv) : ((j == s) ? ci : upd);
+              if (j == s + 1) cn[i] = er[u];
+              else if (i == s + 1) cn[j] = er[u];
+            }
           }
           __syncthreads();
         }
