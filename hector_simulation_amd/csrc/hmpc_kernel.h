@@ -90,6 +90,7 @@ struct Smem {
     float Apow[2 * 169];
     float Phi[HMAX * 156], SPhi[HMAX * 156];
     float e[13 * HMAX];
+    unsigned char pre_nl[HMAX], pre_nv[HMAX], pre_st[HMAX];  // per step: leg-steps / variables before it, stance bits
     float Hs[(NMAX / 2) * (NMAX + 1)];  // H, upper triangle, binary32 (exact), rows i and NMAX-1-i folded into one
   };
   struct Rec {
@@ -218,7 +219,8 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       const int k = i % 5;
       if (k == 2 || k == 4) a = (float)((double)a + 0.3 * PI);
       if (k == 3) a = (float)((double)a - 0.6 * PI);
-      return (float)fmod((double)a, PI2);
+      const double ad = (double)a;
+      return (float)((__builtin_fabs(ad) < PI2) ? ad : fmod(ad, PI2));  // fmod(x,y) == x exactly when |x| < y
     };
     if (tid < 10) {
       double s, c;
@@ -260,34 +262,16 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
         A.ypsc[1] = (float)s;
       }
     } else if (tid == 64) {
-      // a leg-step survives iff its Fz bound f_max*gait is not ~0.  Two orders of the surviving variables:
-      //  reference order (ascending original index, SolverMPC.cpp:644-658): used to build H, g bit-identically;
-      //  sweep order (leg-step major, [F(3), M(3)] each): used by the solver, 6x6 blocks = leg-step pairs.
+      // a leg-step survives iff its Fz bound f_max*gait is not ~0 (SolverMPC.cpp:589-637): per-step prefix counts here,
+      // the index tables are filled in parallel in the next stage
       int nv = 0, nl = 0;
       for (int i = 0; i < h; ++i) {
         float ubL = args.f_max * (float)gait[2 * i], ubR = args.f_max * (float)gait[2 * i + 1];
         const bool sL = !(ubL < 0.0001 && ubL > -.0001), sR = !(ubR < 0.0001 && ubR > -.0001);
         const int nst = (int)sL + (int)sR;
-        for (int c = 0; c < 12; ++c) S.rmap[12 * i + c] = 255;
-        if (nl + nst <= NG) {
-          int rank = 0;
-          for (int leg = 0; leg < 2; ++leg)
-            if (leg == 0 ? sL : sR) {
-              const int e = nl + rank;
-              S.ls_leg[e] = (unsigned char)leg;
-              S.ub7[e] = (double)(leg == 0 ? ubL : ubR);
-              for (int k = 0; k < 3; ++k) {
-                const int oF = nv + 3 * rank + k, oM = nv + 3 * nst + 3 * rank + k;
-                S.vstep[oF] = (unsigned char)i, S.vcomp[oF] = (unsigned char)(3 * leg + k);
-                S.vstep[oM] = (unsigned char)i, S.vcomp[oM] = (unsigned char)(6 + 3 * leg + k);
-                S.o2s[oF] = (unsigned char)(GS * e + k), S.s2o[GS * e + k] = (unsigned char)oF;
-                S.o2s[oM] = (unsigned char)(GS * e + 3 + k), S.s2o[GS * e + 3 + k] = (unsigned char)oM;
-                S.rmap[12 * i + 3 * leg + k] = (unsigned char)(GS * e + k);
-                S.rmap[12 * i + 6 + 3 * leg + k] = (unsigned char)(GS * e + 3 + k);
-              }
-              ++rank;
-            }
-        }
+        A.pre_nl[i] = (unsigned char)(nl > 255 ? 255 : nl);
+        A.pre_nv[i] = (unsigned char)(nv > 255 ? 255 : nv);
+        A.pre_st[i] = (unsigned char)((sL ? 1 : 0) | (sR ? 2 : 0));
         nv += 6 * nst;
         nl += nst;
       }
@@ -295,6 +279,11 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       S.nls = nl;
       S.m = 8 * nl;
     }
+    // constant structure of Acd (identity), Bcd (zeros) and the constraint block (zeros), filled by everyone
+    for (int t = tid; t < 169; t += NT) A.Acd[t] = (t % 14 == 0) ? 1.0f : 0.0f;  // fl(delta + dt*0) = delta
+    for (int t = tid; t < 156; t += NT) A.Bcd[t] = 0.0f;                          // fl(dt*0) = 0
+    for (int t = tid; t < 192; t += NT) A.Fc[t] = 0.0f;
+    for (int t = tid; t < 12 * h; t += NT) S.rmap[t] = 255;
   }
   __syncthreads();
 
@@ -327,8 +316,6 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
 
     // continuous model -> forward Euler (SolverMPC.cpp:312-331, 145-146); mass 9.0 (:423)
     const float dt = args.dt;
-    for (int i = 0; i < 169; ++i) A.Acd[i] = (i % 14 == 0) ? 1.0f : 0.0f;  // fl(delta + dt*0) = delta
-    for (int i = 0; i < 156; ++i) A.Bcd[i] = 0.0f;                          // fl(dt*0) = 0
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) A.Acd[i * 13 + 6 + j] = 0.0f + dt * Rbi[i * 3 + j];
     for (int i = 0; i < 3; ++i) A.Acd[(3 + i) * 13 + 9 + i] = 0.0f + dt * 1.0f;
@@ -352,7 +339,7 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
   {
     // foot rotation Rz(q0)Rx(q1)Ry(q2)Ry(q3)Ry(q4) and this leg's 8 rows of the 16x12 constraint block
     // (SolverMPC.cpp:426-433, 488-548)
-    const int leg_lane0 = (NT >= 256) ? 128 : 64, leg_lane1 = (NT >= 256) ? 192 : 65;
+    const int leg_lane0 = (NT >= 256) ? 128 : 1, leg_lane1 = (NT >= 256) ? 192 : 2;
     if (tid == leg_lane0 || tid == leg_lane1) {
       const int leg = (tid == leg_lane0) ? 0 : 1;
       float R[9], Rt[9];
@@ -392,7 +379,6 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       chain_mm<1, 3, 3>(vlt, Rt, flt);
       chain_mm<1, 3, 3>(vlh, Rt, flh);
       float *row = A.Fc + (8 * leg) * 12;
-      for (int i = 0; i < 96; ++i) row[i] = 0.0f;
       const int cf = 3 * leg, cmo = 6 + 3 * leg;
       row[0 * 12 + cf + 0] = -mu, row[0 * 12 + cf + 2] = 1.0f;
       row[1 * 12 + cf + 0] = mu, row[1 * 12 + cf + 2] = 1.0f;
@@ -412,6 +398,33 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
           S.Cn[leg][rr][k] = (double)row[rr * 12 + cf + k];
           S.Cn[leg][rr][3 + k] = (double)row[rr * 12 + cmo + k];
         }
+    }
+  }
+  {
+    // index tables, one work item per (step, leg, k): two orders of the surviving variables --
+    //  reference order (ascending original index, SolverMPC.cpp:644-658): used to build H, g bit-identically;
+    //  sweep order (leg-step major, [F(3), M(3)] each): used by the solver, 6x6 blocks = leg-step pairs.
+    const int nl_tot = S.nls;
+    if (tid >= 64 && tid < 128 && nl_tot <= NG) {
+      for (int it = tid - 64; it < 6 * h; it += 64) {
+        const int i = it / 6, leg = (it / 3) & 1, k = it % 3;
+        const int st = A.pre_st[i];
+        if (st & (1 << leg)) {
+          const int nst = (st & 1) + (st >> 1), rank = (leg == 1 && (st & 1)) ? 1 : 0;
+          const int e = A.pre_nl[i] + rank, nv = A.pre_nv[i];
+          const int oF = nv + 3 * rank + k, oM = nv + 3 * nst + 3 * rank + k;
+          S.vstep[oF] = (unsigned char)i, S.vcomp[oF] = (unsigned char)(3 * leg + k);
+          S.vstep[oM] = (unsigned char)i, S.vcomp[oM] = (unsigned char)(6 + 3 * leg + k);
+          S.o2s[oF] = (unsigned char)(GS * e + k), S.s2o[GS * e + k] = (unsigned char)oF;
+          S.o2s[oM] = (unsigned char)(GS * e + 3 + k), S.s2o[GS * e + 3 + k] = (unsigned char)oM;
+          S.rmap[12 * i + 3 * leg + k] = (unsigned char)(GS * e + k);
+          S.rmap[12 * i + 6 + 3 * leg + k] = (unsigned char)(GS * e + 3 + k);
+          if (k == 0) {
+            S.ls_leg[e] = (unsigned char)leg;
+            S.ub7[e] = (double)(args.f_max * (float)gait[2 * i + leg]);
+          }
+        }
+      }
     }
   }
   // identity power
@@ -498,17 +511,15 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       const int sb = cbv ? S.vstep[cb] : 0, cc = cbv ? S.vcomp[cb] : 0;
       const int istart = S.vstep[16 * J];
       f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 2
       for (int i = istart; i < h; ++i) {
         const bool la = rav && i >= sa, lb = cbv && i >= sb;
-        const float *pa = A.SPhi + (la ? (i - sa) * 156 + ca : 0);
-        const float *pb = A.Phi + (lb ? (i - sb) * 156 + cc : 0);
-#pragma unroll
-        for (int k4 = 0; k4 < 3; ++k4) {
-          const int s = 4 * k4 + kq;
-          const float av = la ? pa[s * 12] : 0.0f;
-          const float bv = lb ? pb[s * 12] : 0.0f;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-        }
+        const float *pa = A.SPhi + (la ? (i - sa) * 156 + ca : 0) + kq * 12;
+        const float *pb = A.Phi + (lb ? (i - sb) * 156 + cc : 0) + kq * 12;
+        const float a0 = pa[0], a1 = pa[48], a2 = pa[96], b0 = pb[0], b1 = pb[48], b2 = pb[96];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la ? a0 : 0.0f, lb ? b0 : 0.0f, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la ? a1 : 0.0f, lb ? b1 : 0.0f, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la ? a2 : 0.0f, lb ? b2 : 0.0f, acc, 0, 0, 0);
       }
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
