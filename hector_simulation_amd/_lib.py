@@ -14,12 +14,23 @@ EXPORTS = [
     "hmpc_get_q_soln", "hmpc_last_status", "hmpc_record_stride", "hmpc_pack_record", "hmpc_create", "hmpc_destroy",
     "hmpc_upload_records", "hmpc_set_device_records", "hmpc_set_max_reduced_vars", "hmpc_set_warm_start", "hmpc_set_device_outputs",
     "hmpc_solve", "hmpc_download", "hmpc_get_device_outputs", "hmpc_batch", "hmpc_horizon", "hmpc_time_solve",
-    "hmpc_debug_assemble", "hmpc_debug_phase_cycles", "hmpc_download_f64", "hmpc_last_hip_error", "hmpc_version",
+    "hmpc_build_records", "hmpc_build_records_device", "hmpc_body_wrench", "hmpc_body_wrench_device",
+    "hmpc_download_records", "hmpc_debug_assemble", "hmpc_debug_phase_cycles", "hmpc_download_f64", "hmpc_last_hip_error", "hmpc_version",
 ]
 
 
 class ProblemSetup(C.Structure):
     _fields_ = [("dt", C.c_float), ("mu", C.c_float), ("f_max", C.c_float), ("horizon", C.c_int)]
+
+
+class TickInputs(C.Structure):
+    """include/hector_mpc.h struct hmpc_tick_inputs (what updateMPCIfNeeded reads for one tick)."""
+    _fields_ = [("position", C.c_double * 3), ("vWorld", C.c_double * 3), ("omegaWorld", C.c_double * 3),
+                ("orientation", C.c_double * 4), ("rpy", C.c_double * 3), ("rBody", C.c_double * 9),
+                ("leg_q", C.c_double * 10), ("pFoot", C.c_double * 6), ("v_des_robot", C.c_double * 2),
+                ("yaw_rate_des", C.c_double), ("roll_des", C.c_double), ("pitch_des", C.c_double),
+                ("world_position_desired", C.c_double * 2), ("gait_offsets", C.c_int * 2),
+                ("gait_durations", C.c_int * 2), ("gait_iteration", C.c_int), ("pad", C.c_int)]
 
 
 class UpdateData(C.Structure):
@@ -76,6 +87,11 @@ def load():
     L.hmpc_time_solve.argtypes = [vp, vp, ci, C.POINTER(cf)]
     L.hmpc_debug_assemble.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)] + [vp] * 9
     L.hmpc_download_f64.argtypes = [vp, vp, vp]
+    L.hmpc_build_records.argtypes = [vp, vp, ci, cd, vp]
+    L.hmpc_build_records_device.argtypes = [vp, vp, ci, cd, vp, vp]
+    L.hmpc_body_wrench.argtypes = [vp, vp, vp]
+    L.hmpc_body_wrench_device.argtypes = [vp, vp, vp, vp]
+    L.hmpc_download_records.argtypes = [vp, vp]
     L.hmpc_debug_phase_cycles.argtypes = [vp, vp]
     L.hmpc_last_hip_error.restype = C.c_char_p
     L.hmpc_version.restype = C.c_char_p

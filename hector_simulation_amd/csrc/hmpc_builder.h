@@ -1,0 +1,126 @@
+// hmpc_builder.h -- the caller-side rows either side of the solve, batched on the device:
+//   f1  record builder      = ConvexMPCLocomotion::updateMPCIfNeeded's input construction
+//                             (ConvexMPC/ConvexMPCLocomotion.cpp:283-406) + the double->float narrowing of
+//                             update_problem_data (ConvexMPC/convexMPC_interface.cpp:83-103)
+//   f2  gait table          = Gait::mpc_gait (ConvexMPC/GaitGenerator.cpp:85-103), fused into f1
+//   f3  body-frame wrenches = f_ff[leg] = -rBody [GRF; GRM] (ConvexMPCLocomotion.cpp:419-440)
+// Both are plain streaming kernels (HBM-bound): binary64 arithmetic in the order the reference writes it, no contraction
+// (this translation unit is built with -ffp-contract=off), so the packed records are bit-identical to the CPU restatement.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hector_mpc.h"
+
+namespace hmpc {
+
+// One workgroup per instance; thread t produces 32-bit word t of the packed record (coalesced 720-B burst out).
+__global__ __launch_bounds__(256) void build_records_kernel(const hmpc_tick_inputs *ticks, int batch, int h, double dtMPC,
+                                                            unsigned char *records, int stride, double *wpd_out) {
+  const int inst = blockIdx.x;
+  if (inst >= batch) return;
+  const hmpc_tick_inputs &tk = ticks[inst];
+  const int nwords = stride >> 2, ntraj = 12 * h;
+  uint32_t *out = reinterpret_cast<uint32_t *>(records + (size_t)inst * stride);
+  const double PI = 3.14159265359, PI2 = 2 * PI;
+  const double *p = tk.position;
+  // shared scalars (recomputed per thread: a handful of flops on broadcast loads)
+  double vdw[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    vdw[i] = (tk.rBody[0 * 3 + i] * tk.v_des_robot[0] + tk.rBody[1 * 3 + i] * tk.v_des_robot[1]) + tk.rBody[2 * 3 + i] * 0.0;
+  const double max_pos_error = .05;
+  double xStart = tk.world_position_desired[0], yStart = tk.world_position_desired[1];
+  if (xStart - p[0] > max_pos_error) xStart = p[0] + max_pos_error;
+  if (p[0] - xStart > max_pos_error) xStart = p[0] - max_pos_error;
+  if (yStart - p[1] > max_pos_error) yStart = p[1] + max_pos_error;
+  if (p[1] - yStart > max_pos_error) yStart = p[1] - max_pos_error;
+  if (threadIdx.x == 0 && wpd_out) {
+    wpd_out[2 * inst + 0] = xStart;
+    wpd_out[2 * inst + 1] = yStart;
+  }
+  for (int t = threadIdx.x; t < nwords; t += blockDim.x) {
+    uint32_t word = 0;
+    if (t < 54 + ntraj) {
+      double v;
+      if (t < 3) v = p[t];
+      else if (t < 6) v = tk.vWorld[t - 3];
+      else if (t < 10) v = tk.orientation[t - 6];
+      else if (t < 13) v = tk.omegaWorld[t - 10];
+      else if (t < 19) {
+        const int i = t - 13;
+        v = tk.pFoot[3 * (i % 2) + i / 2] - p[i / 2];
+      } else if (t < 29) {
+        const int i = t - 19, k = i % 5;
+        double a = tk.leg_q[i];
+        if (k == 2 || k == 4) a += 0.3 * PI;
+        if (k == 3) a -= 0.6 * PI;
+        v = (__builtin_fabs(a) < PI2) ? a : fmod(a, PI2);  // fmod(x,y) == x exactly when |x| < y
+      } else if (t == 29) v = tk.rpy[2];
+      else if (t < 42) {
+        const int i = t - 30;
+        v = (i < 2) ? 100.0 : (i == 2 ? 250.0 : (i < 5 ? 200.0 : (i == 5 ? 300.0 : 1.0)));
+      } else if (t < 54) {
+        const int i = t - 42;
+        v = (i >= 6) ? 1e-2 : ((i == 2 || i == 5) ? 5e-4 : 1e-4);
+      } else {
+        const int i = (t - 54) / 12, j = (t - 54) % 12;
+        // trajInitial (ConvexMPCLocomotion.cpp:351-362)
+        double ti;
+        switch (j) {
+          case 0: ti = tk.roll_des; break;
+          case 1: ti = tk.pitch_des; break;
+          case 3: ti = xStart; break;
+          case 4: ti = yStart; break;
+          case 5: ti = 0.55; break;
+          case 8: ti = tk.yaw_rate_des; break;
+          case 9: ti = vdw[0]; break;
+          case 10: ti = vdw[1]; break;
+          default: ti = 0.0; break;
+        }
+        v = ti;
+        if (i == 0) {
+          if (j < 3) v = tk.rpy[j];
+          else if (j < 6) v = p[j - 3];
+        } else {
+          if (j == 3) v = (vdw[0] == 0) ? xStart + i * dtMPC * vdw[0] : p[0] + i * dtMPC * vdw[0];
+          if (j == 4) v = (vdw[1] == 0) ? yStart + i * dtMPC * vdw[1] : p[1] + i * dtMPC * vdw[1];
+          if (j == 2) v = (tk.yaw_rate_des == 0) ? 0.0 : tk.rpy[2] + i * dtMPC * tk.yaw_rate_des;
+        }
+      }
+      word = __float_as_uint((float)v);
+    } else {
+      // gait bytes (GaitGenerator.cpp:85-103), four per word
+      const int b0 = 4 * (t - 54 - ntraj);
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int gi = b0 + bb;
+        uint32_t byte = 0;
+        if (gi < 2 * h) {
+          const int i = gi >> 1, j = gi & 1;
+          const int iter = (i + tk.gait_iteration) % h;
+          int progress = iter - tk.gait_offsets[j];
+          if (progress < 0) progress += h;
+          byte = (progress < tk.gait_durations[j]) ? 1u : 0u;
+        }
+        word |= byte << (8 * bb);
+      }
+    }
+    out[t] = word;
+  }
+}
+
+// thread g -> (instance g/12, leg (g%12)/6, row (g%6)): f_ff = -rBody * [GRF; GRM]
+__global__ __launch_bounds__(256) void body_wrench_kernel(const float *forces, int batch, int h, const double *rBody,
+                                                          double *f_ff) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= 12 * batch) return;
+  const int inst = g / 12, c = g % 12, leg = c / 6, r6 = c % 6, i = r6 % 3;
+  const float *sol = forces + (size_t)inst * 12 * h;
+  const int base = (r6 < 3) ? leg * 3 : leg * 3 + 6;  // GRF = sol[3leg..], GRM = sol[3leg+6..]
+  const double *R = rBody + (size_t)inst * 9 + 3 * i;
+  const double v0 = (double)sol[base], v1 = (double)sol[base + 1], v2 = (double)sol[base + 2];
+  f_ff[g] = ((-R[0]) * v0 + (-R[1]) * v1) + (-R[2]) * v2;
+}
+
+}  // namespace hmpc

@@ -16,6 +16,7 @@
 
 #include "../../include/hector_mpc.h"
 #include "hmpc_kernel.h"
+#include "hmpc_builder.h"
 
 namespace {
 
@@ -358,6 +359,85 @@ int hmpc_debug_phase_cycles(hmpc_handle *h, long long *cycles /*[batch][24]*/) {
   h->d_prof = nullptr;
   return HMPC_OK;
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------- rows f1-f3
+int hmpc_build_records_device(hmpc_handle *h, const void *device_ticks, int batch, double dtMPC, double *device_wpd_out,
+                              void *stream) {
+  if (!h || !device_ticks || batch < 0) return HMPC_E_ARG;
+  if (batch > h->max_batch) return HMPC_E_BATCH;
+  HIP_TRY(hipSetDevice(h->device));
+  if (batch > 0) {
+    const int nwords = (int)h->stride / 4;
+    const int bs = ((nwords + 63) / 64) * 64 > 256 ? 256 : ((nwords + 63) / 64) * 64;
+    hipLaunchKernelGGL(hmpc::build_records_kernel, dim3(batch), dim3(bs), 0, (hipStream_t)stream,
+                       (const hmpc_tick_inputs *)device_ticks, batch, h->setup.horizon, dtMPC, h->d_records_own,
+                       (int)h->stride, device_wpd_out);
+    HIP_TRY(hipGetLastError());
+  }
+  h->d_records = h->d_records_own;
+  h->batch = batch;
+  h->max_stance = -1;
+  h->last_stream = (hipStream_t)stream;
+  return HMPC_OK;
+}
+
+int hmpc_build_records(hmpc_handle *h, const struct hmpc_tick_inputs *host_ticks, int batch, double dtMPC, double *wpd_out) {
+  if (!h || !host_ticks || batch < 0) return HMPC_E_ARG;
+  if (batch > h->max_batch) return HMPC_E_BATCH;
+  HIP_TRY(hipSetDevice(h->device));
+  hmpc_tick_inputs *d_t = nullptr;
+  double *d_w = nullptr;
+  HIP_TRY(hipMalloc(&d_t, sizeof(hmpc_tick_inputs) * (size_t)(batch > 0 ? batch : 1)));
+  HIP_TRY(hipMalloc(&d_w, sizeof(double) * 2 * (size_t)(batch > 0 ? batch : 1)));
+  HIP_TRY(hipMemcpy(d_t, host_ticks, sizeof(hmpc_tick_inputs) * (size_t)batch, hipMemcpyHostToDevice));
+  int rc = hmpc_build_records_device(h, d_t, batch, dtMPC, d_w, nullptr);
+  if (rc == HMPC_OK) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (wpd_out && batch) HIP_TRY(hipMemcpy(wpd_out, d_w, sizeof(double) * 2 * (size_t)batch, hipMemcpyDeviceToHost));
+  }
+  hipFree(d_t);
+  hipFree(d_w);
+  return rc;
+}
+
+int hmpc_body_wrench_device(hmpc_handle *h, const double *device_rBody, double *device_f_ff, void *stream) {
+  if (!h || !device_rBody || !device_f_ff) return HMPC_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->batch > 0) {
+    const int total = 12 * h->batch;
+    hipLaunchKernelGGL(hmpc::body_wrench_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->d_forces,
+                       h->batch, h->setup.horizon, device_rBody, device_f_ff);
+    HIP_TRY(hipGetLastError());
+  }
+  return HMPC_OK;
+}
+
+int hmpc_body_wrench(hmpc_handle *h, const double *host_rBody, double *host_f_ff) {
+  if (!h || !host_rBody || !host_f_ff) return HMPC_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t b = (size_t)(h->batch > 0 ? h->batch : 1);
+  double *d_r = nullptr, *d_f = nullptr;
+  HIP_TRY(hipMalloc(&d_r, sizeof(double) * 9 * b));
+  HIP_TRY(hipMalloc(&d_f, sizeof(double) * 12 * b));
+  HIP_TRY(hipMemcpy(d_r, host_rBody, sizeof(double) * 9 * (size_t)h->batch, hipMemcpyHostToDevice));
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
+  int rc = hmpc_body_wrench_device(h, d_r, d_f, nullptr);
+  if (rc == HMPC_OK) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_f_ff, d_f, sizeof(double) * 12 * (size_t)h->batch, hipMemcpyDeviceToHost));
+  }
+  hipFree(d_r);
+  hipFree(d_f);
+  return rc;
+}
+
+int hmpc_download_records(hmpc_handle *h, void *host_records) {
+  if (!h || !host_records) return HMPC_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
+  if (h->batch) HIP_TRY(hipMemcpy(host_records, h->d_records, (size_t)h->batch * h->stride, hipMemcpyDeviceToHost));
+  return HMPC_OK;
 }
 
 int hmpc_download_f64(hmpc_handle *h, double *x, double *obj) {

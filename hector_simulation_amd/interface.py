@@ -12,6 +12,12 @@ import numpy as np
 
 from . import _lib, records
 
+TICK_DTYPE = np.dtype([("position", "f8", 3), ("vWorld", "f8", 3), ("omegaWorld", "f8", 3), ("orientation", "f8", 4),
+                       ("rpy", "f8", 3), ("rBody", "f8", 9), ("leg_q", "f8", 10), ("pFoot", "f8", 6),
+                       ("v_des_robot", "f8", 2), ("yaw_rate_des", "f8"), ("roll_des", "f8"), ("pitch_des", "f8"),
+                       ("world_position_desired", "f8", 2), ("gait_offsets", "i4", 2), ("gait_durations", "i4", 2),
+                       ("gait_iteration", "i4"), ("pad", "i4")], align=True)
+
 STATUS_NAMES = {0: "ok", 1: "max_iter", 2: "infeasible", 3: "too_large", 4: "kkt", 5: "working_set_full"}
 
 
@@ -116,6 +122,28 @@ class BatchedMPC:
         obj = np.zeros(b, dtype=np.float64)
         _check(self.L.hmpc_download_f64(self.h, x.ctypes.data, obj.ctypes.data), "hmpc_download_f64")
         return x, obj
+
+    # ---- rows either side of the solve
+    def build_records(self, ticks: np.ndarray, dt_mpc: float):
+        """f1+f2 on the device: ticks = structured array with dtype ``TICK_DTYPE``; returns the clamped
+        world_position_desired [batch, 2].  The built records become the current batch."""
+        ticks = np.ascontiguousarray(ticks, dtype=TICK_DTYPE)
+        wpd = np.zeros((ticks.shape[0], 2), dtype=np.float64)
+        _check(self.L.hmpc_build_records(self.h, ticks.ctypes.data, ticks.shape[0], float(dt_mpc), wpd.ctypes.data),
+               "hmpc_build_records")
+        return wpd
+
+    def download_records(self) -> np.ndarray:
+        rec = np.zeros((self.batch, self.stride), dtype=np.uint8)
+        _check(self.L.hmpc_download_records(self.h, rec.ctypes.data), "hmpc_download_records")
+        return rec
+
+    def body_wrench(self, rBody: np.ndarray) -> np.ndarray:
+        """f3: f_ff[batch, 2, 6] = -rBody [GRF; GRM] from the last solve's forces."""
+        rb = np.ascontiguousarray(rBody, dtype=np.float64).reshape(self.batch, 9)
+        out = np.zeros((self.batch, 2, 6), dtype=np.float64)
+        _check(self.L.hmpc_body_wrench(self.h, rb.ctypes.data, out.ctypes.data), "hmpc_body_wrench")
+        return out
 
     def time_solve(self, reps: int, stream: int = 0) -> float:
         ms = C.c_float(0)

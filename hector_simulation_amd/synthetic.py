@@ -114,3 +114,49 @@ CONFIGS = {
     "cfg4_h20_single_4096": dict(batch=4096, horizon=20, gait="single", seed=4, phase="random"),
     "metric_2contact_1024": dict(batch=1024, horizon=10, gait="standing", seed=6),
 }
+
+
+def rotation_world_to_body(q):
+    """orientation_tools.h:182-200 quaternionToRotationMatrix (returns the transposed matrix = world -> body)."""
+    e0, e1, e2, e3 = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    R = np.stack([1 - 2 * (e2 * e2 + e3 * e3), 2 * (e1 * e2 - e0 * e3), 2 * (e1 * e3 + e0 * e2),
+                  2 * (e1 * e2 + e0 * e3), 1 - 2 * (e1 * e1 + e3 * e3), 2 * (e2 * e3 - e0 * e1),
+                  2 * (e1 * e3 - e0 * e2), 2 * (e2 * e3 + e0 * e1), 1 - 2 * (e1 * e1 + e2 * e2)], axis=-1)
+    R = R.reshape(q.shape[:-1] + (3, 3))
+    return np.swapaxes(R, -1, -2)
+
+
+def make_ticks(batch: int, horizon: int = 10, gait: str = "walking", seed: int = 0, randomize: bool = True):
+    """What ConvexMPCLocomotion::updateMPCIfNeeded reads for one tick (ConvexMPCLocomotion.cpp:283-406), as a
+    structured array laid out like ``struct hmpc_tick_inputs`` -- the input of the device-side record builder."""
+    from .interface import TICK_DTYPE
+
+    rng = np.random.default_rng(seed)
+    b, h = batch, horizon
+    u = (lambda lo, hi, *s: rng.uniform(lo, hi, (b,) + s)) if randomize else (lambda lo, hi, *s: np.zeros((b,) + s))
+    t = np.zeros(b, dtype=TICK_DTYPE)
+    rpy = np.stack([u(-0.1, 0.1), u(-0.1, 0.1), u(-0.5, 0.5)], -1)
+    t["rpy"] = rpy
+    t["orientation"] = quat_from_rpy(rpy[:, 0], rpy[:, 1], rpy[:, 2])
+    t["rBody"] = rotation_world_to_body(t["orientation"]).reshape(b, 9)
+    t["position"] = np.stack([u(-2, 2), u(-2, 2), NOMINAL_HEIGHT + u(-0.03, 0.03)], -1)
+    t["vWorld"] = u(-0.3, 0.3, 3)
+    t["omegaWorld"] = u(-0.5, 0.5, 3)
+    foot = np.zeros((b, 2, 3))
+    foot[:, 0, 1], foot[:, 1, 1] = 0.06, -0.06
+    foot[:, :, 0] += u(-0.1, 0.1, 2)
+    foot[:, :, 1] += u(-0.03, 0.03, 2)
+    foot[:, :, 2] = -t["position"][:, 2:3]
+    t["pFoot"] = (foot + t["position"][:, None, :]).reshape(b, 6)
+    t["leg_q"] = u(-0.15, 0.15, 10) + np.tile([0, 0, -0.3 * 3.14159265359, 0.6 * 3.14159265359, -0.3 * 3.14159265359], 2)
+    t["v_des_robot"] = u(-0.5, 0.5, 2) * (rng.random((b, 2)) > 0.25)     # some commands are exactly zero
+    t["yaw_rate_des"] = u(-0.3, 0.3) * (rng.random(b) > 0.5)
+    t["roll_des"], t["pitch_des"] = u(-0.02, 0.02), u(-0.02, 0.02)
+    t["world_position_desired"] = t["position"][:, :2] + u(-0.12, 0.12, 2)  # beyond the 5 cm clamp on some
+    half = h // 2
+    if gait == "standing":
+        t["gait_offsets"], t["gait_durations"] = (0, 0), (h, h)
+    else:
+        t["gait_offsets"], t["gait_durations"] = (0, half), (half, h - half)
+    t["gait_iteration"] = rng.integers(0, h, size=b)
+    return t

@@ -130,6 +130,34 @@ int hmpc_horizon(const hmpc_handle *h);
  * `stream` (used by bench.py for the roofline object) */
 int hmpc_time_solve(hmpc_handle *h, void *stream, int reps, float *ms_per_launch);
 
+
+/* ---- the rows either side of the solve, batched on the device ----
+ * hmpc_tick_inputs = everything ConvexMPCLocomotion::updateMPCIfNeeded reads to build one MPC tick
+ * (ConvexMPC/ConvexMPCLocomotion.cpp:283-406): state estimate, leg joint angles, foot positions, commands, the
+ * persistent world_position_desired, and the Gait parameters of ConvexMPC/GaitGenerator.cpp:85-113. */
+struct hmpc_tick_inputs {
+  double position[3], vWorld[3], omegaWorld[3], orientation[4], rpy[3];
+  double rBody[9];        /* row-major, world -> body (orientation_tools.h:182-200) */
+  double leg_q[10];       /* raw joint angles, left 0-4, right 5-9 */
+  double pFoot[6];        /* world foot positions, [leg][axis] */
+  double v_des_robot[2];  /* stateDes[6], stateDes[7] */
+  double yaw_rate_des;    /* stateDes[11] */
+  double roll_des, pitch_des; /* stateDes[3], stateDes[4] */
+  double world_position_desired[2];
+  int gait_offsets[2], gait_durations[2], gait_iteration, pad;
+};
+/* f1+f2: builds the packed records of `batch` ticks on the device into the handle's own record buffer (which becomes
+ * the current batch) and returns the clamped world_position_desired (ConvexMPCLocomotion.cpp:336-346) per instance.
+ * host_ticks / wpd_out are host pointers (wpd_out may be NULL); the _device form takes device pointers and a stream. */
+int hmpc_build_records(hmpc_handle *h, const struct hmpc_tick_inputs *host_ticks, int batch, double dtMPC, double *wpd_out);
+int hmpc_build_records_device(hmpc_handle *h, const void *device_ticks, int batch, double dtMPC, double *device_wpd_out,
+                              void *stream);
+/* f3: f_ff[batch][2][6] = -rBody [GRF; GRM] from the forces of the last solve (ConvexMPCLocomotion.cpp:419-440) */
+int hmpc_body_wrench(hmpc_handle *h, const double *host_rBody, double *host_f_ff);
+int hmpc_body_wrench_device(hmpc_handle *h, const double *device_rBody, double *device_f_ff, void *stream);
+/* copies the current batch's packed records device -> host (parity hook for f1/f2) */
+int hmpc_download_records(hmpc_handle *h, void *host_records);
+
 /* Parity hook: runs the ASSEMBLY stage only for instance `index` of the current batch (same device code the
  * solve kernel runs) and returns the reduced QP exactly as the solver sees it: n, m, var_ind[n] (original
  * variable index, SolverMPC.cpp:644-658), H[n*n] (float, row-major, symmetric), g[n], the 16x12 constraint

@@ -602,3 +602,92 @@ int orc_solve_records(const unsigned char *records, int stride, int first, int c
   orc_red_free(red);
   return bad;
 }
+
+
+/* ================= SURVEY.md section 8(f): f1 input builder, f2 gait table, f3 wrench consumer ================= */
+
+/* GaitGenerator.cpp:85-103 */
+void orc_mpc_gait(int n, const int offsets[2], const int durations[2], int iteration, int *table) {
+  for (int i = 0; i < n; ++i) {
+    int iter = (i + iteration) % n;
+    for (int j = 0; j < 2; ++j) {
+      int progress = iter - offsets[j];
+      if (progress < 0) progress += n;
+      table[2 * i + j] = (progress < durations[j]) ? 1 : 0;
+    }
+  }
+}
+
+/* ConvexMPCLocomotion.cpp:283-406, then the double->float / int->u8 narrowing of convexMPC_interface.cpp:83-103 */
+void orc_build_record(const orc_tick_t *t, int h, double dtMPC, unsigned char *record, double wpd_out[2]) {
+  double q[10];
+  for (int i = 0; i < 10; ++i) q[i] = t->leg_q[i];
+  const double PI = 3.14159265359;
+  q[2] += 0.3 * PI, q[3] -= 0.6 * PI, q[4] += 0.3 * PI;
+  q[7] += 0.3 * PI, q[8] -= 0.6 * PI, q[9] += 0.3 * PI;
+  const double PI2 = 2 * PI;
+  for (int i = 0; i < 10; ++i) q[i] = fmod(q[i], PI2);
+  double r[6];
+  for (int i = 0; i < 6; ++i) r[i] = t->pFoot[3 * (i % 2) + i / 2] - t->position[i / 2];
+  const double Q[12] = {100, 100, 250, 200, 200, 300, 1, 1, 1, 1, 1, 1};
+  const double Alpha[12] = {1e-4, 1e-4, 5e-4, 1e-4, 1e-4, 5e-4, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2};
+  const double yaw = t->rpy[2];
+  /* v_des_world = rBody' * (vx, vy, 0), three-term dot products in index order */
+  double vdw[3];
+  for (int i = 0; i < 3; ++i)
+    vdw[i] = (t->rBody[0 * 3 + i] * t->v_des_robot[0] + t->rBody[1 * 3 + i] * t->v_des_robot[1]) + t->rBody[2 * 3 + i] * 0.0;
+  const double max_pos_error = .05;
+  double xStart = t->world_position_desired[0], yStart = t->world_position_desired[1];
+  const double *p = t->position;
+  if (xStart - p[0] > max_pos_error) xStart = p[0] + max_pos_error;
+  if (p[0] - xStart > max_pos_error) xStart = p[0] - max_pos_error;
+  if (yStart - p[1] > max_pos_error) yStart = p[1] + max_pos_error;
+  if (p[1] - yStart > max_pos_error) yStart = p[1] - max_pos_error;
+  wpd_out[0] = xStart, wpd_out[1] = yStart;
+  double trajInitial[12] = {t->roll_des, t->pitch_des, 0.0, xStart, yStart, 0.55, 0, 0, t->yaw_rate_des, vdw[0], vdw[1], 0};
+  double *trajAll = (double *)malloc(sizeof(double) * 12 * h);
+  for (int i = 0; i < h; ++i) {
+    for (int j = 0; j < 12; ++j) trajAll[12 * i + j] = trajInitial[j];
+    if (i == 0) {
+      /* the reference writes indices 0..5 of the WHOLE array here (trajAll[0..5]), i.e. step 0 */
+      trajAll[0] = t->rpy[0], trajAll[1] = t->rpy[1], trajAll[2] = t->rpy[2];
+      trajAll[3] = p[0], trajAll[4] = p[1], trajAll[5] = p[2];
+    } else {
+      if (vdw[0] == 0) trajAll[12 * i + 3] = trajInitial[3] + i * dtMPC * vdw[0];
+      else trajAll[12 * i + 3] = p[0] + i * dtMPC * vdw[0];
+      if (vdw[1] == 0) trajAll[12 * i + 4] = trajInitial[4] + i * dtMPC * vdw[1];
+      else trajAll[12 * i + 4] = p[1] + i * dtMPC * vdw[1];
+      if (t->yaw_rate_des == 0) trajAll[12 * i + 2] = trajInitial[2];
+      else trajAll[12 * i + 2] = yaw + i * dtMPC * t->yaw_rate_des;
+    }
+  }
+  int *table = (int *)malloc(sizeof(int) * 2 * h);
+  orc_mpc_gait(h, t->gait_offsets, t->gait_durations, t->gait_iteration, table);
+  /* narrowing + packing */
+  const int stride = ((54 + 12 * h) * 4 + 2 * h + 15) / 16 * 16;
+  memset(record, 0, stride);
+  float *f = (float *)record;
+  for (int i = 0; i < 3; ++i) f[i] = (float)p[i], f[3 + i] = (float)t->vWorld[i], f[10 + i] = (float)t->omegaWorld[i];
+  for (int i = 0; i < 4; ++i) f[6 + i] = (float)t->orientation[i];
+  for (int i = 0; i < 6; ++i) f[13 + i] = (float)r[i];
+  for (int i = 0; i < 10; ++i) f[19 + i] = (float)q[i];
+  f[29] = (float)yaw;
+  for (int i = 0; i < 12; ++i) f[30 + i] = (float)Q[i], f[42 + i] = (float)Alpha[i];
+  for (int i = 0; i < 12 * h; ++i) f[54 + i] = (float)trajAll[i];
+  unsigned char *g = record + 4 * (54 + 12 * h);
+  for (int i = 0; i < 2 * h; ++i) g[i] = (unsigned char)table[i];
+  free(trajAll);
+  free(table);
+}
+
+/* ConvexMPCLocomotion.cpp:419-440: GRF_R = -rBody*GRF, GRM_R = -rBody*GRM, f = [GRF_R; GRM_R] per leg */
+void orc_body_wrench(const double *sol, const double *rBody, double *f_ff) {
+  for (int leg = 0; leg < 2; ++leg) {
+    double GRF[3], GRM[3];
+    for (int axis = 0; axis < 3; ++axis) GRF[axis] = sol[leg * 3 + axis], GRM[axis] = sol[leg * 3 + axis + 6];
+    for (int i = 0; i < 3; ++i) {
+      f_ff[6 * leg + i] = ((-rBody[3 * i + 0]) * GRF[0] + (-rBody[3 * i + 1]) * GRF[1]) + (-rBody[3 * i + 2]) * GRF[2];
+      f_ff[6 * leg + 3 + i] = ((-rBody[3 * i + 0]) * GRM[0] + (-rBody[3 * i + 1]) * GRM[1]) + (-rBody[3 * i + 2]) * GRM[2];
+    }
+  }
+}

@@ -102,6 +102,30 @@ void orc_unpack_record(const unsigned char *rec, int horizon, orc_update_t *u);
 int orc_solve_records(const unsigned char *records, int stride, int first, int count, int horizon, float dt,
                       float f_max, double *q_soln, int *nwsr_out, double *obj_out, double *t_assemble, double *t_solve);
 
+
+/* ---- the caller-side code either side of the solve ----
+ * f1  updateMPCIfNeeded input builder, ConvexMPC/ConvexMPCLocomotion.cpp:283-406 (+ narrowing of
+ *     convexMPC_interface.cpp:83-103) -> one packed record;  f2  Gait::mpc_gait, ConvexMPC/GaitGenerator.cpp:85-103;
+ * f3  body-frame feed-forward wrench f_ff[leg] = -rBody [GRF; GRM], ConvexMPCLocomotion.cpp:419-440.
+ * All binary64, evaluated in the order written there. */
+typedef struct {
+  double position[3], vWorld[3], omegaWorld[3], orientation[4], rpy[3];
+  double rBody[9];        /* row-major, world -> body */
+  double leg_q[10];       /* raw joint angles, left 0-4, right 5-9 */
+  double pFoot[6];        /* world foot positions, [leg][axis] */
+  double v_des_robot[2];  /* stateDes[6], stateDes[7] */
+  double yaw_rate_des;    /* stateDes[11] */
+  double roll_des, pitch_des; /* stateDes[3], stateDes[4] */
+  double world_position_desired[2];
+  int gait_offsets[2], gait_durations[2], gait_iteration, pad;
+} orc_tick_t;
+
+void orc_mpc_gait(int n_segments, const int offsets[2], const int durations[2], int iteration, int *table /*[2n]*/);
+/* builds the packed record (layout: hector_simulation_amd/records.py) and the clamped world_position_desired */
+void orc_build_record(const orc_tick_t *t, int horizon, double dtMPC, unsigned char *record, double wpd_out[2]);
+/* q_soln (>= 12 doubles) + rBody -> f_ff[2][6] */
+void orc_body_wrench(const double *q_soln, const double *rBody, double *f_ff);
+
 /* provided by oracle/_ref/libqpoases_ref.so (oracle/qpoases_shim.cpp, built from the reference's own sources) */
 int ref_qpoases_solve(int nV, int nC, const double *H, const double *g, const double *A, const double *lbA,
                       const double *ubA, int nWSR_max, double *x, double *y, double *obj, int *nWSR_used);

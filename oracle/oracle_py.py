@@ -49,6 +49,15 @@ class Red(C.Structure):
                 ("lb", C.POINTER(C.c_double)), ("ub", C.POINTER(C.c_double))]
 
 
+class Tick(C.Structure):
+    _fields_ = [("position", C.c_double * 3), ("vWorld", C.c_double * 3), ("omegaWorld", C.c_double * 3),
+                ("orientation", C.c_double * 4), ("rpy", C.c_double * 3), ("rBody", C.c_double * 9),
+                ("leg_q", C.c_double * 10), ("pFoot", C.c_double * 6), ("v_des_robot", C.c_double * 2),
+                ("yaw_rate_des", C.c_double), ("roll_des", C.c_double), ("pitch_des", C.c_double),
+                ("world_position_desired", C.c_double * 2), ("gait_offsets", C.c_int * 2),
+                ("gait_durations", C.c_int * 2), ("gait_iteration", C.c_int), ("pad", C.c_int)]
+
+
 _lib = None
 
 
@@ -80,6 +89,9 @@ def lib():
         L.orc_solve_records.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_unpack_record.argtypes = [C.c_void_p, C.c_int, C.POINTER(Update)]
+        L.orc_mpc_gait.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_build_record.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        L.orc_body_wrench.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_qpoases_solve.restype = C.c_int
         L.ref_qpoases_solve.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 4
         _lib = L
@@ -177,3 +189,35 @@ def legacy_tick(fields_row: dict, horizon: int, dt: float, mu: float, f_max: flo
     L.orc_update_problem_data(*[a.ctypes.data for a in arrs], float(np.asarray(fields_row["yaw"]).reshape(-1)[0]),
                               *[a.ctypes.data for a in tail], gait.ctypes.data)
     return np.array([L.orc_get_solution(i) for i in range(12 * horizon)])
+
+
+# ---- input builder (f1), gait table (f2), body-frame wrench (f3)
+def mpc_gait(n_segments: int, offsets, durations, iteration: int) -> np.ndarray:
+    off = np.ascontiguousarray(offsets, dtype=np.int32)
+    dur = np.ascontiguousarray(durations, dtype=np.int32)
+    out = np.zeros(2 * n_segments, dtype=np.int32)
+    lib().orc_mpc_gait(n_segments, off.ctypes.data, dur.ctypes.data, int(iteration), out.ctypes.data)
+    return out
+
+
+def build_records(ticks: np.ndarray, horizon: int, dt_mpc: float):
+    """ticks: structured array laid out as struct orc_tick_t (= hmpc_tick_inputs).  Returns (records, wpd)."""
+    ticks = np.ascontiguousarray(ticks)
+    assert ticks.dtype.itemsize == C.sizeof(Tick)
+    stride = ((54 + 12 * horizon) * 4 + 2 * horizon + 15) // 16 * 16
+    rec = np.zeros((ticks.shape[0], stride), dtype=np.uint8)
+    wpd = np.zeros((ticks.shape[0], 2), dtype=np.float64)
+    L = lib()
+    for k in range(ticks.shape[0]):
+        L.orc_build_record(ticks[k:k + 1].ctypes.data, horizon, float(dt_mpc), rec[k].ctypes.data, wpd[k].ctypes.data)
+    return rec, wpd
+
+
+def body_wrench(q_soln: np.ndarray, rBody: np.ndarray) -> np.ndarray:
+    q = np.ascontiguousarray(q_soln, dtype=np.float64)
+    rb = np.ascontiguousarray(rBody, dtype=np.float64).reshape(q.shape[0], 9)
+    out = np.zeros((q.shape[0], 2, 6), dtype=np.float64)
+    L = lib()
+    for k in range(q.shape[0]):
+        L.orc_body_wrench(q[k].ctypes.data, rb[k].ctypes.data, out[k].ctypes.data)
+    return out
