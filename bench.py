@@ -74,6 +74,58 @@ def cpu_baseline(rec: np.ndarray, horizon: int, per_core: int) -> dict:
                 n_failed=sum(r["n_bad"] for r in res), wall_s=wall)
 
 
+def bench_builder(args, torch, local_rank) -> None:
+    """Rows f1-f3 on their own: device-side record builder and body-frame wrench kernels.  Streaming
+    kernels: algorithmic bytes = 408 B tick in + 720 B record out (+16 B) and 480+72 B in / 96 B out per instance."""
+    import ctypes as C
+
+    from hector_simulation_amd import interface, synthetic
+
+    h, B = args.horizon, args.batch
+    dev = torch.device("cuda", local_rank)
+    ticks = synthetic.make_ticks(B, h, "walking", seed=11)
+    d_ticks = torch.from_numpy(ticks.view(np.uint8).reshape(B, -1)).to(dev)
+    d_wpd = torch.zeros((B, 2), dtype=torch.float64, device=dev)
+    d_rb = torch.from_numpy(np.ascontiguousarray(ticks["rBody"])).to(dev)
+    d_fff = torch.zeros((B, 12), dtype=torch.float64, device=dev)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, B, device=local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    L = mpc.L
+
+    def step():
+        interface._check(L.hmpc_build_records_device(mpc.h, C.c_void_p(d_ticks.data_ptr()), B, synthetic.DT_MPC,
+                                                     C.c_void_p(d_wpd.data_ptr()), C.c_void_p(stream)), "build")
+        interface._check(L.hmpc_body_wrench_device(mpc.h, C.c_void_p(d_rb.data_ptr()), C.c_void_p(d_fff.data_ptr()),
+                                                   C.c_void_p(stream)), "wrench")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kms = e0.elapsed_time(e1) / args.steps
+    stride = mpc.stride
+    bytes_per = 408 + stride + 16 + 48 * h + 72 + 96
+    out = {"metric": "MPC tick records built + wrenches rotated per second (rows f1-f3)", "value": B * args.steps / elapsed,
+           "unit": "instances/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"updateMPCIfNeeded input builder + gait table + body-frame wrench, horizon {h}",
+                      "batch_per_gpu": B},
+           "roofline": {"bound": "hbm", "achieved": B * bytes_per / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": B * bytes_per / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "build_records_kernel + body_wrench_kernel", "kernel_ms": kms,
+                        "algorithmic_bytes_per_instance": bytes_per}}
+    print(json.dumps(out), flush=True)
+    mpc.close()
+
+
 def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
@@ -87,6 +139,8 @@ def main() -> None:
     ap.add_argument("--gait", default="standing", help="standing = the metric's 2-contact case")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-per-core", type=int, default=384)
+    ap.add_argument("--path", default="solve", choices=["solve", "builder"],
+                    help="solve = the metric (default); builder = rows f1-f3 only (record builder + wrench kernels)")
     ap.add_argument("--check", type=int, default=32, help="instances checked against the oracle after the timed region")
     args = ap.parse_args()
 
@@ -109,6 +163,8 @@ def main() -> None:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     h, B = args.horizon, args.batch
+    if args.path == "builder":
+        return bench_builder(args, torch, local_rank)
     # every rank owns the contiguous shard [rank*B, (rank+1)*B) of the global batch (seed offset by rank)
     assert sharding.shard_bounds(world * B, world, rank) == (rank * B, (rank + 1) * B)
     fields = synthetic.make_batch(B, h, args.gait, seed=6 + 1000 * rank, phase="random")
