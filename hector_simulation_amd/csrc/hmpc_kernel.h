@@ -100,7 +100,7 @@ struct Smem {
   struct Sol {
     alignas(16) double x[NMAX], xu[NMAX], z[NMAX], w[NMAX];
     alignas(16) double ST[NG][NMAX];  // staged partials of the in-place mat-vec: ST[source leg-step][variable]
-    alignas(16) double piv[2][2][NMAX];  // [buffer][pivot row of the pair][column]
+    alignas(16) double piv[2][NMAX];
     double u[NMAX], d[NMAX], r[NMAX], col[NMAX];
     double redv[NW], redw[NW];
     double gamma;
@@ -599,22 +599,12 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       a[ii][jj] = v;
     }
   __syncthreads();  // every block is loaded before the solver state (which aliases the staging area) is written
-  // Pivots are taken two at a time (2x2 block sweeps): with P = {k, k+1}, D = a_PP,
-  //   a_RR -= a_RP D^-1 a_PR,  a_RP <- a_RP D^-1,  a_PR <- D^-1 a_PR,  a_PP <- -D^-1.
-  // Rows/columns in P reuse the generic two-term update with substituted multipliers (I - D^-1 on the row side, D - I on the
-  // column side), so the 6x6 block update has no special cases; only the 2x2 block itself is patched.  Half the barriers.
-  if (tid < NMAX) {
-    Q.piv[0][0][tid] = 0.0, Q.piv[0][1][tid] = 0.0;
-    Q.piv[1][0][tid] = 0.0, Q.piv[1][1][tid] = 0.0;
-  }
+  if (tid < NMAX) Q.piv[0][tid] = 0.0, Q.piv[1][tid] = 0.0;
   __syncthreads();
   if (owner && e0 == 0) {
 #pragma unroll
-    for (int jj = 0; jj < GS; ++jj) {
-      if (j0 + jj < n) Q.piv[0][0][j0 + jj] = a[0][jj];
-      if (j0 + jj < n && (!diag || jj >= 1)) Q.piv[0][1][j0 + jj] = a[1][jj];
-    }
-    if (diag) Q.piv[0][1][0] = a[0][1];
+    for (int jj = 0; jj < GS; ++jj)
+      if (j0 + jj < n) Q.piv[0][j0 + jj] = a[0][jj];
   }
   __syncthreads();
   for (int kb = 0; kb < ng; ++kb) {
@@ -623,93 +613,70 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
     const bool rown = owner && (e0 == kb + 1);  // next leg-step's row / column blocks (publish at the seam)
     const bool coln = owner && (e1 == kb + 1);
 #pragma unroll
-    for (int kk = 0; kk < GS; kk += 2) {
+    for (int kk = 0; kk < GS; ++kk) {
       const int k = kb * GS + kk;
-      const int buf = ((kb * (GS / 2) + kk / 2) & 1);
-      const double *pv1 = Q.piv[buf][0], *pv2 = Q.piv[buf][1];
-      double *pn1 = Q.piv[buf ^ 1][0], *pn2 = Q.piv[buf ^ 1][1];
-      const double d11 = pv1[k], d12 = pv1[k + 1], d22 = pv2[k + 1];
-      double p1i[GS], p2i[GS], p1j[GS], p2j[GS];
+      const double *pv = Q.piv[k & 1];
+      double *pn = Q.piv[(k + 1) & 1];
+      const double d = pv[k];
+      double pi[GS], pj[GS];
 #pragma unroll
       for (int ii = 0; ii < GS; ii += 2) {
-        const double2 t1 = *reinterpret_cast<const double2 *>(pv1 + i0 + ii);
-        const double2 t2 = *reinterpret_cast<const double2 *>(pv2 + i0 + ii);
-        const double2 u1 = *reinterpret_cast<const double2 *>(pv1 + j0 + ii);
-        const double2 u2 = *reinterpret_cast<const double2 *>(pv2 + j0 + ii);
-        p1i[ii] = t1.x, p1i[ii + 1] = t1.y, p2i[ii] = t2.x, p2i[ii + 1] = t2.y;
-        p1j[ii] = u1.x, p1j[ii + 1] = u1.y, p2j[ii] = u2.x, p2j[ii + 1] = u2.y;
+        const double2 t2 = *reinterpret_cast<const double2 *>(pv + i0 + ii);
+        pi[ii] = t2.x, pi[ii + 1] = t2.y;
       }
-      const double det = dfma(d11, d22, -(d12 * d12));
-      double idet = __builtin_amdgcn_rcp(det);  // v_rcp_f64 + two Newton steps (the solver half is not bit-pinned)
-      idet = dfma(dfma(-det, idet, 1.0), idet, idet);
-      idet = dfma(dfma(-det, idet, 1.0), idet, idet);
-      const double i11 = d22 * idet, i12 = -(d12 * idet), i22 = d11 * idet;  // D^-1
-      double q1[GS], q2[GS];
 #pragma unroll
-      for (int ii = 0; ii < GS; ++ii) {
-        q1[ii] = dfma(p2i[ii], i12, p1i[ii] * i11);
-        q2[ii] = dfma(p2i[ii], i22, p1i[ii] * i12);
+      for (int jj = 0; jj < GS; jj += 2) {
+        const double2 t2 = *reinterpret_cast<const double2 *>(pv + j0 + jj);
+        pj[jj] = t2.x, pj[jj + 1] = t2.y;
       }
-      q1[kk] = rowb ? (1.0 - i11) : q1[kk], q2[kk] = rowb ? -i12 : q2[kk];
-      q1[kk + 1] = rowb ? -i12 : q1[kk + 1], q2[kk + 1] = rowb ? (1.0 - i22) : q2[kk + 1];
-      p1j[kk] = colb ? (d11 - 1.0) : p1j[kk], p2j[kk] = colb ? d12 : p2j[kk];
-      p1j[kk + 1] = colb ? d12 : p1j[kk + 1], p2j[kk + 1] = colb ? (d22 - 1.0) : p2j[kk + 1];
+      double invd = __builtin_amdgcn_rcp(d);  // v_rcp_f64 + two Newton steps (the solver half is not bit-pinned)
+      invd = dfma(dfma(-d, invd, 1.0), invd, invd);
+      invd = dfma(dfma(-d, invd, 1.0), invd, invd);
+      double qi[GS];
+#pragma unroll
+      for (int ii = 0; ii < GS; ++ii) qi[ii] = pi[ii] * invd;
+      qi[kk] = rowb ? (1.0 - invd) : qi[kk];
+      pj[kk] = colb ? (d - 1.0) : pj[kk];
 #pragma unroll
       for (int ii = 0; ii < GS; ++ii)
 #pragma unroll
-        for (int jj = 0; jj < GS; ++jj) a[ii][jj] = dfma(-q2[ii], p2j[jj], dfma(-q1[ii], p1j[jj], a[ii][jj]));
-      if (rowb && colb) {
-        a[kk][kk] = -i11, a[kk][kk + 1] = -i12, a[kk + 1][kk] = -i12, a[kk + 1][kk + 1] = -i22;
-      }
-      // publish rows k+2, k+3 of the symmetric matrix: (r, j >= r) from the row blocks, (i < r, r) from the column blocks
-      if (kk + 2 < GS) {
+        for (int jj = 0; jj < GS; ++jj) a[ii][jj] = dfma(-qi[ii], pj[jj], a[ii][jj]);
+      a[kk][kk] = (rowb && colb) ? -invd : a[kk][kk];
+      // publish row k+1 of the symmetric matrix: (k+1, j >= k+1) from its row blocks, (i < k+1, k+1) from its column blocks
+      if (kk + 1 < GS) {
         if (rowb) {
 #pragma unroll
-          for (int jj = 0; jj < GS; ++jj) {
-            if (!diag || jj >= kk + 2) pn1[j0 + jj] = a[(kk + 2) % GS][jj];
-            if (!diag || jj >= kk + 3) pn2[j0 + jj] = a[(kk + 3) % GS][jj];
-          }
+          for (int jj = 0; jj < GS; ++jj)
+            if (!diag || jj >= kk + 1) pn[j0 + jj] = a[(kk + 1) % GS][jj];
         }
         if (colb) {
 #pragma unroll
-          for (int ii = 0; ii < GS; ++ii) {
-            if (!diag || ii < kk + 2) pn1[i0 + ii] = a[ii][(kk + 2) % GS];
-            if (!diag || ii < kk + 3) pn2[i0 + ii] = a[ii][(kk + 3) % GS];
-          }
+          for (int ii = 0; ii < GS; ++ii)
+            if (!diag || ii < kk + 1) pn[i0 + ii] = a[ii][(kk + 1) % GS];
         }
       } else if (kb + 1 < ng) {
         if (rown) {
 #pragma unroll
-          for (int jj = 0; jj < GS; ++jj) {
-            pn1[j0 + jj] = a[0][jj];
-            if (!diag || jj >= 1) pn2[j0 + jj] = a[1][jj];
-          }
-          if (diag) pn2[i0] = a[0][1];
+          for (int jj = 0; jj < GS; ++jj) pn[j0 + jj] = a[0][jj];
         }
         if (coln && !diag) {
 #pragma unroll
-          for (int ii = 0; ii < GS; ++ii) {
-            pn1[i0 + ii] = a[ii][0];
-            pn2[i0 + ii] = a[ii][1];
-          }
+          for (int ii = 0; ii < GS; ++ii) pn[i0 + ii] = a[ii][0];
         }
       }
       __syncthreads();
     }
   }
-  // M = -a.  Lower-triangle duplicates inside diagonal blocks are zeroed and the diagonal is kept aside, so the in-place
-  // products need no masks: rows use the block as is, the mirrored (column) part subtracts the diagonal term once.
-  double dg[GS];
-#pragma unroll
-  for (int jj = 0; jj < GS; ++jj) dg[jj] = 0.0;
+  // M = -a.  Diagonal blocks keep the full symmetric 6x6 (their lower triangle is overwritten with the mirror of the upper
+  // one, so both halves are bit-identical); off-diagonal blocks hold M(e0,e1) and stand for M(e1,e0) transposed.
 #pragma unroll
   for (int ii = 0; ii < GS; ++ii)
 #pragma unroll
-    for (int jj = 0; jj < GS; ++jj) {
-      const bool low = !owner || (diag && ii > jj);
-      a[ii][jj] = low ? 0.0 : -a[ii][jj];
-      if (ii == jj) dg[jj] = diag ? a[ii][jj] : 0.0;
-    }
+    for (int jj = 0; jj < GS; ++jj) a[ii][jj] = owner ? -a[ii][jj] : 0.0;
+#pragma unroll
+  for (int ii = 1; ii < GS; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < ii; ++jj) a[ii][jj] = diag ? a[jj][ii] : a[ii][jj];
   PROF_MARK(P_SWEEP);
 
   // ---- products with the register blocks --------------------------------------------------------------------------
@@ -737,14 +704,8 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       ca[jj] = s0 + s1;
     }
   };
-  // symmetric diagonal block times a 6-vector (upper triangle stored, lower zeroed, diagonal in dg)
-  auto blk_sym = [&](const double (&w)[GS], double (&out)[GS]) {
-    double ra[GS], ca[GS];
-    blk_rows(w, ra);
-    blk_cols(w, ca);
-#pragma unroll
-    for (int k = 0; k < GS; ++k) out[k] = (ra[k] + ca[k]) - dg[k] * w[k];
-  };
+  // a diagonal block is stored as the full symmetric 6x6
+  auto blk_sym = [&](const double (&w)[GS], double (&out)[GS]) { blk_rows(w, out); };
   // z = M w for a dense w in LDS (entries >= n exactly 0).  Every block writes its row partial to ST[e1][vars of e0]
   // and its mirrored partial to ST[e0][vars of e1]; variable i then sums ST[0..ng-1][i] in index order (deterministic).
   auto rmatvec = [&](const double *w) {
@@ -772,14 +733,18 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
     }
     __syncthreads();
     if (is_v) {
-      double sv[NG];
-#pragma unroll
-      for (int s = 0; s < NG; ++s) sv[s] = Q.ST[(s < ng) ? s : 0][tid];
       double s0 = 0.0, s1 = 0.0;
+      constexpr int HB = NG / 2;
 #pragma unroll
-      for (int s = 0; s < NG; s += 2) {
-        s0 += (s < ng) ? sv[s] : 0.0;
-        s1 += (s + 1 < ng) ? sv[s + 1] : 0.0;
+      for (int hb = 0; hb < 2; ++hb) {
+        double sv[HB];
+#pragma unroll
+        for (int s = 0; s < HB; ++s) sv[s] = Q.ST[(hb * HB + s < ng) ? hb * HB + s : 0][tid];
+#pragma unroll
+        for (int s = 0; s < HB; s += 2) {
+          s0 += (hb * HB + s < ng) ? sv[s] : 0.0;
+          if (s + 1 < HB) s1 += (hb * HB + s + 1 < ng) ? sv[s + 1] : 0.0;
+        }
       }
       Q.z[tid] = s0 + s1;
     }
@@ -792,12 +757,12 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
   const double INF = __builtin_huge_val();
   const double FEAS_TOL = 1e-9;
   const int c_e = tid >> 3, c_rr = tid & 7;
-  double c_cn[6] = {0, 0, 0, 0, 0, 0}, c_ub = INF, c_scale = 1.0;
+  double c_ub = INF, c_scale = 1.0;
   bool c_hasl = false, c_hasu = false;
+  const double *c_cn = S.Cn[0][0];  // this row's 6 coefficients (LDS; re-read where used: cheaper than 12 live VGPRs)
   if (is_c) {
     const int leg = S.ls_leg[c_e];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) c_cn[k] = S.Cn[leg][c_rr][k];
+    c_cn = S.Cn[leg][c_rr];
     c_hasl = (c_rr <= 4) || (c_rr == 7);  // every finite lower bound is 0 (SolverMPC.cpp:466-482)
     c_hasu = (c_rr >= 4);
     c_ub = (c_rr == 4) ? (double)0.01f : (c_rr == 7 ? S.ub7[c_e] : 0.0);
