@@ -12,7 +12,7 @@ _lib = None
 EXPORTS = [
     "setup_problem", "update_problem_data", "get_solution", "update_solver_settings", "hmpc_solve_mpc", "solveDenseMPC",
     "hmpc_get_q_soln", "hmpc_last_status", "hmpc_record_stride", "hmpc_pack_record", "hmpc_create", "hmpc_destroy",
-    "hmpc_upload_records", "hmpc_set_device_records", "hmpc_set_max_reduced_vars", "hmpc_set_warm_start", "hmpc_set_device_outputs",
+    "hmpc_upload_records", "hmpc_set_device_records", "hmpc_set_max_reduced_vars", "hmpc_set_warm_start", "hmpc_resolve_failed", "hmpc_set_auto_resolve", "hmpc_set_device_outputs",
     "hmpc_solve", "hmpc_download", "hmpc_get_device_outputs", "hmpc_batch", "hmpc_horizon", "hmpc_time_solve",
     "hmpc_build_records", "hmpc_build_records_device", "hmpc_body_wrench", "hmpc_body_wrench_device",
     "hmpc_download_records", "hmpc_debug_assemble", "hmpc_debug_phase_cycles", "hmpc_download_f64", "hmpc_last_hip_error", "hmpc_version",
@@ -78,6 +78,8 @@ def load():
     L.hmpc_set_device_records.argtypes = [vp, vp, ci]
     L.hmpc_set_max_reduced_vars.argtypes = [vp, ci]
     L.hmpc_set_warm_start.argtypes = [vp, ci]
+    L.hmpc_resolve_failed.argtypes = [vp, C.POINTER(ci)]
+    L.hmpc_set_auto_resolve.argtypes = [vp, ci]
     L.hmpc_set_device_outputs.argtypes = [vp, vp, vp]
     L.hmpc_solve.argtypes = [vp, vp]
     L.hmpc_download.argtypes = [vp, vp, vp]

@@ -34,26 +34,31 @@ thread_local std::string g_hip_err;
 typedef void (*kernel_fn)(hmpc::KernelArgs);
 
 struct Variant {
-  int nmax, hmax, nt;
+  int nmax, hmax, nt, qcap;
   kernel_fn solve, assemble;
   size_t smem;
   int dbg_floats;
 };
 
 // NMAX = reduced variables held on chip (6 per stance leg-step); 120 -> 256-thread workgroups (210 register blocks),
-// 60 (single support over h <= 10) -> 128-thread workgroups (55 blocks)
-template <int NMAX, int HMAX, int NT>
+// 60 (single support over h <= 10) -> 128-thread workgroups (55 blocks).  QCAP = working-set capacity: the fast variants
+// hold 80 rows (two workgroups per CU); the "safe" variants hold NMAX rows (can never overflow, one workgroup per CU)
+// and re-solve the few instances the fast pass flags (hmpc_resolve_failed).
+template <int NMAX, int HMAX, int NT, int QCAP>
 Variant make_variant() {
-  return Variant{NMAX, HMAX, NT, hmpc::hmpc_kernel<NMAX, HMAX, NT, false>, hmpc::hmpc_kernel<NMAX, HMAX, NT, true>,
-                 sizeof(hmpc::Smem<NMAX, HMAX, NT>), hmpc::DbgLayout<NMAX>::TOTAL};
+  return Variant{NMAX, HMAX, NT, QCAP, hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, false>,
+                 hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, true>, sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP>),
+                 hmpc::DbgLayout<NMAX>::TOTAL};
 }
 
 const Variant *variants() {
-  static const Variant v[] = {make_variant<60, 10, 128>(), make_variant<120, 10, 256>(), make_variant<60, 20, 128>(),
-                              make_variant<120, 20, 256>()};
+  static const Variant v[] = {make_variant<60, 10, 128, 60>(),   make_variant<120, 10, 256, 80>(),
+                              make_variant<60, 20, 128, 60>(),   make_variant<120, 20, 256, 80>(),
+                              make_variant<120, 10, 256, 120>(), make_variant<120, 20, 256, 120>()};
   return v;
 }
-constexpr int N_VARIANTS = 4;
+constexpr int N_FAST = 4;
+constexpr int N_VARIANTS = 6;
 
 size_t record_stride(int h) { return (size_t)(((54 + 12 * h) * 4 + 2 * h + 15) / 16 * 16); }
 
@@ -72,6 +77,7 @@ struct hmpc_handle {
   int *d_dbg_i;
   long long *d_prof;
   int warm;        // block warm start of the working set (default on)
+  int auto_resolve;  // hmpc_download re-solves flagged instances with the safe variant (default on)
   int max_stance;  // max reduced variables of the current batch (known only for host-uploaded records; else -1)
   hipStream_t last_stream;
   bool attrs_set[N_VARIANTS];
@@ -81,20 +87,26 @@ static const Variant &pick_variant(const hmpc_handle *h, int *index) {
   const Variant *v = variants();
   const int hz = h->setup.horizon;
   int best = -1;
-  for (int i = 0; i < N_VARIANTS; ++i) {
+  for (int i = 0; i < N_FAST; ++i) {
     if (v[i].hmax < hz) continue;
     if (h->max_stance >= 0 && v[i].nmax < h->max_stance) continue;
     if (h->max_stance < 0 && v[i].nmax < HMPC_MAX_VARS) continue;
     if (best < 0 || v[i].smem < v[best].smem) best = i;
   }
-  if (best < 0) best = N_VARIANTS - 1;  // oversize batches are reported per instance (HMPC_S_TOO_LARGE)
+  if (best < 0) best = N_FAST - 1;  // oversize batches are reported per instance (HMPC_S_TOO_LARGE)
   if (index) *index = best;
   return v[best];
 }
 
-static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int dbg_index) {
+static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int dbg_index, const int *d_index_list = nullptr,
+                  int n_list = 0) {
   int vi = 0;
-  const Variant &v = pick_variant(h, &vi);
+  const Variant *pv = &pick_variant(h, &vi);
+  if (d_index_list) {  // safe variant: working set as large as the variable count
+    vi = (h->setup.horizon <= 10) ? N_FAST : N_FAST + 1;
+    pv = &variants()[vi];
+  }
+  const Variant &v = *pv;
   kernel_fn fn = assemble_only ? v.assemble : v.solve;
   if (!h->attrs_set[vi]) {
     HIP_TRY(hipFuncSetAttribute((const void *)v.solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.smem));
@@ -117,7 +129,8 @@ static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int db
   a.dbg_i = h->d_dbg_i;
   a.prof = h->d_prof;
   a.warm = h->warm;
-  const int grid = assemble_only ? 1 : h->batch;
+  a.index_list = d_index_list;
+  const int grid = assemble_only ? 1 : (d_index_list ? n_list : h->batch);
   hipLaunchKernelGGL(fn, dim3(grid), dim3(v.nt), v.smem, stream, a);
   HIP_TRY(hipGetLastError());
   return HMPC_OK;
@@ -168,6 +181,7 @@ int hmpc_create(hmpc_handle **out, const struct problem_setup *setup, int max_ba
   h->stride = record_stride(setup->horizon);
   h->max_stance = -1;
   h->warm = 1;
+  h->auto_resolve = 1;
   const size_t nf = (size_t)max_batch * 12 * setup->horizon;
   if (hipMalloc(&h->d_records_own, (size_t)max_batch * h->stride) != hipSuccess ||
       hipMalloc(&h->d_forces_own, nf * sizeof(float)) != hipSuccess ||
@@ -237,6 +251,12 @@ int hmpc_set_max_reduced_vars(hmpc_handle *h, int n_reduced) {
   return HMPC_OK;
 }
 
+int hmpc_set_auto_resolve(hmpc_handle *h, int on) {
+  if (!h) return HMPC_E_ARG;
+  h->auto_resolve = on ? 1 : 0;
+  return HMPC_OK;
+}
+
 int hmpc_set_warm_start(hmpc_handle *h, int on) {
   if (!h) return HMPC_E_ARG;
   h->warm = on ? 1 : 0;
@@ -258,10 +278,41 @@ int hmpc_solve(hmpc_handle *h, void *stream) {
   return launch(h, (hipStream_t)stream, false, 0);
 }
 
+int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
+  if (!h) return HMPC_E_ARG;
+  if (n_resolved) *n_resolved = 0;
+  if (h->batch == 0) return HMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
+  std::vector<uint32_t> st(h->batch);
+  HIP_TRY(hipMemcpy(st.data(), h->d_status, (size_t)h->batch * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  std::vector<int> idx;
+  for (int i = 0; i < h->batch; ++i) {
+    const uint32_t c = HMPC_STATUS_CODE(st[i]);
+    if (c == HMPC_S_WORKSET || c == HMPC_S_MAXITER || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT) idx.push_back(i);
+  }
+  if (idx.empty()) return HMPC_OK;
+  int *d_idx = nullptr;
+  HIP_TRY(hipMalloc(&d_idx, idx.size() * sizeof(int)));
+  HIP_TRY(hipMemcpy(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+  const int warm = h->warm;
+  h->warm = 0;  // the safe pass starts cold, as the reference does
+  int rc = launch(h, h->last_stream, false, 0, d_idx, (int)idx.size());
+  h->warm = warm;
+  if (rc == HMPC_OK) HIP_TRY(hipStreamSynchronize(h->last_stream));
+  hipFree(d_idx);
+  if (n_resolved) *n_resolved = (int)idx.size();
+  return rc;
+}
+
 int hmpc_download(hmpc_handle *h, float *forces, uint32_t *status) {
   if (!h) return HMPC_E_ARG;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->last_stream));
+  if (h->auto_resolve) {
+    int rc = hmpc_resolve_failed(h, nullptr);
+    if (rc != HMPC_OK) return rc;
+  }
   const size_t nf = (size_t)h->batch * 12 * h->setup.horizon;
   if (forces && nf) HIP_TRY(hipMemcpy(forces, h->d_forces, nf * sizeof(float), hipMemcpyDeviceToHost));
   if (status && h->batch)

@@ -38,6 +38,7 @@ struct KernelArgs {
   float *dbg_f;
   int *dbg_i;
   long long *prof;  // optional [batch][NPROF] per-phase shader-clock cycles (thread 0's view), profiling builds only
+  const int *index_list;  // optional: workgroup b solves instance index_list[b] (re-solve of flagged instances)
   int warm;         // 1: block warm start of the working set (default), 0: cold start as the reference does
 };
 constexpr int NPROF = 24;
@@ -63,12 +64,12 @@ enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT =
 
 constexpr int GS = 6;  // variables per stance leg-step: force (3) then moment (3)
 
-template <int NMAX, int HMAX, int NT>
+template <int NMAX, int HMAX, int NT, int QCAP>
 struct Smem {
   static constexpr int NG = NMAX / GS;   // leg-steps (blocks per matrix side)
   static constexpr int MMAX = NG * 8;    // constraint rows
   static constexpr int NW = NT / 64;
-  static constexpr int QMAX = (NMAX >= 120) ? 80 : NMAX;  // working-set capacity (packed Schur inverse)
+  static constexpr int QMAX = QCAP;      // working-set capacity (packed Schur inverse); QCAP = NMAX can never overflow
   static constexpr int RECW = ((54 + 12 * HMAX) * 4 + 2 * HMAX + 15) / 16 * 4;  // record words
 
   double g[NMAX];        // gradient, sweep order
@@ -182,9 +183,9 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int NMAX, int HMAX, int NT, bool ASM_ONLY>
+template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY>
 __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
-  using SM = Smem<NMAX, HMAX, NT>;
+  using SM = Smem<NMAX, HMAX, NT, QCAP>;
   constexpr int NG = SM::NG, NW = SM::NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SM &S = *reinterpret_cast<SM *>(smem_raw);
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
   auto &Q = S.u.s;
 
   const int tid = threadIdx.x, wv = uni(tid >> 6), ln = tid & 63;
-  const int inst = ASM_ONLY ? args.dbg_index : (int)blockIdx.x;
+  const int inst = ASM_ONLY ? args.dbg_index : (args.index_list ? args.index_list[blockIdx.x] : (int)blockIdx.x);
   const int h = args.horizon;
   if (inst >= args.batch) return;
   PROF_DECL;
@@ -788,6 +789,7 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
 
   int q = 0, iters = 0, code = S_OK;
   const int itmax = 4 * m + 16;
+  bool c_ignored = false;  // this thread's row was found redundant at a degenerate vertex (violated by round-off only)
 
   // slack of this thread's constraint row on its tighter side at xv (unit-scaled); side = +1 lower, -1 upper
   auto my_slack = [&](const double *xv, int &side, double &raw) -> double {
@@ -1074,7 +1076,7 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       // (1) most violated constraint; the winning lane of each wave also publishes its constants
       double val = INF, raw = INF;
       int side = 1;
-      if (is_c && Q.act[tid] == 0) val = my_slack(Q.x, side, raw);
+      if (is_c && !c_ignored && Q.act[tid] == 0) val = my_slack(Q.x, side, raw);
       {
         const double wmin = wave_min(val);
         const unsigned long long bal = __ballot(val == wmin);
@@ -1192,7 +1194,11 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
         const double t2 = dep ? INF : -sp / delta;
         const double t = (t1 < t2) ? t1 : t2;
         if (ub(t == INF)) {
-          code = S_INFEASIBLE;
+          // Row p is (numerically) a combination of the working set and no multiplier can absorb it.  F = M = 0 satisfies
+          // every row of this QP, so the problem is never infeasible: the event only occurs at degenerate vertices, for a
+          // redundant row violated by accumulated round-off.  The row is set aside and the iteration goes on; the final
+          // KKT check (which looks at every row again, relative to the force scale) decides the status.
+          if (tid == p) c_ignored = true;
           break;
         }
         if (!dep && is_v) Q.x[tid] = dfma(t, Q.z[tid], Q.x[tid]);
@@ -1263,7 +1269,7 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
   {
     double val = INF, raw;
     int side;
-    if (is_c && Q.act[tid] == 0) val = my_slack(Q.x, side, raw);
+    if (is_c && Q.act[tid] == 0) val = my_slack(Q.x, side, raw);  // set-aside rows are checked again here
     double umin = (tid < q) ? Q.u[tid] : INF;
     val = wave_min(val);
     umin = wave_min(umin);
@@ -1274,7 +1280,15 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       val = (Q.redv[w] < val) ? Q.redv[w] : val;
       umin = (Q.redw[w] < umin) ? Q.redw[w] : umin;
     }
-    if (code == S_OK && (val < -1e-6 || umin < -1e-6)) code = S_KKT;
+    __syncthreads();
+    const double xm = wave_min(is_v ? -__builtin_fabs(Q.x[tid]) : 0.0);
+    if (ln == 0) Q.redw[wv] = xm;
+    __syncthreads();
+    double xmax = 1.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) xmax = (-Q.redw[w] > xmax) ? -Q.redw[w] : xmax;
+    constexpr double KKT_TOL = (QCAP >= NMAX && NMAX >= 120) ? 2e-5 : 2e-6;
+    if (code == S_OK && (val < -KKT_TOL * xmax || umin < -1e-6 * xmax)) code = S_KKT;  // relative to the force scale
   }
 
   // ---------------- output: scatter to the reference's 12h layout, eliminated variables exactly 0 (SolverMPC.cpp:720-732)

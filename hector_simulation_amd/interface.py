@@ -106,6 +106,14 @@ class BatchedMPC:
     def set_warm_start(self, on: bool) -> None:
         _check(self.L.hmpc_set_warm_start(self.h, 1 if on else 0), "hmpc_set_warm_start")
 
+    def set_auto_resolve(self, on: bool) -> None:
+        _check(self.L.hmpc_set_auto_resolve(self.h, 1 if on else 0), "hmpc_set_auto_resolve")
+
+    def resolve_failed(self) -> int:
+        n = C.c_int(0)
+        _check(self.L.hmpc_resolve_failed(self.h, C.byref(n)), "hmpc_resolve_failed")
+        return int(n.value)
+
     def solve(self, stream: int = 0) -> None:
         _check(self.L.hmpc_solve(self.h, C.c_void_p(stream)), "hmpc_solve")
 

@@ -123,6 +123,12 @@ int hmpc_set_max_reduced_vars(hmpc_handle *h, int n_reduced);
  * unconstrained minimiser enters at once (block warm start); on = 0: cold start from the empty set, one row per
  * iteration, as the reference's qpOASES call does.  Same optimum either way (strictly convex QP). */
 int hmpc_set_warm_start(hmpc_handle *h, int on);
+/* Safe pass: waits for the last solve, then re-solves every instance whose status is working-set-full / max-iter /
+ * infeasible / KKT with the large-working-set kernel variant (capacity = number of variables: cannot overflow; cold
+ * start) and overwrites its forces and status in place.  *n_resolved (may be NULL) = how many were re-solved.
+ * hmpc_download does this automatically unless hmpc_set_auto_resolve(h, 0). */
+int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved);
+int hmpc_set_auto_resolve(hmpc_handle *h, int on);
 int hmpc_get_device_outputs(hmpc_handle *h, float **device_forces, uint32_t **device_status);
 int hmpc_batch(const hmpc_handle *h);
 int hmpc_horizon(const hmpc_handle *h);

@@ -1,0 +1,49 @@
+"""Robustness outside the nominal input distribution: 3x the SURVEY 8d ranges must solve 100 %; at 6x (roll/pitch up
+to 0.6 rad, 3 rad/s body rates: far outside what the controller lets happen) working sets outgrow the fast kernel's 80
+rows -> the safe pass (hmpc_resolve_failed, capacity = variable count, cold start) must pick those up, and whatever is
+left must be FLAGGED, never silently wrong."""
+import numpy as np
+import pytest
+
+from hector_simulation_amd import interface, records, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def hard_batch(nb, h, gait, seed, scale):
+    f = synthetic.make_batch(nb, h, gait, seed=seed, phase="random", yaw_rate_cmd=True)
+    rng = np.random.default_rng(seed + 1)
+    rpy = rng.uniform(-0.1 * scale, 0.1 * scale, (nb, 3))
+    f["q"] = synthetic.quat_from_rpy(rpy[:, 0], rpy[:, 1], rpy[:, 2])
+    f["v"] = rng.uniform(-0.3 * scale, 0.3 * scale, (nb, 3))
+    f["w"] = rng.uniform(-0.5 * scale, 0.5 * scale, (nb, 3))
+    f["joint_angles"] = rng.uniform(-0.15 * scale, 0.15 * scale, (nb, 10))
+    tr = f["traj"].reshape(nb, h, 12)
+    tr[:, :, 9] *= scale
+    f["traj"] = tr.reshape(nb, -1)
+    return f
+
+
+@pytest.mark.parametrize("gait,h,scale,min_ok", [("standing", 10, 3, 1.0), ("walking", 10, 3, 1.0), ("single", 20, 3, 1.0),
+                                                  ("standing", 10, 6, 0.97), ("single", 20, 6, 0.97)])
+def test_hard_inputs(oracle, gait, h, scale, min_ok):
+    nb = 192
+    rec = records.pack_records(hard_batch(nb, h, gait, 17, scale), h)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb)
+    mpc.set_auto_resolve(False)
+    mpc.upload(rec)
+    mpc.solve()
+    _, st_fast = mpc.download()
+    n_flagged = int((interface.status_code(st_fast) != 0).sum())
+    assert mpc.resolve_failed() == n_flagged
+    forces, status = mpc.download()
+    mpc.close()
+    ok = interface.status_code(status) == 0
+    assert ok.mean() >= min_ok, (ok.mean(), np.unique(interface.status_code(status), return_counts=True))
+    if scale >= 6:
+        assert n_flagged > 0  # the regime really exercises the safe pass
+        assert (interface.status_code(status) != 5).all()  # ... which cannot run out of working-set room
+    ref = oracle.solve_records(rec, h, synthetic.DT_MPC, synthetic.F_MAX)
+    q = ref["q_soln"]
+    err = np.abs(forces - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+    assert ref["n_bad"] == 0 and err[ok].max() < 1e-4  # everything reported ok matches qpOASES
