@@ -14,7 +14,7 @@ EXPORTS = [
     "hmpc_get_q_soln", "hmpc_last_status", "hmpc_record_stride", "hmpc_pack_record", "hmpc_create", "hmpc_destroy",
     "hmpc_upload_records", "hmpc_set_device_records", "hmpc_set_max_reduced_vars", "hmpc_set_warm_start", "hmpc_resolve_failed", "hmpc_set_auto_resolve", "hmpc_set_device_outputs",
     "hmpc_solve", "hmpc_download", "hmpc_get_device_outputs", "hmpc_batch", "hmpc_horizon", "hmpc_time_solve",
-    "hmpc_build_records", "hmpc_build_records_device", "hmpc_body_wrench", "hmpc_body_wrench_device",
+    "hmpc_build_records", "hmpc_build_records_device", "hmpc_body_wrench", "hmpc_body_wrench_device", "hmpc_leg_torques", "hmpc_leg_torques_device",
     "hmpc_download_records", "hmpc_debug_assemble", "hmpc_debug_phase_cycles", "hmpc_download_f64", "hmpc_last_hip_error", "hmpc_version",
 ]
 
@@ -94,6 +94,8 @@ def load():
     L.hmpc_body_wrench.argtypes = [vp, vp, vp]
     L.hmpc_body_wrench_device.argtypes = [vp, vp, vp, vp]
     L.hmpc_download_records.argtypes = [vp, vp]
+    L.hmpc_leg_torques.argtypes = [vp, vp, vp, vp, vp]
+    L.hmpc_leg_torques_device.argtypes = [vp, vp, vp, vp, vp, vp]
     L.hmpc_debug_phase_cycles.argtypes = [vp, vp]
     L.hmpc_last_hip_error.restype = C.c_char_p
     L.hmpc_version.restype = C.c_char_p

@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "../../include/hector_mpc.h"
+#include "hmpc_math.h"
 
 namespace hmpc {
 
@@ -121,6 +122,79 @@ __global__ __launch_bounds__(256) void body_wrench_kernel(const float *forces, i
   const double *R = rBody + (size_t)inst * 9 + 3 * i;
   const double v0 = (double)sol[base], v1 = (double)sol[base + 1], v2 = (double)sol[base + 2];
   f_ff[g] = ((-R[0]) * v0 + (-R[1]) * v1) + (-R[2]) * v2;
+}
+
+// thread g -> (instance g/2, leg g%2): body-frame wrench of that leg, force-moment Jacobian of the leg
+// (common/LegController.cpp:108-167, repeated factors named) and tau = J' f (LegController.cpp:57-61)
+__global__ __launch_bounds__(256) void leg_torque_kernel(const float *forces, int batch, int h, const double *rBody,
+                                                         const double *leg_q, double *f_ff, double *tau) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= 2 * batch) return;
+  const int inst = g >> 1, leg = g & 1;
+  const float *sol = forces + (size_t)inst * 12 * h;
+  const double *R = rBody + (size_t)inst * 9;
+  double f[6];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int base = leg * 3 + 6 * half;
+    const double v0 = (double)sol[base], v1 = (double)sol[base + 1], v2 = (double)sol[base + 2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) f[3 * half + i] = ((-R[3 * i]) * v0 + (-R[3 * i + 1]) * v1) + (-R[3 * i + 2]) * v2;
+  }
+  if (f_ff) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) f_ff[(size_t)inst * 12 + 6 * leg + i] = f[i];
+  }
+  const double *q = leg_q + (size_t)inst * 10 + 5 * leg;
+  const double q0 = q[0], q1 = q[1];
+  const double q2 = q[2] + 0.3 * 3.14159, q3 = q[3] - 0.6 * 3.14159, q4 = q[4] + 0.3 * 3.14159;
+  const double side = (leg == 0) ? 1.0 : -1.0;
+  double s0, c0, s1, c1, s2, c2, s23, c23, s234, c234;
+  det_sincos(q0, s0, c0);
+  det_sincos(q1, s1, c1);
+  det_sincos(q2, s2, c2);
+  det_sincos(q2 + q3, s23, c23);
+  det_sincos(q2 + q3 + q4, s234, c234);
+  const double Ls = 0.04 * s234 + 0.22 * s23 + 0.22 * s2, Lc = 0.04 * c234 + 0.22 * c23 + 0.22 * c2;
+  const double Ls3 = 0.04 * s234 + 0.22 * s23, Lc3 = 0.04 * c234 + 0.22 * c23;
+  const double k1 = 0.018 * side + 0.0025, k0 = 0.015 * side;
+  const double hip = k0 + c1 * k1 - 1.0 * s1 * Lc;
+  const double lat = s1 * k1 + c1 * Lc;
+  double J[6][5];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) J[r][c] = 0.0;
+  J[0][0] = s0 * (Ls + 0.0135) + c0 * hip;
+  J[1][0] = s0 * hip - 1.0 * c0 * (Ls + 0.0135);
+  J[5][0] = 1.0;
+  J[0][1] = -1.0 * s0 * lat;
+  J[1][1] = c0 * lat;
+  J[2][1] = s1 * Lc - 1.0 * c1 * k1;
+  J[3][1] = c0;
+  J[4][1] = s0;
+  J[0][2] = s0 * s1 * Ls - 1.0 * c0 * Lc;
+  J[1][2] = -1.0 * s0 * Lc - 1.0 * c0 * s1 * Ls;
+  J[2][2] = c1 * Ls;
+  J[0][3] = s0 * s1 * Ls3 - 1.0 * c0 * Lc3;
+  J[1][3] = -1.0 * s0 * Lc3 - 1.0 * c0 * s1 * Ls3;
+  J[2][3] = c1 * Ls3;
+  J[0][4] = 0.04 * s234 * s0 * s1 - 0.04 * c234 * c0;
+  J[1][4] = -0.04 * c234 * s0 - 0.04 * s234 * c0 * s1;
+  J[2][4] = 0.04 * s234 * c1;
+#pragma unroll
+  for (int c = 2; c < 5; ++c) {
+    J[3][c] = -c1 * s0;
+    J[4][c] = c0 * c1;
+    J[5][c] = s1;
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc = acc + J[i][j] * f[i];
+    tau[(size_t)inst * 10 + 5 * leg + j] = acc;
+  }
 }
 
 }  // namespace hmpc

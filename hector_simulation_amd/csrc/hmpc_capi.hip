@@ -483,6 +483,41 @@ int hmpc_body_wrench(hmpc_handle *h, const double *host_rBody, double *host_f_ff
   return rc;
 }
 
+int hmpc_leg_torques_device(hmpc_handle *h, const double *device_rBody, const double *device_leg_q, double *device_f_ff,
+                            double *device_tau, void *stream) {
+  if (!h || !device_rBody || !device_leg_q || !device_tau) return HMPC_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->batch > 0) {
+    const int total = 2 * h->batch;
+    hipLaunchKernelGGL(hmpc::leg_torque_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->d_forces,
+                       h->batch, h->setup.horizon, device_rBody, device_leg_q, device_f_ff, device_tau);
+    HIP_TRY(hipGetLastError());
+  }
+  return HMPC_OK;
+}
+
+int hmpc_leg_torques(hmpc_handle *h, const double *host_rBody, const double *host_leg_q, double *host_f_ff, double *host_tau) {
+  if (!h || !host_rBody || !host_leg_q || !host_tau) return HMPC_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t b = (size_t)(h->batch > 0 ? h->batch : 1), nb = (size_t)h->batch;
+  double *d_r = nullptr, *d_q = nullptr, *d_f = nullptr, *d_t = nullptr;
+  HIP_TRY(hipMalloc(&d_r, sizeof(double) * 9 * b));
+  HIP_TRY(hipMalloc(&d_q, sizeof(double) * 10 * b));
+  HIP_TRY(hipMalloc(&d_f, sizeof(double) * 12 * b));
+  HIP_TRY(hipMalloc(&d_t, sizeof(double) * 10 * b));
+  HIP_TRY(hipMemcpy(d_r, host_rBody, sizeof(double) * 9 * nb, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_q, host_leg_q, sizeof(double) * 10 * nb, hipMemcpyHostToDevice));
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
+  int rc = hmpc_leg_torques_device(h, d_r, d_q, d_f, d_t, nullptr);
+  if (rc == HMPC_OK) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (host_f_ff) HIP_TRY(hipMemcpy(host_f_ff, d_f, sizeof(double) * 12 * nb, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host_tau, d_t, sizeof(double) * 10 * nb, hipMemcpyDeviceToHost));
+  }
+  hipFree(d_r), hipFree(d_q), hipFree(d_f), hipFree(d_t);
+  return rc;
+}
+
 int hmpc_download_records(hmpc_handle *h, void *host_records) {
   if (!h || !host_records) return HMPC_E_ARG;
   HIP_TRY(hipSetDevice(h->device));

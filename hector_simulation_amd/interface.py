@@ -153,6 +153,16 @@ class BatchedMPC:
         _check(self.L.hmpc_body_wrench(self.h, rb.ctypes.data, out.ctypes.data), "hmpc_body_wrench")
         return out
 
+    def leg_torques(self, rBody: np.ndarray, leg_q: np.ndarray):
+        """f3 with torques: returns (f_ff[batch,2,6], tau[batch,2,5]) from the last solve's forces."""
+        rb = np.ascontiguousarray(rBody, dtype=np.float64).reshape(self.batch, 9)
+        lq = np.ascontiguousarray(leg_q, dtype=np.float64).reshape(self.batch, 10)
+        fff = np.zeros((self.batch, 2, 6), dtype=np.float64)
+        tau = np.zeros((self.batch, 2, 5), dtype=np.float64)
+        _check(self.L.hmpc_leg_torques(self.h, rb.ctypes.data, lq.ctypes.data, fff.ctypes.data, tau.ctypes.data),
+               "hmpc_leg_torques")
+        return fff, tau
+
     def time_solve(self, reps: int, stream: int = 0) -> float:
         ms = C.c_float(0)
         _check(self.L.hmpc_time_solve(self.h, C.c_void_p(stream), int(reps), C.byref(ms)), "hmpc_time_solve")

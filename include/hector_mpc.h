@@ -161,6 +161,11 @@ int hmpc_build_records_device(hmpc_handle *h, const void *device_ticks, int batc
 /* f3: f_ff[batch][2][6] = -rBody [GRF; GRM] from the forces of the last solve (ConvexMPCLocomotion.cpp:419-440) */
 int hmpc_body_wrench(hmpc_handle *h, const double *host_rBody, double *host_f_ff);
 int hmpc_body_wrench_device(hmpc_handle *h, const double *device_rBody, double *device_f_ff, void *stream);
+/* f3, with the joint torques: f_ff as above, then tau[batch][2][5] = J_fm' f_ff with the force-moment Jacobian of
+ * common/LegController.cpp:108-167 evaluated at leg_q[batch][10] (LegController.cpp:57-61).  f_ff may be NULL. */
+int hmpc_leg_torques(hmpc_handle *h, const double *host_rBody, const double *host_leg_q, double *host_f_ff, double *host_tau);
+int hmpc_leg_torques_device(hmpc_handle *h, const double *device_rBody, const double *device_leg_q, double *device_f_ff,
+                            double *device_tau, void *stream);
 /* copies the current batch's packed records device -> host (parity hook for f1/f2) */
 int hmpc_download_records(hmpc_handle *h, void *host_records);
 

@@ -691,3 +691,63 @@ void orc_body_wrench(const double *sol, const double *rBody, double *f_ff) {
     }
   }
 }
+
+
+/* LegController.cpp:108-167 computeLegJacobianAndPosition (force-moment Jacobian only) and :57-61 legtau = J' f.
+ * The reference's expression is written here with its repeated factors named (Ls = 0.04 s234 + 0.22 s23 + 0.22 s2, ...);
+ * sin/cos through the deterministic routines above (binary64, not narrowed).  Note the 3.14159 (not 3.14159265359)
+ * in the offsets, as in the reference. */
+void orc_leg_jacobian(const double q_in[5], int leg, double J[30] /* row-major 6x5 */) {
+  const double q0 = q_in[0], q1 = q_in[1];
+  const double q2 = q_in[2] + 0.3 * 3.14159, q3 = q_in[3] - 0.6 * 3.14159, q4 = q_in[4] + 0.3 * 3.14159;
+  const double side = (leg == 0) ? 1.0 : -1.0;
+  double s0, c0, s1, c1, s2, c2, s23, c23, s234, c234;
+  orc_sincos(q0, &s0, &c0);
+  orc_sincos(q1, &s1, &c1);
+  orc_sincos(q2, &s2, &c2);
+  orc_sincos(q2 + q3, &s23, &c23);
+  orc_sincos(q2 + q3 + q4, &s234, &c234);
+  const double Ls = 0.04 * s234 + 0.22 * s23 + 0.22 * s2, Lc = 0.04 * c234 + 0.22 * c23 + 0.22 * c2;
+  const double Ls3 = 0.04 * s234 + 0.22 * s23, Lc3 = 0.04 * c234 + 0.22 * c23;
+  const double k1 = 0.018 * side + 0.0025, k0 = 0.015 * side;
+  const double hip = k0 + c1 * k1 - 1.0 * s1 * Lc;
+  const double lat = s1 * k1 + c1 * Lc;
+  memset(J, 0, sizeof(double) * 30);
+#define JJ(r, c) J[(r) * 5 + (c)]
+  JJ(0, 0) = s0 * (Ls + 0.0135) + c0 * hip;
+  JJ(1, 0) = s0 * hip - 1.0 * c0 * (Ls + 0.0135);
+  JJ(5, 0) = 1.0;
+  JJ(0, 1) = -1.0 * s0 * lat;
+  JJ(1, 1) = c0 * lat;
+  JJ(2, 1) = s1 * Lc - 1.0 * c1 * k1;
+  JJ(3, 1) = c0;
+  JJ(4, 1) = s0;
+  JJ(0, 2) = s0 * s1 * Ls - 1.0 * c0 * Lc;
+  JJ(1, 2) = -1.0 * s0 * Lc - 1.0 * c0 * s1 * Ls;
+  JJ(2, 2) = c1 * Ls;
+  JJ(0, 3) = s0 * s1 * Ls3 - 1.0 * c0 * Lc3;
+  JJ(1, 3) = -1.0 * s0 * Lc3 - 1.0 * c0 * s1 * Ls3;
+  JJ(2, 3) = c1 * Ls3;
+  JJ(0, 4) = 0.04 * s234 * s0 * s1 - 0.04 * c234 * c0;
+  JJ(1, 4) = -0.04 * c234 * s0 - 0.04 * s234 * c0 * s1;
+  JJ(2, 4) = 0.04 * s234 * c1;
+  for (int c = 2; c < 5; ++c) {
+    JJ(3, c) = -c1 * s0;
+    JJ(4, c) = c0 * c1;
+    JJ(5, c) = s1;
+  }
+#undef JJ
+}
+
+/* tau[leg][j] = sum_i J(i,j) f_ff[leg][i], i ascending (LegController.cpp:60) */
+void orc_leg_torques(const double *f_ff /*[2][6]*/, const double *leg_q /*[10]*/, double *tau /*[2][5]*/) {
+  for (int leg = 0; leg < 2; ++leg) {
+    double J[30];
+    orc_leg_jacobian(leg_q + 5 * leg, leg, J);
+    for (int j = 0; j < 5; ++j) {
+      double acc = 0.0;
+      for (int i = 0; i < 6; ++i) acc = acc + J[i * 5 + j] * f_ff[6 * leg + i];
+      tau[5 * leg + j] = acc;
+    }
+  }
+}

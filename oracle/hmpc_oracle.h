@@ -125,6 +125,9 @@ void orc_mpc_gait(int n_segments, const int offsets[2], const int durations[2], 
 void orc_build_record(const orc_tick_t *t, int horizon, double dtMPC, unsigned char *record, double wpd_out[2]);
 /* q_soln (>= 12 doubles) + rBody -> f_ff[2][6] */
 void orc_body_wrench(const double *q_soln, const double *rBody, double *f_ff);
+/* f3, second half: leg Jacobian (common/LegController.cpp:108-167) and joint torques tau = J' f_ff (:57-61) */
+void orc_leg_jacobian(const double q[5], int leg, double J[30]);
+void orc_leg_torques(const double *f_ff, const double *leg_q, double *tau);
 
 /* provided by oracle/_ref/libqpoases_ref.so (oracle/qpoases_shim.cpp, built from the reference's own sources) */
 int ref_qpoases_solve(int nV, int nC, const double *H, const double *g, const double *A, const double *lbA,

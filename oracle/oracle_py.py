@@ -92,6 +92,8 @@ def lib():
         L.orc_mpc_gait.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_build_record.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         L.orc_body_wrench.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_leg_torques.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_leg_jacobian.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ref_qpoases_solve.restype = C.c_int
         L.ref_qpoases_solve.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 4
         _lib = L
@@ -221,3 +223,20 @@ def body_wrench(q_soln: np.ndarray, rBody: np.ndarray) -> np.ndarray:
     for k in range(q.shape[0]):
         L.orc_body_wrench(q[k].ctypes.data, rb[k].ctypes.data, out[k].ctypes.data)
     return out
+
+
+def leg_torques(f_ff: np.ndarray, leg_q: np.ndarray) -> np.ndarray:
+    f = np.ascontiguousarray(f_ff, dtype=np.float64).reshape(-1, 12)
+    q = np.ascontiguousarray(leg_q, dtype=np.float64).reshape(-1, 10)
+    out = np.zeros((f.shape[0], 2, 5), dtype=np.float64)
+    L = lib()
+    for k in range(f.shape[0]):
+        L.orc_leg_torques(f[k].ctypes.data, q[k].ctypes.data, out[k].ctypes.data)
+    return out
+
+
+def leg_jacobian(q5: np.ndarray, leg: int) -> np.ndarray:
+    q = np.ascontiguousarray(q5, dtype=np.float64)
+    J = np.zeros(30, dtype=np.float64)
+    lib().orc_leg_jacobian(q.ctypes.data, int(leg), J.ctypes.data)
+    return J.reshape(6, 5)

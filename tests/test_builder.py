@@ -81,6 +81,43 @@ def test_oracle_body_wrench(oracle):
             np.testing.assert_allclose(f[k, leg, 3:], -rb[k] @ q[k, 6 + 3 * leg:9 + 3 * leg], rtol=1e-14, atol=1e-13)
 
 
+def test_oracle_jacobian_structure(oracle):
+    rng = np.random.default_rng(3)
+    for leg in (0, 1):
+        q = rng.uniform(-0.3, 0.3, 5)
+        J = oracle.leg_jacobian(q, leg)
+        s0, c0, s1, c1 = math.sin(q[0]), math.cos(q[0]), math.sin(q[1]), math.cos(q[1])
+        # angular rows: joint axes of a Rz(q0) Rx(q1) Ry(...) chain (LegController.cpp:134-165 rows 3-5)
+        np.testing.assert_allclose(J[3:, 0], [0, 0, 1], atol=1e-15)
+        np.testing.assert_allclose(J[3:, 1], [c0, s0, 0], atol=1e-15)
+        for c in (2, 3, 4):
+            np.testing.assert_allclose(J[3:, c], [-c1 * s0, c0 * c1, s1], atol=1e-15)
+        # translational columns 2..4 shrink with the lever arm: |J_v(:,4)| = 0.04 (the 4 cm foot link)
+        assert abs(np.linalg.norm(J[:3, 4]) - 0.04) < 1e-12
+        # column 3 = column 4 + 0.22 m shank contribution, column 2 adds the 0.22 m thigh: norms are ordered
+        assert np.linalg.norm(J[:3, 2]) > np.linalg.norm(J[:3, 4])
+    # integrability: the translational columns are the gradient of ONE foot position, so d J(:,j)/d q_k == d J(:,k)/d q_j
+    # (a transcription slip in any entry breaks this); central differences on the restated Jacobian itself
+    for leg in (0, 1):
+        q = rng.uniform(-0.4, 0.4, 5)
+        hstep = 1e-5
+        D = np.zeros((5, 5, 3))
+        for k in range(5):
+            dq = np.zeros(5)
+            dq[k] = hstep
+            D[:, k, :] = ((oracle.leg_jacobian(q + dq, leg)[:3] - oracle.leg_jacobian(q - dq, leg)[:3]) / (2 * hstep)).T
+        for j in range(5):
+            for k in range(5):
+                np.testing.assert_allclose(D[j, k], D[k, j], atol=2e-8)
+    f = rng.normal(size=(3, 12)) * 20
+    lq = rng.uniform(-0.3, 0.3, (3, 10))
+    tau = oracle.leg_torques(f, lq)
+    for k in range(3):
+        for leg in (0, 1):
+            J = oracle.leg_jacobian(lq[k, 5 * leg:5 * leg + 5], leg)
+            np.testing.assert_allclose(tau[k, leg], J.T @ f[k, 6 * leg:6 * leg + 6], rtol=1e-13, atol=1e-13)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("gait,h,nb", [("walking", 10, 64), ("standing", 10, 33), ("walking", 20, 16)])
 def test_device_builder_bitwise(oracle, gait, h, nb):
@@ -102,4 +139,8 @@ def test_device_builder_bitwise(oracle, gait, h, nb):
     fff = mpc.body_wrench(t["rBody"])
     want_f = oracle.body_wrench(forces.astype(np.float64), t["rBody"])
     np.testing.assert_array_equal(fff.view(np.uint64), want_f.view(np.uint64))
+    fff2, tau = mpc.leg_torques(t["rBody"], t["leg_q"])
+    np.testing.assert_array_equal(fff2.view(np.uint64), want_f.view(np.uint64))
+    want_tau = oracle.leg_torques(want_f, t["leg_q"])
+    np.testing.assert_array_equal(tau.view(np.uint64), want_tau.view(np.uint64))
     mpc.close()
