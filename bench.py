@@ -253,6 +253,26 @@ def main() -> None:
             "solver": {"failed": n_fail, "iters_median": float(np.median(iters)), "iters_max": int(iters.max()), "active_median": float(np.median(nact)), "active_max": int(nact.max()),
                        "kernel_solves_per_s": B / (kernel_ms * 1e-3)},
         }
+        # the other BASELINE.json shapes on the same kernel family, a few launches each (not the headline value)
+        extra = {}
+        try:
+            for name, gait2, hh, bb in (("cfg2_walking_b1024_fixed_phase", "walking", 10, 1024),
+                                        ("metric_2contact_b1024", "standing", 10, 1024),
+                                        ("cfg3_walking_sweep_b8192_per_gpu", "walking", 10, 8192),
+                                        ("cfg4_h20_single_support_b4096", "single", 20, 4096)):
+                f2 = synthetic.make_batch(bb, hh, gait2, seed=2, phase=(0 if "fixed" in name else "random"))
+                m2 = interface.BatchedMPC(synthetic.DT_MPC, hh, synthetic.F_MAX, bb, device=local_rank)
+                m2.upload(records.pack_records(f2, hh))
+                m2.solve(stream)
+                torch.cuda.synchronize()
+                ms2 = m2.time_solve(10, stream)
+                _, st2 = m2.download()
+                extra[name] = {"solves_per_s": bb / (ms2 * 1e-3), "kernel_ms": ms2,
+                               "failed": int((interface.status_code(st2) != 0).sum())}
+                m2.close()
+        except Exception as exc:  # never let the side measurements break the headline line
+            extra["error"] = repr(exc)
+        out["other_configs"] = extra
         if args.check > 0:
             from oracle import oracle_py  # checker only, after the timed region
             nchk = min(args.check, B)
