@@ -136,12 +136,12 @@ static inline float cosf_orc(float a) {
 orc_qp_t *orc_qp_alloc(int h) {
   orc_qp_t *q = (orc_qp_t *)calloc(1, sizeof(orc_qp_t));
   q->horizon = h;
-  q->Phi = (float *)calloc((size_t)h * 13 * 12, sizeof(float));
+  q->Phi = (float *)calloc((size_t)h * 13 * 18, sizeof(float));
   q->Apow = (float *)calloc((size_t)(h + 1) * 169, sizeof(float));
-  q->H = (float *)calloc((size_t)144 * h * h, sizeof(float));
-  q->g = (float *)calloc((size_t)12 * h, sizeof(float));
-  q->lb = (float *)calloc((size_t)16 * h, sizeof(float));
-  q->ub = (float *)calloc((size_t)16 * h, sizeof(float));
+  q->H = (float *)calloc((size_t)324 * h * h, sizeof(float));
+  q->g = (float *)calloc((size_t)18 * h, sizeof(float));
+  q->lb = (float *)calloc((size_t)24 * h, sizeof(float));
+  q->ub = (float *)calloc((size_t)24 * h, sizeof(float));
   return q;
 }
 void orc_qp_free(orc_qp_t *q) {
@@ -150,7 +150,7 @@ void orc_qp_free(orc_qp_t *q) {
 }
 orc_red_t *orc_red_alloc(int h) {
   orc_red_t *r = (orc_red_t *)calloc(1, sizeof(orc_red_t));
-  int N = 12 * h, M = 16 * h;
+  int N = 18 * h, M = 24 * h;
   r->var_ind = (int *)calloc(N, sizeof(int));
   r->con_ind = (int *)calloc(M, sizeof(int));
   r->H = (double *)calloc((size_t)N * N, sizeof(double));
@@ -228,6 +228,8 @@ void orc_set_dense_chain(int on) { g_dense_chain = on; }
 ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_qp_t *o) {
   const int h = st->horizon;
   o->horizon = h;
+  const int nc = (u->nc == 3) ? 3 : 2, U = 6 * nc, C8 = 8 * nc;
+  o->nc = nc;
 
   /* 1. joint angles (SolverMPC.cpp:374-393): float += double offsets, then fmod by 2*PI in double */
   const double PI = 3.14159265359;
@@ -308,7 +310,7 @@ ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_q
   inverse3(Iw, Iinv);
 
   /* 7. continuous model (SolverMPC.cpp:312-331), mass 9.0 (:423); r_feet(axis,leg) = r[2*axis+leg] */
-  float Act[169], Bct[156];
+  float Act[169], Bct[13 * 18];
   memset(Act, 0, sizeof Act);
   memset(Bct, 0, sizeof Bct);
   for (int i = 0; i < 3; ++i)
@@ -316,17 +318,17 @@ ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_q
   for (int i = 0; i < 3; ++i) Act[(3 + i) * 13 + 9 + i] = 1.0f;
   Act[11 * 13 + 12] = -1.0f;
   const float inv_m = 1.0f / 9.0f;
-  for (int leg = 0; leg < 2; ++leg) {
-    float r0 = u->r[0 + leg], r1 = u->r[2 + leg], r2 = u->r[4 + leg];
+  for (int leg = 0; leg < nc; ++leg) {
+    float r0 = u->r[0 * nc + leg], r1 = u->r[1 * nc + leg], r2 = u->r[2 * nc + leg];
     float cm[9] = {0.0f, -r2, r1, r2, 0.0f, -r0, -r1, r0, 0.0f};
     float blk[9];
     chain_matmul(Iinv, cm, blk, 3, 3, 3);
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) {
-        Bct[(6 + i) * 12 + 3 * leg + j] = blk[i * 3 + j];
-        Bct[(6 + i) * 12 + 6 + 3 * leg + j] = Iinv[i * 3 + j];
+        Bct[(6 + i) * U + 3 * leg + j] = blk[i * 3 + j];
+        Bct[(6 + i) * U + 3 * nc + 3 * leg + j] = Iinv[i * 3 + j];
       }
-    for (int i = 0; i < 3; ++i) Bct[(9 + i) * 12 + 3 * leg + i] = inv_m;
+    for (int i = 0; i < 3; ++i) Bct[(9 + i) * U + 3 * leg + i] = inv_m;
   }
 
   /* 8. forward-Euler discretisation (SolverMPC.cpp:145-146) */
@@ -334,13 +336,14 @@ ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_q
   float *Acd = o->Acd, *Bcd = o->Bcd;
   for (int i = 0; i < 13; ++i)
     for (int j = 0; j < 13; ++j) Acd[i * 13 + j] = ((i == j) ? 1.0f : 0.0f) + dt * Act[i * 13 + j];
-  for (int i = 0; i < 156; ++i) Bcd[i] = dt * Bct[i];
+  for (int i = 0; i < 13 * U; ++i) Bcd[i] = dt * Bct[i];
 
   /* 9. powers by repeated right-multiplication from the identity and Phi_k = Acd^k Bcd (SolverMPC.cpp:148-178);
    *    the reference hard-codes 10 here; the oracle uses the horizon. */
   for (int i = 0; i < 169; ++i) o->Apow[i] = (i % 14 == 0) ? 1.0f : 0.0f;
   for (int k = 0; k < h; ++k) chain_matmul(o->Apow + k * 169, Acd, o->Apow + (k + 1) * 169, 13, 13, 13);
-  for (int k = 0; k < h; ++k) chain_matmul(o->Apow + k * 169, Bcd, o->Phi + k * 156, 13, 13, 12);
+  const int PS = 13 * U; /* floats per Phi_k */
+  for (int k = 0; k < h; ++k) chain_matmul(o->Apow + k * 169, Bcd, o->Phi + k * PS, 13, 13, U);
 
   /* 10. tracking error e = A_qp x0 - X_d (SolverMPC.cpp:457-461, :570) */
   float *e = (float *)malloc(sizeof(float) * 13 * h);
@@ -360,21 +363,21 @@ ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_q
   float W[13];
   for (int s = 0; s < 12; ++s) W[s] = u->weights[s];
   W[12] = 0.0f;
-  float *SPhi = (float *)malloc(sizeof(float) * h * 156);
+  float *SPhi = (float *)malloc(sizeof(float) * h * PS);
   for (int k = 0; k < h; ++k)
     for (int s = 0; s < 13; ++s)
-      for (int c = 0; c < 12; ++c) SPhi[k * 156 + s * 12 + c] = W[s] * o->Phi[k * 156 + s * 12 + c];
-  const int N = 12 * h;
+      for (int c = 0; c < U; ++c) SPhi[k * PS + s * U + c] = W[s] * o->Phi[k * PS + s * U + c];
+  const int N = U * h;
   for (int I = 0; I < N; ++I) {
-    int a = I / 12, r = I % 12;
+    int a = I / U, r = I % U;
     for (int J = I; J < N; ++J) {
-      int b = J / 12, c = J % 12;
+      int b = J / U, c = J % U;
       float acc = 0.0f;
       int i0 = g_dense_chain ? 0 : b; /* b >= a because J >= I */
       for (int i = i0; i < h; ++i) {
         for (int s = 0; s < 13; ++s) {
-          float sb = (i >= a) ? SPhi[(i - a) * 156 + s * 12 + r] : 0.0f;
-          float bb = (i >= b) ? o->Phi[(i - b) * 156 + s * 12 + c] : 0.0f;
+          float sb = (i >= a) ? SPhi[(i - a) * PS + s * U + r] : 0.0f;
+          float bb = (i >= b) ? o->Phi[(i - b) * PS + s * U + c] : 0.0f;
           acc = fmaf(sb, bb, acc);
         }
       }
@@ -384,12 +387,12 @@ ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_q
     }
   }
   for (int J = 0; J < N; ++J) {
-    int b = J / 12, c = J % 12;
+    int b = J / U, c = J % U;
     float acc = 0.0f;
     int i0 = g_dense_chain ? 0 : b;
     for (int i = i0; i < h; ++i)
       for (int s = 0; s < 13; ++s) {
-        float sb = (i >= b) ? SPhi[(i - b) * 156 + s * 12 + c] : 0.0f;
+        float sb = (i >= b) ? SPhi[(i - b) * PS + s * U + c] : 0.0f;
         acc = fmaf(sb, e[13 * i + s], acc);
       }
     o->g[J] = 2.0f * acc;
@@ -400,10 +403,11 @@ ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_q
   /* 12. foot rotations and constraint block (SolverMPC.cpp:426-433, :488-548); mu, lt, lh hard-coded there */
   foot_rotation(qj, o->Rfoot[0]);
   foot_rotation(qj + 5, o->Rfoot[1]);
+  if (nc == 3) memcpy(o->Rfoot[2], u->Rhand, sizeof(float) * 9); /* extension: the hand contact frame is an input */
   const float mu = 2.0f, lt = 0.09f, lh = 0.06f;
   float *Fc = o->Fc;
-  memset(Fc, 0, sizeof(float) * 16 * 12);
-  for (int leg = 0; leg < 2; ++leg) {
+  memset(Fc, 0, sizeof(float) * C8 * U);
+  for (int leg = 0; leg < nc; ++leg) {
     const float *Rf = o->Rfoot[leg];
     float col0[3], col1[3], vlt[3], vlh[3], t0[3], t1[3], flt[3], flh[3];
     for (int k = 0; k < 3; ++k) {
@@ -416,32 +420,32 @@ ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_q
     chain_matmul(col1, Rt, t1, 1, 3, 3); /* (e_y' Rfoot') R'  */
     chain_matmul(vlt, Rt, flt, 1, 3, 3); /* (-lt e_z' Rfoot') R' */
     chain_matmul(vlh, Rt, flh, 1, 3, 3);
-    float *row = Fc + (8 * leg) * 12;
-    const int cf = 3 * leg, cmo = 6 + 3 * leg;
-    row[0 * 12 + cf + 0] = -mu, row[0 * 12 + cf + 2] = 1.0f;
-    row[1 * 12 + cf + 0] = mu, row[1 * 12 + cf + 2] = 1.0f;
-    row[2 * 12 + cf + 1] = -mu, row[2 * 12 + cf + 2] = 1.0f;
-    row[3 * 12 + cf + 1] = mu, row[3 * 12 + cf + 2] = 1.0f;
+    float *row = Fc + (8 * leg) * U;
+    const int cf = 3 * leg, cmo = 3 * nc + 3 * leg;
+    row[0 * U + cf + 0] = -mu, row[0 * U + cf + 2] = 1.0f;
+    row[1 * U + cf + 0] = mu, row[1 * U + cf + 2] = 1.0f;
+    row[2 * U + cf + 1] = -mu, row[2 * U + cf + 2] = 1.0f;
+    row[3 * U + cf + 1] = mu, row[3 * U + cf + 2] = 1.0f;
     for (int j = 0; j < 3; ++j) {
-      row[4 * 12 + cmo + j] = t0[j];
-      row[5 * 12 + cf + j] = flt[j];
-      row[5 * 12 + cmo + j] = t1[j];
-      row[6 * 12 + cf + j] = flh[j];
-      row[6 * 12 + cmo + j] = (leg == 0) ? -t1[j] : t1[j]; /* SolverMPC.cpp:526 vs :546 */
+      row[4 * U + cmo + j] = t0[j];
+      row[5 * U + cf + j] = flt[j];
+      row[5 * U + cmo + j] = t1[j];
+      row[6 * U + cf + j] = flh[j];
+      row[6 * U + cmo + j] = (leg != 1) ? -t1[j] : t1[j]; /* SolverMPC.cpp:526 vs :546; the hand follows the left foot */
     }
-    row[7 * 12 + cf + 2] = 2.0f;
+    row[7 * U + cf + 2] = 2.0f;
   }
 
   /* 13. bounds (SolverMPC.cpp:466-482) */
   const float big = (float)ORC_BIG;
   for (int i = 0; i < h; ++i)
-    for (int leg = 0; leg < 2; ++leg) {
-      float *lb = o->lb + 16 * i + 8 * leg, *ub = o->ub + 16 * i + 8 * leg;
+    for (int leg = 0; leg < nc; ++leg) {
+      float *lb = o->lb + C8 * i + 8 * leg, *ub = o->ub + C8 * i + 8 * leg;
       for (int j = 0; j < 4; ++j) lb[j] = 0.0f, ub[j] = big;
       lb[4] = 0.0f, ub[4] = 0.01f;
       lb[5] = -big, ub[5] = 0.0f;
       lb[6] = -big, ub[6] = 0.0f;
-      lb[7] = 0.0f, ub[7] = st->f_max * (float)u->gait[2 * i + leg];
+      lb[7] = 0.0f, ub[7] = ((leg == 2) ? u->f_max_hand : st->f_max) * (float)u->gait[nc * i + leg];
     }
 }
 
@@ -451,17 +455,20 @@ static int near_zero(float a) { return (a < 0.0001 && a > -.0001); }
  * coefficient ~2 sits in column j removes that leg-step's force (j-2..j) and moment (j+4..j+6) variables and its 8
  * constraint rows; the survivors are gathered in ascending original order. */
 void orc_reduce(const orc_qp_t *qp, orc_red_t *red) {
-  const int h = qp->horizon, N = 12 * h, M = 16 * h;
+  const int nc = qp->nc, U = 6 * nc, C8 = 8 * nc;
+  const int h = qp->horizon, N = U * h, M = C8 * h;
   char *ve = (char *)calloc(N, 1), *ce = (char *)calloc(M, 1);
   for (int i = 0; i < M; ++i) {
     if (!(near_zero((float)(double)qp->lb[i]) && near_zero((float)(double)qp->ub[i]))) continue;
-    int step = i / 16;
-    const float *crow = qp->Fc + (i % 16) * 12;
-    for (int jj = 0; jj < 12; ++jj) {
+    int step = i / C8;
+    const float *crow = qp->Fc + (i % C8) * U;
+    for (int jj = 0; jj < U; ++jj) {
       if (!near_zero(crow[jj] - 2)) continue;
-      int j = 12 * step + jj;
-      int last = (j % 2 == 0) ? (j + 4) / 6 * 8 - 1 : (j + 1) / 6 * 8 + 7;
-      for (int k = 0; k < 3; ++k) ve[j - k] = 1, ve[j + 4 + k] = 1;
+      /* column jj is Fz of contact c = jj/3: its force (jj-2..jj), its moment (3 nc further) and its 8 rows go.
+       * For nc = 2 this is the reference's index arithmetic (j+4..j+6, rows (j+4)/6*8-1 resp. (j+1)/6*8+7 and the 7 before). */
+      int j = U * step + jj, c = jj / 3;
+      int last = C8 * step + 8 * c + 7;
+      for (int k = 0; k < 3; ++k) ve[j - k] = 1, ve[j - 2 + 3 * nc + k] = 1;
       for (int k = 0; k < 8; ++k) ce[last - k] = 1;
     }
   }
@@ -479,11 +486,11 @@ void orc_reduce(const orc_qp_t *qp, orc_red_t *red) {
   }
   for (int c = 0; c < m; ++c) {
     int oc = red->con_ind[c];
-    int step = oc / 16;
-    const float *crow = qp->Fc + (oc % 16) * 12;
+    int step = oc / C8;
+    const float *crow = qp->Fc + (oc % C8) * U;
     for (int j = 0; j < n; ++j) {
       int ov = red->var_ind[j];
-      red->A[(size_t)c * n + j] = (ov / 12 == step) ? (double)crow[ov % 12] : 0.0; /* fmat is block diagonal (:552-555) */
+      red->A[(size_t)c * n + j] = (ov / U == step) ? (double)crow[ov % U] : 0.0; /* fmat is block diagonal (:552-555) */
     }
     red->lb[c] = (double)qp->lb[oc];
     red->ub[c] = (double)qp->ub[oc];
@@ -504,7 +511,7 @@ static double now_s(void) {
 
 static int solve_with(const orc_update_t *u, const orc_setup_t *s, orc_qp_t *qp, orc_red_t *red, double *q_soln,
                       int *nwsr, double *obj, double *t_asm, double *t_sol) {
-  const int N = 12 * s->horizon;
+  const int N = 6 * ((u->nc == 3) ? 3 : 2) * s->horizon;
   double t0 = now_s();
   orc_assemble(u, s, qp);
   orc_reduce(qp, red);
@@ -551,6 +558,7 @@ void orc_setup_problem(double dt, int horizon, double mu, double f_max) {
 void orc_update_problem_data(double *p, double *v, double *q, double *w, double *r, double *joint_angles, double yaw,
                              double *weights, double *state_trajectory, double *Alpha_K, int *gait) {
   const int h = g_setup.horizon;
+  g_update.nc = 2;
   for (int i = 0; i < 3; ++i) g_update.p[i] = (float)p[i], g_update.v[i] = (float)v[i], g_update.w[i] = (float)w[i];
   for (int i = 0; i < 4; ++i) g_update.q[i] = (float)q[i];
   for (int i = 0; i < 6; ++i) g_update.r[i] = (float)r[i];
@@ -579,7 +587,24 @@ void orc_unpack_record(const unsigned char *rec, int horizon, orc_update_t *u) {
   memcpy(u->weights, f + 30, 48), memcpy(u->Alpha_K, f + 42, 48);
   memcpy(u->traj, f + 54, sizeof(float) * 12 * horizon);
   memcpy(u->gait, rec + 4 * (54 + 12 * horizon), 2 * horizon);
+  u->nc = 2;
 }
+
+/* extension record (nc = 3): p3 v3 q4 w3 r9 joint10 yaw weights12 alpha18 Rhand9 f_max_hand traj12h | gait 3h bytes */
+void orc_unpack_record3(const unsigned char *rec, int horizon, orc_update_t *u) {
+  const float *f = (const float *)rec;
+  memcpy(u->p, f + 0, 12), memcpy(u->v, f + 3, 12), memcpy(u->q, f + 6, 16), memcpy(u->w, f + 10, 12);
+  memcpy(u->r, f + 13, 36), memcpy(u->joint_angles, f + 22, 40);
+  u->yaw = f[32];
+  memcpy(u->weights, f + 33, 48), memcpy(u->Alpha_K, f + 45, 72), memcpy(u->Rhand, f + 63, 36);
+  u->f_max_hand = f[72];
+  memcpy(u->traj, f + 73, sizeof(float) * 12 * horizon);
+  memcpy(u->gait, rec + 4 * (73 + 12 * horizon), 3 * horizon);
+  u->nc = 3;
+}
+
+static int g_records_nc = 2;
+void orc_set_records_nc(int nc) { g_records_nc = (nc == 3) ? 3 : 2; }
 
 int orc_solve_records(const unsigned char *records, int stride, int first, int count, int horizon, float dt,
                       float f_max, double *q_soln, int *nwsr_out, double *obj_out, double *t_assemble,
@@ -588,12 +613,15 @@ int orc_solve_records(const unsigned char *records, int stride, int first, int c
   orc_qp_t *qp = orc_qp_alloc(horizon);
   orc_red_t *red = orc_red_alloc(horizon);
   orc_update_t u;
+  memset(&u, 0, sizeof u);
+  const int nc = g_records_nc, NU = 6 * nc;
   int bad = 0;
   for (int k = 0; k < count; ++k) {
-    orc_unpack_record(records + (size_t)(first + k) * stride, horizon, &u);
+    if (nc == 3) orc_unpack_record3(records + (size_t)(first + k) * stride, horizon, &u);
+    else orc_unpack_record(records + (size_t)(first + k) * stride, horizon, &u);
     int nwsr = 0;
     double obj = 0;
-    int rv = solve_with(&u, &s, qp, red, q_soln + (size_t)k * 12 * horizon, &nwsr, &obj, t_assemble, t_solve);
+    int rv = solve_with(&u, &s, qp, red, q_soln + (size_t)k * NU * horizon, &nwsr, &obj, t_assemble, t_solve);
     if (nwsr_out) nwsr_out[k] = nwsr;
     if (obj_out) obj_out[k] = obj;
     if (rv != 0) ++bad;

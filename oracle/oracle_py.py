@@ -26,9 +26,10 @@ def build(force: bool = False) -> None:
 
 class Update(C.Structure):
     _fields_ = [("p", C.c_float * 3), ("v", C.c_float * 3), ("q", C.c_float * 4), ("w", C.c_float * 3),
-                ("r", C.c_float * 6), ("joint_angles", C.c_float * 10), ("yaw", C.c_float),
-                ("weights", C.c_float * 12), ("traj", C.c_float * (12 * MAXH)), ("Alpha_K", C.c_float * 12),
-                ("gait", C.c_ubyte * (2 * MAXH))]
+                ("r", C.c_float * 9), ("joint_angles", C.c_float * 10), ("yaw", C.c_float),
+                ("weights", C.c_float * 12), ("traj", C.c_float * (12 * MAXH)), ("Alpha_K", C.c_float * 18),
+                ("gait", C.c_ubyte * (3 * MAXH)), ("nc", C.c_int), ("Rhand", C.c_float * 9),
+                ("f_max_hand", C.c_float)]
 
 
 class Setup(C.Structure):
@@ -37,8 +38,8 @@ class Setup(C.Structure):
 
 class QP(C.Structure):
     _fields_ = [("horizon", C.c_int), ("qj", C.c_float * 10), ("R", C.c_float * 9), ("rpy", C.c_float * 3),
-                ("x0", C.c_float * 13), ("Acd", C.c_float * 169), ("Bcd", C.c_float * 156),
-                ("Rfoot", (C.c_float * 9) * 2), ("Fc", C.c_float * 192),
+                ("x0", C.c_float * 13), ("Acd", C.c_float * 169), ("nc", C.c_int), ("Bcd", C.c_float * (13 * 18)),
+                ("Rfoot", (C.c_float * 9) * 3), ("Fc", C.c_float * (24 * 18)),
                 ("Phi", C.POINTER(C.c_float)), ("Apow", C.POINTER(C.c_float)), ("H", C.POINTER(C.c_float)),
                 ("g", C.POINTER(C.c_float)), ("lb", C.POINTER(C.c_float)), ("ub", C.POINTER(C.c_float))]
 
@@ -89,6 +90,8 @@ def lib():
         L.orc_solve_records.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_unpack_record.argtypes = [C.c_void_p, C.c_int, C.POINTER(Update)]
+        L.orc_unpack_record3.argtypes = [C.c_void_p, C.c_int, C.POINTER(Update)]
+        L.orc_set_records_nc.argtypes = [C.c_int]
         L.orc_mpc_gait.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_build_record.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         L.orc_body_wrench.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -105,31 +108,35 @@ def _np(ptr, shape, dtype):
     return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype).reshape(shape).copy()
 
 
-def update_from_record(rec_row: np.ndarray, horizon: int) -> Update:
+def update_from_record(rec_row: np.ndarray, horizon: int, nc: int = 2) -> Update:
     u = Update()
     row = np.ascontiguousarray(rec_row)
-    lib().orc_unpack_record(row.ctypes.data, horizon, C.byref(u))
+    (lib().orc_unpack_record3 if nc == 3 else lib().orc_unpack_record)(row.ctypes.data, horizon, C.byref(u))
     return u
 
 
 def assemble_record(rec_row: np.ndarray, horizon: int, dt: float, f_max: float, reduce: bool = True,
-                    dense_chain: bool = False) -> dict:
-    """Runs orc_assemble (+ orc_reduce) on one packed record and returns every intermediate as numpy arrays."""
+                    dense_chain: bool = False, nc: int = 2) -> dict:
+    """Runs orc_assemble (+ orc_reduce) on one packed record and returns every intermediate as numpy arrays.
+
+    nc = 3 reads the extension record layout (hand contact, BASELINE config 5)."""
     L = lib()
-    u = update_from_record(rec_row, horizon)
+    u = update_from_record(rec_row, horizon, nc)
     s = Setup(np.float32(dt), np.float32(0.25), np.float32(f_max), horizon)
     qp = L.orc_qp_alloc(horizon)
     L.orc_set_dense_chain(1 if dense_chain else 0)
     L.orc_assemble(C.byref(u), C.byref(s), qp)
     L.orc_set_dense_chain(0)
     q = qp.contents
-    h, N, M = horizon, 12 * horizon, 16 * horizon
+    U, C8 = 6 * nc, 8 * nc
+    h, N, M = horizon, U * horizon, C8 * horizon
     out = dict(
         qj=np.array(q.qj, dtype=np.float32), R=np.array(q.R, dtype=np.float32).reshape(3, 3),
         rpy=np.array(q.rpy, dtype=np.float32), x0=np.array(q.x0, dtype=np.float32),
-        Acd=np.array(q.Acd, dtype=np.float32).reshape(13, 13), Bcd=np.array(q.Bcd, dtype=np.float32).reshape(13, 12),
-        Rfoot=np.array(q.Rfoot, dtype=np.float32).reshape(2, 3, 3), Fc=np.array(q.Fc, dtype=np.float32).reshape(16, 12),
-        Phi=_np(q.Phi, (h, 13, 12), np.float32), Apow=_np(q.Apow, (h + 1, 13, 13), np.float32),
+        Acd=np.array(q.Acd, dtype=np.float32).reshape(13, 13), Bcd=np.array(q.Bcd, dtype=np.float32)[:13 * U].reshape(13, U),
+        Rfoot=np.array(q.Rfoot, dtype=np.float32).reshape(3, 3, 3)[:nc],
+        Fc=np.array(q.Fc, dtype=np.float32)[:C8 * U].reshape(C8, U),
+        Phi=_np(q.Phi, (h, 13, U), np.float32), Apow=_np(q.Apow, (h + 1, 13, 13), np.float32),
         H=_np(q.H, (N, N), np.float32), g=_np(q.g, (N,), np.float32), lb=_np(q.lb, (M,), np.float32),
         ub=_np(q.ub, (M,), np.float32),
     )
@@ -164,13 +171,15 @@ def qpoases_solve(H, g, A, lb, ub, nwsr_max: int = 500):
     return x, y, obj.value, nwsr.value, st
 
 
-def solve_records(records: np.ndarray, horizon: int, dt: float, f_max: float, first: int = 0, count: int | None = None):
+def solve_records(records: np.ndarray, horizon: int, dt: float, f_max: float, first: int = 0, count: int | None = None,
+                  nc: int = 2):
     """Full reference path (assembly + elimination + qpOASES + scatter) on packed records.
 
-    Returns dict(q_soln [count,12h] float64, nwsr, obj, n_bad, t_assemble, t_solve)."""
+    Returns dict(q_soln [count,6 nc h] float64, nwsr, obj, n_bad, t_assemble, t_solve)."""
     records = np.ascontiguousarray(records)
     count = records.shape[0] - first if count is None else count
-    q = np.zeros((count, 12 * horizon))
+    q = np.zeros((count, 6 * nc * horizon))
+    lib().orc_set_records_nc(nc)
     nwsr = np.zeros(count, dtype=np.int32)
     obj = np.zeros(count)
     ta = C.c_double(0)
@@ -178,6 +187,7 @@ def solve_records(records: np.ndarray, horizon: int, dt: float, f_max: float, fi
     bad = lib().orc_solve_records(records.ctypes.data, records.shape[1], first, count, horizon, np.float32(dt),
                                   np.float32(f_max), q.ctypes.data, nwsr.ctypes.data, obj.ctypes.data,
                                   C.addressof(ta), C.addressof(ts))
+    lib().orc_set_records_nc(2)
     return dict(q_soln=q, nwsr=nwsr, obj=obj, n_bad=bad, t_assemble=ta.value, t_solve=ts.value)
 
 
