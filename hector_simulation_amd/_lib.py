@@ -16,6 +16,7 @@ EXPORTS = [
     "hmpc_solve", "hmpc_download", "hmpc_get_device_outputs", "hmpc_batch", "hmpc_horizon", "hmpc_time_solve",
     "hmpc_build_records", "hmpc_build_records_device", "hmpc_body_wrench", "hmpc_body_wrench_device", "hmpc_leg_torques", "hmpc_leg_torques_device",
     "hmpc_download_records", "hmpc_debug_assemble", "hmpc_debug_phase_cycles", "hmpc_download_f64", "hmpc_last_hip_error", "hmpc_version",
+    "hmpc_create_ex", "hmpc_contacts", "hmpc_record_stride_ex", "hmpc_pack_record_ex",
 ]
 
 
@@ -73,6 +74,11 @@ def load():
     L.hmpc_record_stride.restype = C.c_size_t
     L.hmpc_pack_record.argtypes = [vp, ci] + [vp] * 6 + [cd] + [vp] * 4
     L.hmpc_create.argtypes = [C.POINTER(vp), C.POINTER(ProblemSetup), ci, ci]
+    L.hmpc_create_ex.argtypes = [C.POINTER(vp), C.POINTER(ProblemSetup), ci, ci, ci]
+    L.hmpc_contacts.argtypes = [vp]
+    L.hmpc_record_stride_ex.argtypes = [ci, ci]
+    L.hmpc_record_stride_ex.restype = C.c_size_t
+    L.hmpc_pack_record_ex.argtypes = [vp, ci, ci] + [vp] * 6 + [cd] + [vp] * 5 + [cd]
     L.hmpc_destroy.argtypes = [vp]
     L.hmpc_upload_records.argtypes = [vp, vp, ci]
     L.hmpc_set_device_records.argtypes = [vp, vp, ci]

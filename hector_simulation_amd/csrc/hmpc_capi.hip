@@ -34,7 +34,7 @@ thread_local std::string g_hip_err;
 typedef void (*kernel_fn)(hmpc::KernelArgs);
 
 struct Variant {
-  int nmax, hmax, nt, qcap;
+  int nmax, hmax, nt, qcap, nc;
   kernel_fn solve, assemble;
   size_t smem;
   int dbg_floats;
@@ -44,28 +44,39 @@ struct Variant {
 // 60 (single support over h <= 10) -> 128-thread workgroups (55 blocks).  QCAP = working-set capacity: the fast variants
 // hold 80 rows (two workgroups per CU); the "safe" variants hold NMAX rows (can never overflow, one workgroup per CU)
 // and re-solve the few instances the fast pass flags (hmpc_resolve_failed).
-template <int NMAX, int HMAX, int NT, int QCAP>
+// The extension with a third (hand) contact -- BASELINE config 5, 180 variables x 240 rows at h = 10 -- runs 512-thread
+// workgroups (465 register blocks, one workgroup per CU).
+template <int NMAX, int HMAX, int NT, int QCAP, int NC = 2>
 Variant make_variant() {
-  return Variant{NMAX, HMAX, NT, QCAP, hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, false>,
-                 hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, true>, sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP>),
-                 hmpc::DbgLayout<NMAX>::TOTAL};
+  static_assert(sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC>) <= 160 * 1024, "LDS budget of a gfx950 CU");
+  return Variant{NMAX, HMAX, NT, QCAP, NC, hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, false, NC>,
+                 hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, true, NC>, sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC>),
+                 hmpc::DbgLayout<NMAX, NC>::TOTAL};
 }
 
 const Variant *variants() {
   static const Variant v[] = {make_variant<60, 10, 128, 60>(),   make_variant<120, 10, 256, 80>(),
                               make_variant<60, 20, 128, 60>(),   make_variant<120, 20, 256, 80>(),
-                              make_variant<120, 10, 256, 120>(), make_variant<120, 20, 256, 120>()};
+                              make_variant<120, 10, 256, 120>(), make_variant<120, 20, 256, 120>(),
+                              make_variant<180, 10, 512, 100, 3>(), make_variant<180, 10, 512, 140, 3>()};
   return v;
 }
-constexpr int N_FAST = 4;
-constexpr int N_VARIANTS = 6;
+constexpr int N_FAST = 4;       // two-contact fast variants [0, N_FAST), their safe variants N_FAST + (h > 10)
+constexpr int V3_FAST = 6, V3_SAFE = 7;
+constexpr int N_VARIANTS = 8;
+constexpr int MAX_VARS_ANY = 180;
+constexpr int DBG_FLOATS_MAX = hmpc::DbgLayout<180, 3>::TOTAL > hmpc::DbgLayout<120, 2>::TOTAL
+                                   ? hmpc::DbgLayout<180, 3>::TOTAL
+                                   : hmpc::DbgLayout<120, 2>::TOTAL;
 
-size_t record_stride(int h) { return (size_t)(((54 + 12 * h) * 4 + 2 * h + 15) / 16 * 16); }
+int fixed_floats(int nc) { return nc == 3 ? 73 : 54; }
+size_t record_stride(int h, int nc = 2) { return (size_t)(((fixed_floats(nc) + 12 * h) * 4 + nc * h + 15) / 16 * 16); }
 
 }  // namespace
 
 struct hmpc_handle {
   problem_setup setup;
+  int nc;  // contacts per horizon step: 2 (reference) or 3 (hand-contact extension)
   int max_batch, device, batch;
   size_t stride;
   unsigned char *d_records_own;
@@ -86,6 +97,10 @@ struct hmpc_handle {
 static const Variant &pick_variant(const hmpc_handle *h, int *index) {
   const Variant *v = variants();
   const int hz = h->setup.horizon;
+  if (h->nc == 3) {
+    if (index) *index = V3_FAST;
+    return v[V3_FAST];
+  }
   int best = -1;
   for (int i = 0; i < N_FAST; ++i) {
     if (v[i].hmax < hz) continue;
@@ -103,7 +118,7 @@ static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int db
   int vi = 0;
   const Variant *pv = &pick_variant(h, &vi);
   if (d_index_list) {  // safe variant: working set as large as the variable count
-    vi = (h->setup.horizon <= 10) ? N_FAST : N_FAST + 1;
+    vi = (h->nc == 3) ? V3_SAFE : ((h->setup.horizon <= 10) ? N_FAST : N_FAST + 1);
     pv = &variants()[vi];
   }
   const Variant &v = *pv;
@@ -142,6 +157,33 @@ const char *hmpc_last_hip_error(void) { return g_hip_err.c_str(); }
 const char *hmpc_version(void) { return "hector_mpc_hip 0.1 (gfx950)"; }
 
 size_t hmpc_record_stride(int horizon) { return record_stride(horizon); }
+size_t hmpc_record_stride_ex(int horizon, int n_contacts) { return record_stride(horizon, n_contacts == 3 ? 3 : 2); }
+
+int hmpc_pack_record_ex(void *record, int horizon, int n_contacts, const double *p, const double *v, const double *q,
+                        const double *w, const double *r, const double *joint_angles, double yaw, const double *weights,
+                        const double *state_trajectory, const double *Alpha_K, const int *gait, const double *Rhand,
+                        double f_max_hand) {
+  if (n_contacts == 2)
+    return hmpc_pack_record(record, horizon, p, v, q, w, r, joint_angles, yaw, weights, state_trajectory, Alpha_K, gait);
+  if (n_contacts != 3) return HMPC_E_ARG;
+  if (!record || !p || !v || !q || !w || !r || !joint_angles || !weights || !state_trajectory || !Alpha_K || !gait || !Rhand)
+    return HMPC_E_ARG;
+  if (horizon < 1 || horizon > 10) return HMPC_E_HORIZON;
+  memset(record, 0, record_stride(horizon, 3));
+  float *f = (float *)record;
+  for (int i = 0; i < 3; ++i) f[0 + i] = (float)p[i], f[3 + i] = (float)v[i], f[10 + i] = (float)w[i];
+  for (int i = 0; i < 4; ++i) f[6 + i] = (float)q[i];
+  for (int i = 0; i < 9; ++i) f[13 + i] = (float)r[i], f[63 + i] = (float)Rhand[i];
+  for (int i = 0; i < 10; ++i) f[22 + i] = (float)joint_angles[i];
+  f[32] = (float)yaw;
+  for (int i = 0; i < 12; ++i) f[33 + i] = (float)weights[i];
+  for (int i = 0; i < 18; ++i) f[45 + i] = (float)Alpha_K[i];
+  f[72] = (float)f_max_hand;
+  for (int i = 0; i < 12 * horizon; ++i) f[73 + i] = (float)state_trajectory[i];
+  unsigned char *g = (unsigned char *)record + 4 * (73 + 12 * horizon);
+  for (int i = 0; i < 3 * horizon; ++i) g[i] = (unsigned char)gait[i];
+  return HMPC_OK;
+}
 
 int hmpc_pack_record(void *record, int horizon, const double *p, const double *v, const double *q, const double *w,
                      const double *r, const double *joint_angles, double yaw, const double *weights,
@@ -164,8 +206,14 @@ int hmpc_pack_record(void *record, int horizon, const double *p, const double *v
 }
 
 int hmpc_create(hmpc_handle **out, const struct problem_setup *setup, int max_batch, int device) {
-  if (!out || !setup || max_batch < 1) return HMPC_E_ARG;
-  if (setup->horizon < 1 || setup->horizon > HMPC_MAX_HORIZON) return HMPC_E_HORIZON;
+  return hmpc_create_ex(out, setup, max_batch, device, 2);
+}
+
+int hmpc_contacts(const hmpc_handle *h) { return h ? h->nc : HMPC_E_ARG; }
+
+int hmpc_create_ex(hmpc_handle **out, const struct problem_setup *setup, int max_batch, int device, int n_contacts) {
+  if (!out || !setup || max_batch < 1 || (n_contacts != 2 && n_contacts != 3)) return HMPC_E_ARG;
+  if (setup->horizon < 1 || setup->horizon > (n_contacts == 3 ? 10 : HMPC_MAX_HORIZON)) return HMPC_E_HORIZON;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device >= ndev) {
     g_hip_err = "no HIP device visible (libhector_mpc_hip has no CPU fallback)";
@@ -178,11 +226,12 @@ int hmpc_create(hmpc_handle **out, const struct problem_setup *setup, int max_ba
   h->setup = *setup;
   h->max_batch = max_batch;
   h->device = device;
-  h->stride = record_stride(setup->horizon);
+  h->nc = n_contacts;
+  h->stride = record_stride(setup->horizon, n_contacts);
   h->max_stance = -1;
   h->warm = 1;
   h->auto_resolve = 1;
-  const size_t nf = (size_t)max_batch * 12 * setup->horizon;
+  const size_t nf = (size_t)max_batch * 6 * n_contacts * setup->horizon;
   if (hipMalloc(&h->d_records_own, (size_t)max_batch * h->stride) != hipSuccess ||
       hipMalloc(&h->d_forces_own, nf * sizeof(float)) != hipSuccess ||
       hipMalloc(&h->d_status_own, (size_t)max_batch * sizeof(uint32_t)) != hipSuccess) {
@@ -223,11 +272,15 @@ int hmpc_upload_records(hmpc_handle *h, const void *host_records, int batch) {
   const int hz = h->setup.horizon;
   int mx = 0;
   const unsigned char *rec = (const unsigned char *)host_records;
+  const int nc = h->nc, nfix = fixed_floats(nc);
   for (int b = 0; b < batch; ++b) {
-    const unsigned char *g = rec + (size_t)b * h->stride + 4 * (54 + 12 * hz);
+    const unsigned char *rb = rec + (size_t)b * h->stride;
+    const unsigned char *g = rb + 4 * (nfix + 12 * hz);
+    float hand_cap = 0.f;
+    if (nc == 3) memcpy(&hand_cap, rb + 4 * 72, 4);
     int cnt = 0;
-    for (int i = 0; i < 2 * hz; ++i) {
-      float ub = h->setup.f_max * (float)g[i];
+    for (int i = 0; i < nc * hz; ++i) {
+      float ub = ((i % nc) == 2 ? hand_cap : h->setup.f_max) * (float)g[i];
       if (!(ub < 0.0001 && ub > -.0001)) ++cnt;
     }
     if (cnt > mx) mx = cnt;
@@ -313,7 +366,7 @@ int hmpc_download(hmpc_handle *h, float *forces, uint32_t *status) {
     int rc = hmpc_resolve_failed(h, nullptr);
     if (rc != HMPC_OK) return rc;
   }
-  const size_t nf = (size_t)h->batch * 12 * h->setup.horizon;
+  const size_t nf = (size_t)h->batch * 6 * h->nc * h->setup.horizon;
   if (forces && nf) HIP_TRY(hipMemcpy(forces, h->d_forces, nf * sizeof(float), hipMemcpyDeviceToHost));
   if (status && h->batch)
     HIP_TRY(hipMemcpy(status, h->d_status, (size_t)h->batch * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -360,33 +413,33 @@ int hmpc_debug_assemble(hmpc_handle *h, int index, int *n, int *m, int *var_ind,
   int vi = 0;
   const Variant &v = pick_variant(h, &vi);
   if (!h->d_dbg_f) {
-    HIP_TRY(hipMalloc(&h->d_dbg_f, sizeof(float) * (size_t)hmpc::DbgLayout<HMPC_MAX_VARS>::TOTAL));
-    HIP_TRY(hipMalloc(&h->d_dbg_i, sizeof(int) * (2 + HMPC_MAX_VARS)));
+    HIP_TRY(hipMalloc(&h->d_dbg_f, sizeof(float) * (size_t)DBG_FLOATS_MAX));
+    HIP_TRY(hipMalloc(&h->d_dbg_i, sizeof(int) * (2 + MAX_VARS_ANY)));
   }
-  HIP_TRY(hipMemset(h->d_dbg_i, 0, sizeof(int) * (2 + HMPC_MAX_VARS)));
+  HIP_TRY(hipMemset(h->d_dbg_i, 0, sizeof(int) * (2 + MAX_VARS_ANY)));
   int rc = launch(h, 0, true, index);
   if (rc != HMPC_OK) return rc;
   HIP_TRY(hipDeviceSynchronize());
   std::vector<float> hf(v.dbg_floats);
-  std::vector<int> hi(2 + HMPC_MAX_VARS);
+  std::vector<int> hi(2 + MAX_VARS_ANY);
   HIP_TRY(hipMemcpy(hf.data(), h->d_dbg_f, sizeof(float) * hf.size(), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(hi.data(), h->d_dbg_i, sizeof(int) * hi.size(), hipMemcpyDeviceToHost));
   const int nn = hi[0], mm = hi[1], hz = h->setup.horizon;
   if (n) *n = nn;
   if (m) *m = mm;
   if (nn > v.nmax) return HMPC_OK;  // too large: only n, m are meaningful
-  const int NM = v.nmax;
-  const int oG = NM * NM, oFC = oG + NM, oLB = oFC + 192, oUB = oLB + 320, oX0 = oUB + 320, oACD = oX0 + 16,
-            oBCD = oACD + 176;
+  const int NM = v.nmax, nc = v.nc;
+  const int oG = NM * NM, oFC = oG + NM, oLB = oFC + 48 * nc * nc, oUB = oLB + 160 * nc, oX0 = oUB + 160 * nc,
+            oACD = oX0 + 16, oBCD = oACD + 176;
   if (var_ind) memcpy(var_ind, hi.data() + 2, sizeof(int) * nn);
   if (H) memcpy(H, hf.data(), sizeof(float) * (size_t)nn * nn);
   if (g) memcpy(g, hf.data() + oG, sizeof(float) * nn);
-  if (Fc) memcpy(Fc, hf.data() + oFC, sizeof(float) * 192);
-  if (lb) memcpy(lb, hf.data() + oLB, sizeof(float) * 16 * hz);
-  if (ub) memcpy(ub, hf.data() + oUB, sizeof(float) * 16 * hz);
+  if (Fc) memcpy(Fc, hf.data() + oFC, sizeof(float) * 48 * nc * nc);
+  if (lb) memcpy(lb, hf.data() + oLB, sizeof(float) * 8 * nc * hz);
+  if (ub) memcpy(ub, hf.data() + oUB, sizeof(float) * 8 * nc * hz);
   if (x0) memcpy(x0, hf.data() + oX0, sizeof(float) * 13);
   if (Acd) memcpy(Acd, hf.data() + oACD, sizeof(float) * 169);
-  if (Bcd) memcpy(Bcd, hf.data() + oBCD, sizeof(float) * 156);
+  if (Bcd) memcpy(Bcd, hf.data() + oBCD, sizeof(float) * 78 * nc);
   return HMPC_OK;
 }
 
@@ -415,6 +468,7 @@ int hmpc_debug_phase_cycles(hmpc_handle *h, long long *cycles /*[batch][24]*/) {
 // ---------------------------------------------------------------------------------------------------- rows f1-f3
 int hmpc_build_records_device(hmpc_handle *h, const void *device_ticks, int batch, double dtMPC, double *device_wpd_out,
                               void *stream) {
+  if (h && h->nc != 2) return HMPC_E_ARG;  // rows f1-f3 restate the reference's two-foot controller code
   if (!h || !device_ticks || batch < 0) return HMPC_E_ARG;
   if (batch > h->max_batch) return HMPC_E_BATCH;
   HIP_TRY(hipSetDevice(h->device));
@@ -453,6 +507,7 @@ int hmpc_build_records(hmpc_handle *h, const struct hmpc_tick_inputs *host_ticks
 }
 
 int hmpc_body_wrench_device(hmpc_handle *h, const double *device_rBody, double *device_f_ff, void *stream) {
+  if (h && h->nc != 2) return HMPC_E_ARG;  // rows f1-f3 restate the reference's two-foot controller code
   if (!h || !device_rBody || !device_f_ff) return HMPC_E_ARG;
   HIP_TRY(hipSetDevice(h->device));
   if (h->batch > 0) {
@@ -485,6 +540,7 @@ int hmpc_body_wrench(hmpc_handle *h, const double *host_rBody, double *host_f_ff
 
 int hmpc_leg_torques_device(hmpc_handle *h, const double *device_rBody, const double *device_leg_q, double *device_f_ff,
                             double *device_tau, void *stream) {
+  if (h && h->nc != 2) return HMPC_E_ARG;  // rows f1-f3 restate the reference's two-foot controller code
   if (!h || !device_rBody || !device_leg_q || !device_tau) return HMPC_E_ARG;
   HIP_TRY(hipSetDevice(h->device));
   if (h->batch > 0) {
@@ -529,7 +585,7 @@ int hmpc_download_records(hmpc_handle *h, void *host_records) {
 int hmpc_download_f64(hmpc_handle *h, double *x, double *obj) {
   if (!h) return HMPC_E_ARG;
   HIP_TRY(hipSetDevice(h->device));
-  const size_t nf = (size_t)h->max_batch * 12 * h->setup.horizon;
+  const size_t nf = (size_t)h->max_batch * 6 * h->nc * h->setup.horizon;
   if (!h->d_x64) {
     // first use: allocate and re-run the last batch with the binary64 copy-out enabled
     HIP_TRY(hipMalloc(&h->d_x64, nf * sizeof(double)));
@@ -538,7 +594,7 @@ int hmpc_download_f64(hmpc_handle *h, double *x, double *obj) {
     if (rc != HMPC_OK) return rc;
   }
   HIP_TRY(hipStreamSynchronize(h->last_stream));
-  const size_t nb = (size_t)h->batch * 12 * h->setup.horizon;
+  const size_t nb = (size_t)h->batch * 6 * h->nc * h->setup.horizon;
   if (x && nb) HIP_TRY(hipMemcpy(x, h->d_x64, nb * sizeof(double), hipMemcpyDeviceToHost));
   if (obj && h->batch) HIP_TRY(hipMemcpy(obj, h->d_obj64, (size_t)h->batch * sizeof(double), hipMemcpyDeviceToHost));
   return HMPC_OK;

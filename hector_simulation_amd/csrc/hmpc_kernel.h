@@ -54,30 +54,40 @@ enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, 
 #endif
 
 // offsets (in floats) of the debug dump, shared with the host
-template <int NMAX>
+template <int NMAX, int NC = 2>
 struct DbgLayout {
-  static constexpr int H = 0, G = NMAX * NMAX, FC = G + NMAX, LB = FC + 192, UB = LB + 16 * 20, X0 = UB + 16 * 20,
-                       ACD = X0 + 16, BCD = ACD + 176, TOTAL = BCD + 160;
+  static constexpr int H = 0, G = NMAX * NMAX, FC = G + NMAX, LB = FC + 48 * NC * NC, UB = LB + 8 * NC * 20,
+                       X0 = UB + 8 * NC * 20, ACD = X0 + 16, BCD = ACD + 176, TOTAL = BCD + 80 * NC;
+};
+
+// record field offsets in floats (hector_simulation_amd/records.py).  NC = 2 is the reference's update_data_t; NC = 3 is
+// the extension record with a hand contact (its frame Rhand and force cap travel in the record).
+template <int NC>
+struct RecLayout {
+  static constexpr int P = 0, V = 3, Q = 6, W = 10, R = 13, JA = R + 3 * NC, YAW = JA + 10, WT = YAW + 1, AL = WT + 12,
+                       RH = AL + 6 * NC, FMH = RH + 9, NF = (NC == 2) ? RH : FMH + 1;
 };
 
 enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT = 4, S_WORKSET = 5 };
 
 constexpr int GS = 6;  // variables per stance leg-step: force (3) then moment (3)
 
-template <int NMAX, int HMAX, int NT, int QCAP>
+template <int NMAX, int HMAX, int NT, int QCAP, int NC = 2>
 struct Smem {
+  static constexpr int U = 6 * NC;       // variables per horizon step before elimination: F of each contact, then M
+  static constexpr int PS = 13 * U;      // floats per Phi_k
   static constexpr int NG = NMAX / GS;   // leg-steps (blocks per matrix side)
   static constexpr int MMAX = NG * 8;    // constraint rows
   static constexpr int NW = NT / 64;
   static constexpr int QMAX = QCAP;      // working-set capacity (packed Schur inverse); QCAP = NMAX can never overflow
-  static constexpr int RECW = ((54 + 12 * HMAX) * 4 + 2 * HMAX + 15) / 16 * 4;  // record words
+  static constexpr int RECW = ((RecLayout<NC>::NF + 12 * HMAX) * 4 + NC * HMAX + 15) / 16 * 4;  // record words
 
   double g[NMAX];        // gradient, sweep order
-  double Cn[2][8][6];    // per-leg constraint normals (columns: F then M of that leg)
+  double Cn[NC][8][6];   // per-contact constraint normals (columns: F then M of that contact)
   double ub7[NG];        // Fz cap f_max*gait of each stance leg-step
   unsigned char vstep[NMAX], vcomp[NMAX];  // reference-order reduced variable -> horizon step, component (0..11)
   unsigned char o2s[NMAX], s2o[NMAX];      // reference order <-> sweep order (leg-step major)
-  unsigned char rmap[12 * HMAX];           // original variable 12*step+comp -> sweep index (255 = eliminated)
+  unsigned char rmap[U * HMAX];            // original variable U*step+comp -> sweep index (255 = eliminated)
   unsigned char ls_leg[NG];
   int n, m, nls, pad0;
 
@@ -87,9 +97,9 @@ struct Smem {
     float sc234[2][2];
     float rpy[3];
     float ypsc[4];  // cy, sy, cp, sp
-    float Acd[169], Bcd[156], x0[13], W[13], Fc[192];
+    float Acd[169], Bcd[PS], x0[13], W[13], Fc[8 * NC * U];
     float Apow[2 * 169];
-    float Phi[HMAX * 156], SPhi[HMAX * 156];
+    float Phi[HMAX * PS], SPhi[HMAX * PS];
     float e[13 * HMAX];
     unsigned char pre_nl[HMAX], pre_nv[HMAX], pre_st[HMAX];  // per step: leg-steps / variables before it, stance bits
     float Hs[(NMAX / 2) * (NMAX + 1)];  // H, upper triangle, binary32 (exact), rows i and NMAX-1-i folded into one
@@ -183,10 +193,12 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY>
-__global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
-  using SM = Smem<NMAX, HMAX, NT, QCAP>;
-  constexpr int NG = SM::NG, NW = SM::NW;
+template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC = 2>
+__global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArgs args) {
+  using SM = Smem<NMAX, HMAX, NT, QCAP, NC>;
+  using RL = RecLayout<NC>;
+  constexpr int NG = SM::NG, NW = SM::NW, U = SM::U, PS = SM::PS, C8 = 8 * NC;
+  static_assert(NC == 2 || (NC == 3 && NT >= 512), "contacts: two feet (reference) or two feet + hand (extension)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SM &S = *reinterpret_cast<SM *>(smem_raw);
   auto &A = S.u.a;
@@ -206,10 +218,11 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
   }
   __syncthreads();
   const float *rf = reinterpret_cast<const float *>(A.rec);
-  const unsigned char *gait = reinterpret_cast<const unsigned char *>(A.rec + 54 + 12 * h);
-  // record field offsets (hector_simulation_amd/records.py)
-  const float *in_p = rf + 0, *in_v = rf + 3, *in_q = rf + 6, *in_w = rf + 10, *in_r = rf + 13, *in_ja = rf + 19,
-              *in_wt = rf + 30, *in_al = rf + 42, *in_traj = rf + 54;
+  const unsigned char *gait = reinterpret_cast<const unsigned char *>(A.rec + RL::NF + 12 * h);
+  const float *in_p = rf + RL::P, *in_v = rf + RL::V, *in_q = rf + RL::Q, *in_w = rf + RL::W, *in_r = rf + RL::R,
+              *in_ja = rf + RL::JA, *in_wt = rf + RL::WT, *in_al = rf + RL::AL, *in_traj = rf + RL::NF;
+  // Fz cap of a contact: f_max for the feet; the hand's own cap travels in the extension record
+  auto fz_cap = [&](int c) -> float { return (NC == 3 && c == 2) ? rf[RL::FMH] : args.f_max; };
 
   // ---------------- A1: trigonometry, one lane per angle (SolverMPC.cpp:374-393, 333-342, 74-85); a lane of another
   // wave builds the swing-leg elimination tables meanwhile (SolverMPC.cpp:589-637)
@@ -267,12 +280,17 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       // the index tables are filled in parallel in the next stage
       int nv = 0, nl = 0;
       for (int i = 0; i < h; ++i) {
-        float ubL = args.f_max * (float)gait[2 * i], ubR = args.f_max * (float)gait[2 * i + 1];
-        const bool sL = !(ubL < 0.0001 && ubL > -.0001), sR = !(ubR < 0.0001 && ubR > -.0001);
-        const int nst = (int)sL + (int)sR;
+        int bits = 0, nst = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float ubc = fz_cap(c) * (float)gait[NC * i + c];
+          const bool st = !(ubc < 0.0001 && ubc > -.0001);
+          bits |= st ? (1 << c) : 0;
+          nst += (int)st;
+        }
         A.pre_nl[i] = (unsigned char)(nl > 255 ? 255 : nl);
         A.pre_nv[i] = (unsigned char)(nv > 255 ? 255 : nv);
-        A.pre_st[i] = (unsigned char)((sL ? 1 : 0) | (sR ? 2 : 0));
+        A.pre_st[i] = (unsigned char)bits;
         nv += 6 * nst;
         nl += nst;
       }
@@ -282,9 +300,9 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
     }
     // constant structure of Acd (identity), Bcd (zeros) and the constraint block (zeros), filled by everyone
     for (int t = tid; t < 169; t += NT) A.Acd[t] = (t % 14 == 0) ? 1.0f : 0.0f;  // fl(delta + dt*0) = delta
-    for (int t = tid; t < 156; t += NT) A.Bcd[t] = 0.0f;                          // fl(dt*0) = 0
-    for (int t = tid; t < 192; t += NT) A.Fc[t] = 0.0f;
-    for (int t = tid; t < 12 * h; t += NT) S.rmap[t] = 255;
+    for (int t = tid; t < PS; t += NT) A.Bcd[t] = 0.0f;                           // fl(dt*0) = 0
+    for (int t = tid; t < C8 * U; t += NT) A.Fc[t] = 0.0f;
+    for (int t = tid; t < U * h; t += NT) S.rmap[t] = 255;
   }
   __syncthreads();
 
@@ -322,17 +340,17 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
     for (int i = 0; i < 3; ++i) A.Acd[(3 + i) * 13 + 9 + i] = 0.0f + dt * 1.0f;
     A.Acd[11 * 13 + 12] = 0.0f + dt * -1.0f;
     const float inv_m = 1.0f / 9.0f;
-    for (int leg = 0; leg < 2; ++leg) {
-      const float r0 = in_r[0 + leg], r1 = in_r[2 + leg], r2 = in_r[4 + leg];
+    for (int leg = 0; leg < NC; ++leg) {
+      const float r0 = in_r[0 * NC + leg], r1 = in_r[1 * NC + leg], r2 = in_r[2 * NC + leg];
       float cm[9] = {0.0f, -r2, r1, r2, 0.0f, -r0, -r1, r0, 0.0f};
       float blk[9];
       chain_mm<3, 3, 3>(Iinv, cm, blk);
       for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
-          A.Bcd[(6 + i) * 12 + 3 * leg + j] = dt * blk[i * 3 + j];
-          A.Bcd[(6 + i) * 12 + 6 + 3 * leg + j] = dt * Iinv[i * 3 + j];
+          A.Bcd[(6 + i) * U + 3 * leg + j] = dt * blk[i * 3 + j];
+          A.Bcd[(6 + i) * U + 3 * NC + 3 * leg + j] = dt * Iinv[i * 3 + j];
         }
-      for (int i = 0; i < 3; ++i) A.Bcd[(9 + i) * 12 + 3 * leg + i] = dt * inv_m;
+      for (int i = 0; i < 3; ++i) A.Bcd[(9 + i) * U + 3 * leg + i] = dt * inv_m;
     }
     for (int s = 0; s < 12; ++s) A.W[s] = in_wt[s];
     A.W[12] = 0.0f;
@@ -340,17 +358,17 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
   {
     // foot rotation Rz(q0)Rx(q1)Ry(q2)Ry(q3)Ry(q4) and this leg's 8 rows of the 16x12 constraint block
     // (SolverMPC.cpp:426-433, 488-548)
-    const int leg_lane0 = (NT >= 256) ? 128 : 1, leg_lane1 = (NT >= 256) ? 192 : 2;
-    if (tid == leg_lane0 || tid == leg_lane1) {
-      const int leg = (tid == leg_lane0) ? 0 : 1;
+    const int leg_lane0 = (NT >= 256) ? 128 : 1, leg_lane1 = (NT >= 256) ? 192 : 2, leg_lane2 = (NC == 3) ? 256 : -1;
+    if (tid == leg_lane0 || tid == leg_lane1 || tid == leg_lane2) {
+      const int leg = (tid == leg_lane0) ? 0 : (tid == leg_lane1 ? 1 : 2);
       float R[9], Rt[9];
       quat_to_R(in_q, R, Rt);
       const float mu = 2.0f, lt = 0.09f, lh = 0.06f;
-      const int b = 5 * leg;
+      const int b = (leg < 2) ? 5 * leg : 0;
       const float s0 = A.sc[b][0], c0 = A.sc[b][1], s1 = A.sc[b + 1][0], c1 = A.sc[b + 1][1];
       const float s2 = A.sc[b + 2][0], c2 = A.sc[b + 2][1], s3 = A.sc[b + 3][0], c3 = A.sc[b + 3][1];
       const float s4 = A.sc[b + 4][0], c4 = A.sc[b + 4][1];
-      const float s234 = A.sc234[leg][0], c234 = A.sc234[leg][1];
+      const float s234 = A.sc234[leg & 1][0], c234 = A.sc234[leg & 1][1];
       float a = c0 * s2 + (c2 * s0) * s1;
       float bb = c0 * c2 - (s0 * s1) * s2;
       float d = c2 * s0 + (c0 * s1) * s2;
@@ -367,6 +385,10 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       Rf[6] = -(s234 * c1);
       Rf[7] = s1;
       Rf[8] = c234 * c1;
+      if (NC == 3 && leg == 2) {  // the hand's contact frame is an input of the extension record
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rf[k] = rf[RL::RH + k];
+      }
       float col0[3], col1[3], vlt[3], vlh[3], t0[3], t1[3], flt[3], flh[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -379,25 +401,25 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
       chain_mm<1, 3, 3>(col1, Rt, t1);
       chain_mm<1, 3, 3>(vlt, Rt, flt);
       chain_mm<1, 3, 3>(vlh, Rt, flh);
-      float *row = A.Fc + (8 * leg) * 12;
-      const int cf = 3 * leg, cmo = 6 + 3 * leg;
-      row[0 * 12 + cf + 0] = -mu, row[0 * 12 + cf + 2] = 1.0f;
-      row[1 * 12 + cf + 0] = mu, row[1 * 12 + cf + 2] = 1.0f;
-      row[2 * 12 + cf + 1] = -mu, row[2 * 12 + cf + 2] = 1.0f;
-      row[3 * 12 + cf + 1] = mu, row[3 * 12 + cf + 2] = 1.0f;
+      float *row = A.Fc + (8 * leg) * U;
+      const int cf = 3 * leg, cmo = 3 * NC + 3 * leg;
+      row[0 * U + cf + 0] = -mu, row[0 * U + cf + 2] = 1.0f;
+      row[1 * U + cf + 0] = mu, row[1 * U + cf + 2] = 1.0f;
+      row[2 * U + cf + 1] = -mu, row[2 * U + cf + 2] = 1.0f;
+      row[3 * U + cf + 1] = mu, row[3 * U + cf + 2] = 1.0f;
       for (int j = 0; j < 3; ++j) {
-        row[4 * 12 + cmo + j] = t0[j];
-        row[5 * 12 + cf + j] = flt[j];
-        row[5 * 12 + cmo + j] = t1[j];
-        row[6 * 12 + cf + j] = flh[j];
-        row[6 * 12 + cmo + j] = (leg == 0) ? -t1[j] : t1[j];
+        row[4 * U + cmo + j] = t0[j];
+        row[5 * U + cf + j] = flt[j];
+        row[5 * U + cmo + j] = t1[j];
+        row[6 * U + cf + j] = flh[j];
+        row[6 * U + cmo + j] = (leg != 1) ? -t1[j] : t1[j];
       }
-      row[7 * 12 + cf + 2] = 2.0f;
+      row[7 * U + cf + 2] = 2.0f;
       // per-leg 8x6 constraint normals in binary64 (columns: F then M of this leg)
       for (int rr = 0; rr < 8; ++rr)
         for (int k = 0; k < 3; ++k) {
-          S.Cn[leg][rr][k] = (double)row[rr * 12 + cf + k];
-          S.Cn[leg][rr][3 + k] = (double)row[rr * 12 + cmo + k];
+          S.Cn[leg][rr][k] = (double)row[rr * U + cf + k];
+          S.Cn[leg][rr][3 + k] = (double)row[rr * U + cmo + k];
         }
     }
   }
@@ -407,22 +429,22 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
     //  sweep order (leg-step major, [F(3), M(3)] each): used by the solver, 6x6 blocks = leg-step pairs.
     const int nl_tot = S.nls;
     if (tid >= 64 && tid < 128 && nl_tot <= NG) {
-      for (int it = tid - 64; it < 6 * h; it += 64) {
-        const int i = it / 6, leg = (it / 3) & 1, k = it % 3;
+      for (int it = tid - 64; it < 3 * NC * h; it += 64) {
+        const int i = it / (3 * NC), leg = (it / 3) % NC, k = it % 3;
         const int st = A.pre_st[i];
         if (st & (1 << leg)) {
-          const int nst = (st & 1) + (st >> 1), rank = (leg == 1 && (st & 1)) ? 1 : 0;
+          const int nst = __popc(st), rank = __popc(st & ((1 << leg) - 1));
           const int e = A.pre_nl[i] + rank, nv = A.pre_nv[i];
           const int oF = nv + 3 * rank + k, oM = nv + 3 * nst + 3 * rank + k;
           S.vstep[oF] = (unsigned char)i, S.vcomp[oF] = (unsigned char)(3 * leg + k);
-          S.vstep[oM] = (unsigned char)i, S.vcomp[oM] = (unsigned char)(6 + 3 * leg + k);
+          S.vstep[oM] = (unsigned char)i, S.vcomp[oM] = (unsigned char)(3 * NC + 3 * leg + k);
           S.o2s[oF] = (unsigned char)(GS * e + k), S.s2o[GS * e + k] = (unsigned char)oF;
           S.o2s[oM] = (unsigned char)(GS * e + 3 + k), S.s2o[GS * e + 3 + k] = (unsigned char)oM;
-          S.rmap[12 * i + 3 * leg + k] = (unsigned char)(GS * e + k);
-          S.rmap[12 * i + 6 + 3 * leg + k] = (unsigned char)(GS * e + 3 + k);
+          S.rmap[U * i + 3 * leg + k] = (unsigned char)(GS * e + k);
+          S.rmap[U * i + 3 * NC + 3 * leg + k] = (unsigned char)(GS * e + 3 + k);
           if (k == 0) {
             S.ls_leg[e] = (unsigned char)leg;
-            S.ub7[e] = (double)(args.f_max * (float)gait[2 * i + leg]);
+            S.ub7[e] = (double)(fz_cap(leg) * (float)gait[NC * i + leg]);
           }
         }
       }
@@ -435,7 +457,7 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
   const int n = uni(S.n), m = uni(S.m), ng = uni(S.nls);
   if (ng > NG) {  // uniform
     if (!ASM_ONLY) {
-      for (int t = tid; t < 12 * h; t += NT) args.forces[(size_t)inst * 12 * h + t] = 0.0f;
+      for (int t = tid; t < U * h; t += NT) args.forces[(size_t)inst * U * h + t] = 0.0f;
       if (tid == 0) args.status[inst] = S_TOO_LARGE;
     } else if (tid == 0) {
       args.dbg_i[0] = n;
@@ -450,7 +472,7 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
   for (int k = 0; k <= h; ++k) {
     const float *Pk = A.Apow + (k & 1) * 169;
     float *Pn = A.Apow + ((k + 1) & 1) * 169;
-    for (int t = tid; t < 169 + 156 + 13; t += NT) {
+    for (int t = tid; t < 169 + PS + 13; t += NT) {
       if (t < 169) {
         if (k < h) {
           const int i = t / 13, j = t % 13;
@@ -459,17 +481,17 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
           for (int mm = 0; mm < 13; ++mm) acc = ffma(Pk[i * 13 + mm], A.Acd[mm * 13 + j], acc);
           Pn[t] = acc;
         }
-      } else if (t < 325) {
+      } else if (t < 169 + PS) {
         if (k < h) {
-          const int rem = t - 169, i = rem / 12, j = rem % 12;
+          const int rem = t - 169, i = rem / U, j = rem % U;
           float acc = 0.0f;
 #pragma unroll
-          for (int mm = 0; mm < 13; ++mm) acc = ffma(Pk[i * 13 + mm], A.Bcd[mm * 12 + j], acc);
-          A.Phi[k * 156 + rem] = acc;
-          A.SPhi[k * 156 + rem] = A.W[i] * acc;
+          for (int mm = 0; mm < 13; ++mm) acc = ffma(Pk[i * 13 + mm], A.Bcd[mm * U + j], acc);
+          A.Phi[k * PS + rem] = acc;
+          A.SPhi[k * PS + rem] = A.W[i] * acc;
         }
       } else if (k >= 1) {
-        const int s = t - 325, i = k - 1;
+        const int s = t - (169 + PS), i = k - 1;
         float acc = 0.0f;
 #pragma unroll
         for (int mm = 0; mm < 13; ++mm) acc = ffma(Pk[s * 13 + mm], A.x0[mm], acc);
@@ -486,10 +508,10 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
     const int a = S.vstep[tid], c = S.vcomp[tid];
     float acc = 0.0f;
     for (int i = a; i < h; ++i) {
-      const float *sp = A.SPhi + (i - a) * 156 + c;
+      const float *sp = A.SPhi + (i - a) * PS + c;
       const float *ep = A.e + 13 * i;
 #pragma unroll
-      for (int s = 0; s < 13; ++s) acc = ffma(sp[s * 12], ep[s], acc);
+      for (int s = 0; s < 13; ++s) acc = ffma(sp[s * U], ep[s], acc);
     }
     S.g[S.o2s[tid]] = (double)(2.0f * acc);
   }
@@ -515,9 +537,9 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
 #pragma unroll 2
       for (int i = istart; i < h; ++i) {
         const bool la = rav && i >= sa, lb = cbv && i >= sb;
-        const float *pa = A.SPhi + (la ? (i - sa) * 156 + ca : 0) + kq * 12;
-        const float *pb = A.Phi + (lb ? (i - sb) * 156 + cc : 0) + kq * 12;
-        const float a0 = pa[0], a1 = pa[48], a2 = pa[96], b0 = pb[0], b1 = pb[48], b2 = pb[96];
+        const float *pa = A.SPhi + (la ? (i - sa) * PS + ca : 0) + kq * U;
+        const float *pb = A.Phi + (lb ? (i - sb) * PS + cc : 0) + kq * U;
+        const float a0 = pa[0], a1 = pa[4 * U], a2 = pa[8 * U], b0 = pb[0], b1 = pb[4 * U], b2 = pb[8 * U];
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la ? a0 : 0.0f, lb ? b0 : 0.0f, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la ? a1 : 0.0f, lb ? b1 : 0.0f, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la ? a2 : 0.0f, lb ? b2 : 0.0f, acc, 0, 0, 0);
@@ -537,35 +559,35 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
 
   PROF_MARK(P_HG);
   if (ASM_ONLY) {
-    using DL = DbgLayout<NMAX>;
+    using DL = DbgLayout<NMAX, NC>;
     float *o = args.dbg_f;
     if (tid == 0) {
       args.dbg_i[0] = n;
       args.dbg_i[1] = m;
     }
     for (int t = tid; t < n; t += NT) {
-      args.dbg_i[2 + t] = 12 * S.vstep[t] + S.vcomp[t];
+      args.dbg_i[2 + t] = U * S.vstep[t] + S.vcomp[t];
       o[DL::G + t] = (float)S.g[S.o2s[t]];
     }
     for (int t = tid; t < n * n; t += NT) {
       const int i = t / n, j = t % n;
       o[DL::H + t] = A.Hs[hs_index<NMAX>(i < j ? i : j, i < j ? j : i)];
     }
-    for (int t = tid; t < 192; t += NT) o[DL::FC + t] = A.Fc[t];
+    for (int t = tid; t < C8 * U; t += NT) o[DL::FC + t] = A.Fc[t];
     const float big = 5e10f;
-    for (int t = tid; t < 16 * h; t += NT) {
-      const int i = t / 16, rr = t % 8, leg = (t % 16) / 8;
+    for (int t = tid; t < C8 * h; t += NT) {
+      const int i = t / C8, rr = t % 8, leg = (t % C8) / 8;
       float lbv, ubv;
       if (rr < 4) lbv = 0.0f, ubv = big;
       else if (rr == 4) lbv = 0.0f, ubv = 0.01f;
       else if (rr < 7) lbv = -big, ubv = 0.0f;
-      else lbv = 0.0f, ubv = args.f_max * (float)gait[2 * i + leg];
+      else lbv = 0.0f, ubv = fz_cap(leg) * (float)gait[NC * i + leg];
       o[DL::LB + t] = lbv;
       o[DL::UB + t] = ubv;
     }
     for (int t = tid; t < 13; t += NT) o[DL::X0 + t] = A.x0[t];
     for (int t = tid; t < 169; t += NT) o[DL::ACD + t] = A.Acd[t];
-    for (int t = tid; t < 156; t += NT) o[DL::BCD + t] = A.Bcd[t];
+    for (int t = tid; t < PS; t += NT) o[DL::BCD + t] = A.Bcd[t];
     return;
   }
 
@@ -929,7 +951,7 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
     }
     k0 = uni(k0);
     constexpr int EPT = 5;  // packed-triangle entries per thread during the Schur inversion
-    constexpr int KBMAX = (NT >= 256) ? 45 : 34;  // KBMAX(KBMAX+1)/2 <= EPT*NT
+    constexpr int KBMAX = (NT >= 512) ? 71 : ((NT >= 256) ? 45 : 34);  // KBMAX(KBMAX+1)/2 <= EPT*NT
     static_assert(KBMAX * (KBMAX + 1) / 2 <= EPT * NT && KBMAX <= SM::QMAX, "block start capacity");
     if (k0 > KBMAX) k0 = KBMAX;
     if (take && base + below < k0) {
@@ -1292,11 +1314,11 @@ __global__ __launch_bounds__(NT, 2) void hmpc_kernel(KernelArgs args) {
   }
 
   // ---------------- output: scatter to the reference's 12h layout, eliminated variables exactly 0 (SolverMPC.cpp:720-732)
-  for (int t = tid; t < 12 * h; t += NT) {
+  for (int t = tid; t < U * h; t += NT) {
     const int rmp = S.rmap[t];
     const double xv = (rmp == 255) ? 0.0 : Q.x[rmp];
-    args.forces[(size_t)inst * 12 * h + t] = (float)xv;
-    if (args.x64) args.x64[(size_t)inst * 12 * h + t] = xv;
+    args.forces[(size_t)inst * U * h + t] = (float)xv;
+    if (args.x64) args.x64[(size_t)inst * U * h + t] = xv;
   }
   if (tid == 0) {
     args.status[inst] = (uint32_t)code | ((uint32_t)(iters & 0xfff) << 8) | ((uint32_t)(q & 0xfff) << 20);

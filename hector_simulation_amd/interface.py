@@ -58,15 +58,21 @@ def last_status() -> int:
 
 # ---------------------------------------------------------------- batched handle API
 class BatchedMPC:
-    """One handle = one GPU, one (dt, f_max, horizon) problem shape, up to ``max_batch`` independent MPC instances."""
+    """One handle = one GPU, one (dt, f_max, horizon) problem shape, up to ``max_batch`` independent MPC instances.
 
-    def __init__(self, dt: float, horizon: int, f_max: float, max_batch: int, mu: float = 0.25, device: int = 0):
+    ``contacts=3`` selects the hand-contact extension (BASELINE config 5; include/hector_mpc.h ``hmpc_create_ex``)."""
+
+    def __init__(self, dt: float, horizon: int, f_max: float, max_batch: int, mu: float = 0.25, device: int = 0,
+                 contacts: int = 2):
         self.L = _lib.load()
         self.horizon, self.max_batch, self.device = int(horizon), int(max_batch), int(device)
+        self.contacts = int(contacts)
+        self.nvar = 6 * self.contacts * self.horizon  # forces per instance: [step][F of each contact, M of each contact]
         self.setup = _lib.ProblemSetup(np.float32(dt), np.float32(mu), np.float32(f_max), int(horizon))
         self.h = C.c_void_p()
-        _check(self.L.hmpc_create(C.byref(self.h), C.byref(self.setup), self.max_batch, self.device), "hmpc_create")
-        self.stride = int(self.L.hmpc_record_stride(self.horizon))
+        _check(self.L.hmpc_create_ex(C.byref(self.h), C.byref(self.setup), self.max_batch, self.device, self.contacts),
+               "hmpc_create_ex")
+        self.stride = int(self.L.hmpc_record_stride_ex(self.horizon, self.contacts))
         self._keep = None
         self._keep_out = None
 
@@ -91,7 +97,7 @@ class BatchedMPC:
         _check(self.L.hmpc_upload_records(self.h, recs.ctypes.data, recs.shape[0]), "hmpc_upload_records")
 
     def upload_fields(self, fields: dict) -> None:
-        self.upload(records.pack_records(fields, self.horizon))
+        self.upload(records.pack_records(fields, self.horizon, self.contacts))
 
     def set_device_records(self, device_ptr: int, batch: int, max_reduced_vars: int = -1, keepalive=None) -> None:
         self._keep = keepalive
@@ -119,14 +125,14 @@ class BatchedMPC:
 
     def download(self):
         b = self.batch
-        forces = np.zeros((b, 12 * self.horizon), dtype=np.float32)
+        forces = np.zeros((b, self.nvar), dtype=np.float32)
         status = np.zeros(b, dtype=np.uint32)
         _check(self.L.hmpc_download(self.h, forces.ctypes.data, status.ctypes.data), "hmpc_download")
         return forces, status
 
     def download_f64(self):
         b = self.batch
-        x = np.zeros((b, 12 * self.horizon), dtype=np.float64)
+        x = np.zeros((b, self.nvar), dtype=np.float64)
         obj = np.zeros(b, dtype=np.float64)
         _check(self.L.hmpc_download_f64(self.h, x.ctypes.data, obj.ctypes.data), "hmpc_download_f64")
         return x, obj
@@ -170,26 +176,28 @@ class BatchedMPC:
 
     def debug_assemble(self, index: int) -> dict:
         """Assembly stage only (same device code the solve kernel runs) -> the reduced QP as the solver sees it."""
-        h = self.horizon
+        h, nc = self.horizon, self.contacts
+        nmax = 60 * nc
         n, m = C.c_int(0), C.c_int(0)
-        var_ind = np.zeros(120, dtype=np.int32)
-        H = np.zeros(120 * 120, dtype=np.float32)
-        g = np.zeros(120, dtype=np.float32)
-        Fc = np.zeros(192, dtype=np.float32)
-        lb = np.zeros(16 * h, dtype=np.float32)
-        ub = np.zeros(16 * h, dtype=np.float32)
+        var_ind = np.zeros(nmax, dtype=np.int32)
+        H = np.zeros(nmax * nmax, dtype=np.float32)
+        g = np.zeros(nmax, dtype=np.float32)
+        Fc = np.zeros(48 * nc * nc, dtype=np.float32)
+        lb = np.zeros(8 * nc * h, dtype=np.float32)
+        ub = np.zeros(8 * nc * h, dtype=np.float32)
         x0 = np.zeros(13, dtype=np.float32)
         Acd = np.zeros(169, dtype=np.float32)
-        Bcd = np.zeros(156, dtype=np.float32)
+        Bcd = np.zeros(78 * nc, dtype=np.float32)
         _check(self.L.hmpc_debug_assemble(self.h, int(index), C.byref(n), C.byref(m), var_ind.ctypes.data,
                                           H.ctypes.data, g.ctypes.data, Fc.ctypes.data, lb.ctypes.data,
                                           ub.ctypes.data, x0.ctypes.data, Acd.ctypes.data, Bcd.ctypes.data),
                "hmpc_debug_assemble")
         nn = n.value
-        if nn > 120:
+        if nn > nmax:
             return dict(n=nn, m=m.value)
         return dict(n=nn, m=m.value, var_ind=var_ind[:nn].copy(), H=H[: nn * nn].reshape(nn, nn).copy(), g=g[:nn].copy(),
-                    Fc=Fc.reshape(16, 12), lb=lb, ub=ub, x0=x0, Acd=Acd.reshape(13, 13), Bcd=Bcd.reshape(13, 12))
+                    Fc=Fc.reshape(8 * nc, 6 * nc), lb=lb, ub=ub, x0=x0, Acd=Acd.reshape(13, 13),
+                    Bcd=Bcd.reshape(13, 6 * nc))
 
 
 def status_code(status: np.ndarray) -> np.ndarray:

@@ -106,6 +106,52 @@ def make_batch(batch: int, horizon: int = 10, gait: str = "walking", seed: int =
                 Alpha_K=np.tile(ALPHA, (b, 1)), traj=traj.reshape(b, 12 * h), gait=g)
 
 
+ALPHA3 = np.array([1e-4, 1e-4, 5e-4] * 3 + [1e-2] * 9, dtype=np.float64)
+F_MAX_HAND = 150.0
+
+
+def rot_from_rpy(roll, pitch, yaw):
+    """Rz(yaw) Ry(pitch) Rx(roll), batched -> [..., 3, 3]."""
+    cr, sr, cp, sp, cy, sy = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw)
+    R = np.stack([cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
+                  sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
+                  -sp, cp * sr, cp * cr], axis=-1)
+    return R.reshape(np.shape(roll) + (3, 3))
+
+
+def make_batch3(batch: int, horizon: int = 10, gait: str = "standing", seed: int = 0, randomize: bool = True,
+                phase: int | str = 0, hand: str = "contact") -> dict:
+    """Three-contact (two feet + one hand) instances of the extension formulation -- BASELINE config 5's shape
+    (180 variables x 240 rows at h = 10 when every contact is in stance).  The feet and the body come from
+    ``make_batch`` (same seed -> same values); the hand rests on a surface in front of the body.
+
+    hand: "contact" (in stance every step), "window" (in stance for a random window of the horizon), "off" (never)."""
+    f = make_batch(batch, horizon, gait, seed, randomize, phase)
+    rng = np.random.default_rng(seed + 7919)
+    b, h = batch, horizon
+    u = (lambda lo, hi, *s: rng.uniform(lo, hi, (b,) + s)) if randomize else (lambda lo, hi, *s: np.zeros((b,) + s))
+    rh = np.stack([0.25 + u(-0.05, 0.05), -0.15 + u(-0.05, 0.05), 0.10 + u(-0.05, 0.05)], -1)  # hand relative to the body
+    r2 = f["r"].reshape(b, 3, 2)
+    r3 = np.concatenate([r2, rh[:, :, None]], axis=2).reshape(b, 9)  # r[3*axis + contact]
+    Rh = rot_from_rpy(u(-0.2, 0.2), u(-0.2, 0.2), u(-0.4, 0.4)).reshape(b, 9)
+    g2 = f["gait"].reshape(b, h, 2)
+    if hand == "contact":
+        gh = np.ones((b, h), dtype=np.int32)
+    elif hand == "off":
+        gh = np.zeros((b, h), dtype=np.int32)
+    elif hand == "window":
+        a = rng.integers(0, h, size=b)
+        ln = rng.integers(1, h + 1, size=b)
+        idx = np.arange(h)[None, :]
+        gh = ((idx >= a[:, None]) & (idx < (a + ln)[:, None])).astype(np.int32)
+    else:
+        raise ValueError(hand)
+    g3 = np.concatenate([g2, gh[:, :, None]], axis=2).reshape(b, 3 * h)
+    out = dict(f)
+    out.update(r=r3, Alpha_K=np.tile(ALPHA3, (b, 1)), gait=g3, Rhand=Rh, f_max_hand=np.full(b, F_MAX_HAND))
+    return out
+
+
 CONFIGS = {
     # BASELINE.json configs -> generator arguments (seed = config index, SURVEY.md section 8d)
     "cfg1_stand_single": dict(batch=1, horizon=10, gait="standing", seed=1, randomize=False),
@@ -114,6 +160,8 @@ CONFIGS = {
     "cfg4_h20_single_4096": dict(batch=4096, horizon=20, gait="single", seed=4, phase="random"),
     "metric_2contact_1024": dict(batch=1024, horizon=10, gait="standing", seed=6),
 }
+# BASELINE config 5 (extension: make_batch3 arguments)
+CONFIG5 = dict(batch=1024, horizon=10, gait="standing", seed=5, hand="contact")
 
 
 def rotation_world_to_body(q):

@@ -105,6 +105,22 @@ int hmpc_pack_record(void *record, int horizon, const double *p, const double *v
                      const double *state_trajectory, const double *Alpha_K, const int *gait);
 
 int hmpc_create(hmpc_handle **out, const struct problem_setup *setup, int max_batch, int device);
+
+/* ---- extension beyond the reference: a third (hand) contact per horizon step -- BASELINE.json config 5, the
+ * loco-manipulation shape 180 variables x 240 rows at h = 10.  The reference has no code for it;
+ * the formulation is the reference's own with one more contact: B_ct gains the hand's force / moment columns
+ * (SolverMPC.cpp:312-331 with a third r), the hand gets the left foot's 8-row block (SolverMPC.cpp:488-548) expressed
+ * in its contact frame Rhand (body frame, row-major) with its own force cap, gait gets a third flag per step.
+ * Component order within a step: [F_left F_right F_hand M_left M_right M_hand]; r[3*axis + contact]; Alpha_K has 18
+ * entries in that order; gait[3*step + contact].  h <= 10.  Rows f1-f3 (tick builder, wrench, torques) are two-foot only. */
+#define HMPC_MAX_VARS_3C 180
+int hmpc_create_ex(hmpc_handle **out, const struct problem_setup *setup, int max_batch, int device, int n_contacts);
+int hmpc_contacts(const hmpc_handle *h);
+size_t hmpc_record_stride_ex(int horizon, int n_contacts); /* n_contacts 3: (73+12h)*4 + 3h rounded up to 16 */
+int hmpc_pack_record_ex(void *record, int horizon, int n_contacts, const double *p, const double *v, const double *q,
+                        const double *w, const double *r, const double *joint_angles, double yaw, const double *weights,
+                        const double *state_trajectory, const double *Alpha_K, const int *gait, const double *Rhand,
+                        double f_max_hand);
 int hmpc_destroy(hmpc_handle *h);
 /* host records -> device (synchronous copy on the handle's stream) */
 int hmpc_upload_records(hmpc_handle *h, const void *host_records, int batch);

@@ -1,0 +1,5 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_contacts3.py -m gpu -x -q -s 2>&1 | tail -40 > gpurun_out/c3.log
+cat gpurun_out/c3.log
+timeout 600 python -m pytest tests/ -m gpu -x -q --deselect tests/test_gpu_contacts3.py 2>&1 | tail -5

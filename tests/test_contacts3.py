@@ -1,0 +1,105 @@
+"""Three-contact extension (two feet + one hand; BASELINE.json config 5, 180 variables x 240 rows at h = 10).
+
+The reference has no code for this shape, so the oracle's nc = 3 branch is an EXTENSION of the
+pinned restatement.  It is anchored to the pinned part by construction tests here: with the hand never in contact the
+three-contact QP must reduce to exactly the two-contact QP of the reference formulation (bit for bit), and with the hand
+in contact the solution must satisfy the KKT conditions of the QP the oracle assembled."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hector_simulation_amd import records, synthetic
+
+H = 10
+
+
+def _kkt_ok(o, x, tol=1e-6):
+    """x (reduced) is the minimiser of 0.5 x'Hx + g'x s.t. lb <= A x <= ub: projected-gradient test via multipliers."""
+    Hr, g, A, lb, ub = o["H_red"], o["g_red"], o["A_red"], o["lb_red"], o["ub_red"]
+    s = A @ x
+    scale = max(1.0, np.abs(x).max())
+    assert (s >= lb - tol * scale).all() and (s <= ub + tol * scale).all()
+    act_l = np.abs(s - lb) <= 1e-7 * scale
+    act_u = np.abs(s - ub) <= 1e-7 * scale
+    rows = np.where(act_l | act_u)[0]
+    grad = Hr @ x + g
+    if len(rows) == 0:
+        assert np.abs(grad).max() < 1e-5 * max(1.0, np.abs(g).max())
+        return
+    N = A[rows]
+    lam, *_ = np.linalg.lstsq(N.T, grad, rcond=None)
+    assert np.abs(N.T @ lam - grad).max() < 1e-5 * max(1.0, np.abs(g).max())
+    # sign: lower-active rows need lam >= 0, upper-active lam <= 0 (rows active on both sides are equalities)
+    for r, l in zip(rows, lam):
+        if act_l[r] and not act_u[r]:
+            assert l > -1e-6 * max(1.0, np.abs(lam).max())
+        if act_u[r] and not act_l[r]:
+            assert l < 1e-6 * max(1.0, np.abs(lam).max())
+
+
+def test_layout_and_pack_record_ex():
+    f = synthetic.make_batch3(3, H, "walking", seed=9, hand="window", phase="random")
+    rec = records.pack_records(f, H, 3)
+    assert rec.shape == (3, records.record_stride(H, 3)) and records.record_stride(H, 3) == 816
+    back = records.unpack_records(rec, H, 3)
+    np.testing.assert_array_equal(back["gait"], f["gait"].astype(np.uint8))
+    np.testing.assert_array_equal(back["Rhand"], f["Rhand"].astype(np.float32))
+    from hector_simulation_amd import _lib
+
+    L = _lib.load()
+    assert L.hmpc_record_stride_ex(H, 3) == 816 and L.hmpc_record_stride_ex(H, 2) == 720
+    one = np.zeros(816, dtype=np.uint8)
+    k = 1
+    a = [np.ascontiguousarray(f[n][k], dtype=np.float64) for n in ("p", "v", "q", "w", "r", "joint_angles")]
+    b = [np.ascontiguousarray(f[n][k], dtype=np.float64) for n in ("weights", "traj", "Alpha_K")]
+    g = np.ascontiguousarray(f["gait"][k], dtype=np.int32)
+    rh = np.ascontiguousarray(f["Rhand"][k], dtype=np.float64)
+    rc = L.hmpc_pack_record_ex(one.ctypes.data, H, 3, *[x.ctypes.data for x in a], float(f["yaw"][k]),
+                               *[x.ctypes.data for x in b], g.ctypes.data, rh.ctypes.data, float(f["f_max_hand"][k]))
+    assert rc == 0
+    np.testing.assert_array_equal(one, rec[k])
+
+
+def test_hand_off_reduces_to_reference_formulation(oracle):
+    """nc = 3 with the hand out of contact == the reference's two-contact QP, bit for bit (reduced H, g, A, bounds)
+    and solution for solution."""
+    f3 = synthetic.make_batch3(6, H, "walking", seed=31, hand="off", phase="random")
+    f2 = synthetic.make_batch(6, H, "walking", seed=31, phase="random")
+    rec3, rec2 = records.pack_records(f3, H, 3), records.pack_records(f2, H)
+    for k in range(6):
+        o3 = oracle.assemble_record(rec3[k], H, synthetic.DT_MPC, synthetic.F_MAX, nc=3)
+        o2 = oracle.assemble_record(rec2[k], H, synthetic.DT_MPC, synthetic.F_MAX)
+        assert o3["n"] == o2["n"] and o3["m"] == o2["m"]
+        for name in ("H_red", "g_red", "A_red", "lb_red", "ub_red"):
+            np.testing.assert_array_equal(o3[name], o2[name], err_msg=name)
+        # same variables: component c of step i is 12 i + c there, 18 i + c' here
+        st, c = o3["var_ind"] // 18, o3["var_ind"] % 18
+        leg, isM, kk = np.where(c < 9, c // 3, (c - 9) // 3), c >= 9, c % 3
+        np.testing.assert_array_equal(12 * st + 6 * isM + 3 * leg + kk, o2["var_ind"])
+    r3 = oracle.solve_records(rec3, H, synthetic.DT_MPC, synthetic.F_MAX, nc=3)
+    r2 = oracle.solve_records(rec2, H, synthetic.DT_MPC, synthetic.F_MAX)
+    q3 = r3["q_soln"].reshape(6, H, 18)
+    q2 = r2["q_soln"].reshape(6, H, 12)
+    np.testing.assert_array_equal(q3[:, :, [0, 1, 2, 3, 4, 5, 9, 10, 11, 12, 13, 14]], q2)
+    assert (q3[:, :, [6, 7, 8, 15, 16, 17]] == 0).all()
+
+
+@pytest.mark.parametrize("gait,hand,seed", [("standing", "contact", 5), ("walking", "window", 6), ("mixed", "contact", 8)])
+def test_three_contact_solution_is_kkt_point(oracle, gait, hand, seed):
+    f = synthetic.make_batch3(4, H, gait, seed=seed, hand=hand, phase="random")
+    rec = records.pack_records(f, H, 3)
+    r = oracle.solve_records(rec, H, synthetic.DT_MPC, synthetic.F_MAX, nc=3)
+    assert r["n_bad"] == 0
+    for k in range(4):
+        o = oracle.assemble_record(rec[k], H, synthetic.DT_MPC, synthetic.F_MAX, nc=3)
+        if gait == "standing":
+            assert o["n"] == 180 and o["m"] == 240  # BASELINE config 5's QP size
+        np.testing.assert_array_equal(o["H"], o["H"].T)
+        x = r["q_soln"][k][o["var_ind"]]
+        _kkt_ok(o, x)
+        # the hand's 8-row block is the left foot's with the hand frame: spot-check the sign pattern of row 6
+        Fc = o["Fc"]
+        np.testing.assert_array_equal(Fc[16 + 6, 15:18], -Fc[16 + 5, 15:18])
+        np.testing.assert_array_equal(Fc[6, 9:12], -Fc[5, 9:12])
+        np.testing.assert_array_equal(Fc[8 + 6, 12:15], Fc[8 + 5, 12:15])

@@ -1,0 +1,99 @@
+"""GPU parity for the three-contact extension (BASELINE.json config 5: 180 variables x 240 rows, batch 1024):
+assembly bit-identical to the oracle's nc = 3 branch, forces within 1e-4 relative of qpOASES on the same QP, and
+the hand-off case equal to the two-contact kernel."""
+import numpy as np
+import pytest
+
+from hector_simulation_amd import interface, records, synthetic
+
+pytestmark = pytest.mark.gpu
+H = 10
+TOL = 1e-4
+
+
+def rel_inf(a, b):
+    return np.abs(a - b).max(axis=1) / np.maximum(1.0, np.abs(b).max(axis=1))
+
+
+@pytest.mark.parametrize("gait,hand,seed", [("standing", "contact", 5), ("walking", "window", 6), ("mixed", "off", 7)])
+def test_assembly_bitwise_3c(oracle, gait, hand, seed):
+    nb = 4
+    f = synthetic.make_batch3(nb, H, gait, seed=seed, hand=hand, phase="random")
+    rec = records.pack_records(f, H, 3)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb, contacts=3)
+    mpc.upload(rec)
+    for k in range(nb):
+        o = oracle.assemble_record(rec[k], H, synthetic.DT_MPC, synthetic.F_MAX, nc=3)
+        d = mpc.debug_assemble(k)
+        assert d["n"] == o["n"] and d["m"] == o["m"]
+        np.testing.assert_array_equal(d["var_ind"], o["var_ind"])
+        for name in ("x0", "Acd", "Bcd", "Fc", "lb", "ub"):
+            np.testing.assert_array_equal(d[name].view(np.uint32), o[name].view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(d["g"].view(np.uint32), o["g_red"].astype(np.float32).view(np.uint32), err_msg="g")
+        np.testing.assert_array_equal(d["H"].view(np.uint32), o["H_red"].astype(np.float32).view(np.uint32), err_msg="H")
+    mpc.close()
+
+
+@pytest.mark.parametrize("gait,hand,nb,seed", [("standing", "contact", 32, 5), ("walking", "window", 32, 6),
+                                               ("mixed", "contact", 24, 8)])
+def test_forces_match_qpoases_3c(oracle, gait, hand, nb, seed):
+    f = synthetic.make_batch3(nb, H, gait, seed=seed, hand=hand, phase="random")
+    rec = records.pack_records(f, H, 3)
+    ref = oracle.solve_records(rec, H, synthetic.DT_MPC, synthetic.F_MAX, nc=3)
+    assert ref["n_bad"] == 0
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb, contacts=3)
+    mpc.upload(rec)
+    mpc.solve()
+    forces, status = mpc.download()
+    x64, obj64 = mpc.download_f64()
+    mpc.close()
+    assert forces.shape == (nb, 180)
+    assert (interface.status_code(status) == 0).all(), interface.status_code(status)
+    q = ref["q_soln"]
+    assert rel_inf(forces.astype(np.float64), q).max() < TOL
+    assert rel_inf(x64, q).max() < 1e-6
+    assert np.all(forces[q == 0.0] == 0.0)
+    og = np.abs(obj64 - ref["obj"]) / np.maximum(1.0, np.abs(ref["obj"]))
+    assert og.max() < TOL, og.max()
+
+
+def test_hand_off_equals_two_contact_kernel():
+    nb = 16
+    f3 = synthetic.make_batch3(nb, H, "walking", seed=31, hand="off", phase="random")
+    f2 = synthetic.make_batch(nb, H, "walking", seed=31, phase="random")
+    m3 = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb, contacts=3)
+    m2 = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb)
+    m3.upload_fields(f3)
+    m2.upload_fields(f2)
+    m3.solve()
+    m2.solve()
+    q3, s3 = m3.download()
+    q2, s2 = m2.download()
+    m3.close()
+    m2.close()
+    assert (interface.status_code(s3) == 0).all() and (interface.status_code(s2) == 0).all()
+    q3 = q3.reshape(nb, H, 18)
+    # same QP data bit for bit; the two kernels differ only in workgroup shape (reduction partitioning), so the
+    # binary64 solves agree to round-off and the float32 outputs almost always bit for bit
+    np.testing.assert_allclose(q3[:, :, [0, 1, 2, 3, 4, 5, 9, 10, 11, 12, 13, 14]], q2.reshape(nb, H, 12), rtol=1e-6,
+                               atol=1e-6)
+    assert (q3[:, :, [6, 7, 8, 15, 16, 17]] == 0).all()
+
+
+def test_config5_full_batch(oracle):
+    """BASELINE.json configs[4]: batch 1024, every instance 180 x 240; all solved, a sample checked against qpOASES."""
+    c = dict(synthetic.CONFIG5)
+    nb = c.pop("batch")
+    f = synthetic.make_batch3(nb, **c)
+    rec = records.pack_records(f, H, 3)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb, contacts=3)
+    mpc.upload(rec)
+    mpc.solve()
+    forces, status = mpc.download()
+    ms = mpc.time_solve(3)
+    mpc.close()
+    assert (interface.status_code(status) == 0).all(), np.bincount(interface.status_code(status))
+    idx = np.arange(0, nb, 64)
+    ref = oracle.solve_records(rec[idx], H, synthetic.DT_MPC, synthetic.F_MAX, nc=3)
+    assert rel_inf(forces[idx].astype(np.float64), ref["q_soln"]).max() < TOL
+    print(f"config5: {nb / ms * 1e3:.0f} solves/s ({ms:.3f} ms per launch)")
