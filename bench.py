@@ -270,6 +270,18 @@ def main() -> None:
                 extra[name] = {"solves_per_s": bb / (ms2 * 1e-3), "kernel_ms": ms2,
                                "failed": int((interface.status_code(st2) != 0).sum())}
                 m2.close()
+            # BASELINE configs[4]: two feet + hand, 180 variables x 240 rows (the three-contact extension)
+            for name, bb in (("cfg5_3contact_180x240_b2048_per_gpu", 2048), ("cfg5_3contact_180x240_b8192", 8192)):
+                f3 = synthetic.make_batch3(bb, 10, "standing", seed=5, hand="contact")
+                m3 = interface.BatchedMPC(synthetic.DT_MPC, 10, synthetic.F_MAX, bb, device=local_rank, contacts=3)
+                m3.upload(records.pack_records(f3, 10, 3))
+                m3.solve(stream)
+                torch.cuda.synchronize()
+                ms3 = m3.time_solve(5, stream)
+                _, st3 = m3.download()
+                extra[name] = {"solves_per_s": bb / (ms3 * 1e-3), "kernel_ms": ms3,
+                               "failed": int((interface.status_code(st3) != 0).sum())}
+                m3.close()
         except Exception as exc:  # never let the side measurements break the headline line
             extra["error"] = repr(exc)
         out["other_configs"] = extra

@@ -160,8 +160,8 @@ CONFIGS = {
     "cfg4_h20_single_4096": dict(batch=4096, horizon=20, gait="single", seed=4, phase="random"),
     "metric_2contact_1024": dict(batch=1024, horizon=10, gait="standing", seed=6),
 }
-# BASELINE config 5 (extension: make_batch3 arguments)
-CONFIG5 = dict(batch=1024, horizon=10, gait="standing", seed=5, hand="contact")
+# BASELINE config 5 (extension: make_batch3 arguments); 8192 instances = 2048 per GPU on 4 GPUs
+CONFIG5 = dict(batch=8192, horizon=10, gait="standing", seed=5, hand="contact")
 
 
 def rotation_world_to_body(q):

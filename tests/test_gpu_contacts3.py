@@ -81,7 +81,8 @@ def test_hand_off_equals_two_contact_kernel():
 
 
 def test_config5_full_batch(oracle):
-    """BASELINE.json configs[4]: batch 1024, every instance 180 x 240; all solved, a sample checked against qpOASES."""
+    """BASELINE.json configs[4]: batch 8192 (here on one GPU), every instance 180 x 240; all solved, a sample checked
+    against qpOASES."""
     c = dict(synthetic.CONFIG5)
     nb = c.pop("batch")
     f = synthetic.make_batch3(nb, **c)
@@ -93,7 +94,7 @@ def test_config5_full_batch(oracle):
     ms = mpc.time_solve(3)
     mpc.close()
     assert (interface.status_code(status) == 0).all(), np.bincount(interface.status_code(status))
-    idx = np.arange(0, nb, 64)
+    idx = np.arange(0, nb, 256)
     ref = oracle.solve_records(rec[idx], H, synthetic.DT_MPC, synthetic.F_MAX, nc=3)
     assert rel_inf(forces[idx].astype(np.float64), ref["q_soln"]).max() < TOL
     print(f"config5: {nb / ms * 1e3:.0f} solves/s ({ms:.3f} ms per launch)")
