@@ -88,6 +88,8 @@ struct hmpc_handle {
   int *d_dbg_i;
   long long *d_prof;
   int warm;        // block warm start of the working set (default on)
+  signed char *d_wset;  // working sets carried from tick to tick (hmpc_set_tick_warm_start), [max_batch][8 nc h]
+  int tick_warm, tick_shift;
   int auto_resolve;  // hmpc_download re-solves flagged instances with the safe variant (default on)
   int max_stance;  // max reduced variables of the current batch (known only for host-uploaded records; else -1)
   hipStream_t last_stream;
@@ -145,6 +147,8 @@ static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int db
   a.prof = h->d_prof;
   a.warm = h->warm;
   a.index_list = d_index_list;
+  a.wset = (h->tick_warm && !assemble_only) ? h->d_wset : nullptr;
+  a.wset_shift = h->tick_shift;
   const int grid = assemble_only ? 1 : (d_index_list ? n_list : h->batch);
   hipLaunchKernelGGL(fn, dim3(grid), dim3(v.nt), v.smem, stream, a);
   HIP_TRY(hipGetLastError());
@@ -257,6 +261,7 @@ int hmpc_destroy(hmpc_handle *h) {
   if (h->d_dbg_f) hipFree(h->d_dbg_f);
   if (h->d_dbg_i) hipFree(h->d_dbg_i);
   if (h->d_prof) hipFree(h->d_prof);
+  if (h->d_wset) hipFree(h->d_wset);
   delete h;
   return HMPC_OK;
 }
@@ -313,6 +318,28 @@ int hmpc_set_auto_resolve(hmpc_handle *h, int on) {
 int hmpc_set_warm_start(hmpc_handle *h, int on) {
   if (!h) return HMPC_E_ARG;
   h->warm = on ? 1 : 0;
+  return HMPC_OK;
+}
+
+int hmpc_set_tick_warm_start(hmpc_handle *h, int on, int horizon_shift) {
+  if (!h || horizon_shift < 0) return HMPC_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  if (on && !h->d_wset) {
+    const size_t nb = (size_t)h->max_batch * 8 * h->nc * h->setup.horizon;
+    HIP_TRY(hipMalloc(&h->d_wset, nb));
+    HIP_TRY(hipMemset(h->d_wset, 0, nb));
+  }
+  h->tick_warm = on ? 1 : 0;
+  h->tick_shift = horizon_shift;
+  return HMPC_OK;
+}
+
+int hmpc_reset_tick_warm_start(hmpc_handle *h) {
+  if (!h) return HMPC_E_ARG;
+  if (!h->d_wset) return HMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
+  HIP_TRY(hipMemset(h->d_wset, 0, (size_t)h->max_batch * 8 * h->nc * h->setup.horizon));
   return HMPC_OK;
 }
 

@@ -40,6 +40,12 @@ struct KernelArgs {
   long long *prof;  // optional [batch][NPROF] per-phase shader-clock cycles (thread 0's view), profiling builds only
   const int *index_list;  // optional: workgroup b solves instance index_list[b] (re-solve of flagged instances)
   int warm;         // 1: block warm start of the working set (default), 0: cold start as the reference does
+  // warm start across ticks (the reference cold-starts, SolverMPC.cpp:702): per instance the
+  // final working set of the previous solve, one signed byte per ORIGINAL constraint row (8 nc h; +1 lower side,
+  // -1 upper side, 0 inactive).  Read at the start (rows of step i are taken from saved step min(i + wset_shift, h-1)),
+  // overwritten at the end.  nullptr = off.
+  signed char *wset;
+  int wset_shift;
 };
 constexpr int NPROF = 24;
 enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A };
@@ -88,7 +94,7 @@ struct Smem {
   unsigned char vstep[NMAX], vcomp[NMAX];  // reference-order reduced variable -> horizon step, component (0..11)
   unsigned char o2s[NMAX], s2o[NMAX];      // reference order <-> sweep order (leg-step major)
   unsigned char rmap[U * HMAX];            // original variable U*step+comp -> sweep index (255 = eliminated)
-  unsigned char ls_leg[NG];
+  unsigned char ls_leg[NG], ls_step[NG];
   int n, m, nls, pad0;
 
   struct Asm {
@@ -444,6 +450,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
           S.rmap[U * i + 3 * NC + 3 * leg + k] = (unsigned char)(GS * e + 3 + k);
           if (k == 0) {
             S.ls_leg[e] = (unsigned char)leg;
+            S.ls_step[e] = (unsigned char)i;
             S.ub7[e] = (double)(fz_cap(leg) * (float)gait[NC * i + leg]);
           }
         }
@@ -937,19 +944,41 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
     double raw = INF;
     int side = 1;
     bool take = false;
-    if (is_c && c_rr >= 4 && c_rr <= 6) take = my_slack(Q.xu, side, raw) < -FEAS_TOL;
-    const unsigned long long bal = __ballot(take);
-    const int below = __popcll(bal & ((1ull << ln) - 1ull));
-    if (ln == 0) Q.wcount[wv] = __popcll(bal);
-    __syncthreads();
-    int base = 0, k0 = 0;
+    bool tick = false;  // the candidates come from the previous tick's working set (any of the 8 rows of a leg-step)
+    int base = 0, k0 = 0, below = 0;
+    auto count_candidates = [&]() {
+      const unsigned long long bal = __ballot(take);
+      below = __popcll(bal & ((1ull << ln) - 1ull));
+      if (ln == 0) Q.wcount[wv] = __popcll(bal);
+      __syncthreads();
+      base = 0, k0 = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const int cw = Q.wcount[w];
-      base += (w < wv) ? cw : 0;
-      k0 += cw;
+      for (int w = 0; w < NW; ++w) {
+        const int cw = Q.wcount[w];
+        base += (w < wv) ? cw : 0;
+        k0 += cw;
+      }
+      k0 = uni(k0);
+    };
+    if (args.wset) {
+      if (is_c) {
+        int st = (int)S.ls_step[c_e] + args.wset_shift;
+        st = st < h ? st : h - 1;
+        const int sv = (int)args.wset[(size_t)inst * C8 * h + C8 * st + 8 * (int)S.ls_leg[c_e] + c_rr];
+        take = sv != 0;
+        side = sv > 0 ? 1 : -1;
+      }
+      count_candidates();
+      tick = k0 > 0;
+      if (!tick) __syncthreads();  // wcount is rewritten below
     }
-    k0 = uni(k0);
+    if (!tick) {  // uniform.  Rows 4-6 violated at the unconstrained minimiser
+      take = false;
+      if (is_c && c_rr >= 4 && c_rr <= 6) take = my_slack(Q.xu, side, raw) < -FEAS_TOL;
+      count_candidates();
+    }
+    const int rlo = tick ? 0 : 4, rhi = tick ? 7 : 6;
+    bool bad_start = false;
     constexpr int EPT = 5;  // packed-triangle entries per thread during the Schur inversion
     constexpr int KBMAX = (NT >= 512) ? 71 : ((NT >= 256) ? 45 : 34);  // KBMAX(KBMAX+1)/2 <= EPT*NT
     static_assert(KBMAX * (KBMAX + 1) / 2 <= EPT * NT && KBMAX <= SM::QMAX, "block start capacity");
@@ -968,7 +997,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
         const unsigned long long am1 = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * e1]);
         if (am0 != 0ull && am1 != 0ull) {
           const int leg0 = S.ls_leg[e0], leg1 = S.ls_leg[e1];
-          for (int r1 = 4; r1 <= 6; ++r1) {
+          for (int r1 = rlo; r1 <= rhi; ++r1) {
             const int ac1 = (int)(signed char)((am1 >> (8 * r1)) & 0xff);
             if (ac1 == 0) continue;
             double cn1[GS], t6[GS];
@@ -977,7 +1006,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
             if (diag) blk_sym(cn1, t6);
             else blk_rows(cn1, t6);
             const int s1 = Q.slot[8 * e1 + r1];
-            for (int r0 = 4; r0 <= (diag ? r1 : 6); ++r0) {
+            for (int r0 = rlo; r0 <= (diag ? r1 : rhi); ++r0) {
               const int ac0 = (int)(signed char)((am0 >> (8 * r0)) & 0xff);
               if (ac0 == 0) continue;
               double v = 0.0;
@@ -996,6 +1025,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
       {
         const int npair = k0 * (k0 + 1) / 2;
         const int nept = (npair + NT - 1) / NT;
+        bad_start = false;
         double er[EPT];
         int ei[EPT], ej[EPT];
 #pragma unroll
@@ -1023,6 +1053,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
           const double *cs = (s & 1) ? cb1 : cb0;
           double *cn = (s & 1) ? cb0 : cb1;
           const double dv = cs[s];
+          bad_start = bad_start || !(dv > 1e-7);  // a pivot of a positive definite Schur matrix is >= ~2e-3 |n|^2
           double idv = __builtin_amdgcn_rcp(dv);
           idv = dfma(dfma(-dv, idv, 1.0), idv, idv);
           idv = dfma(dfma(-dv, idv, 1.0), idv, idv);
@@ -1045,6 +1076,14 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
       }
       q = k0;
       PROF_MARK(P_B_INV);
+      if (ub(bad_start)) {
+        // only possible for a working set inherited from the previous tick whose rows have become (nearly) dependent
+        // under this tick's data: forget it and start from the empty set
+        for (int t = tid; t < SM::MMAX; t += NT) Q.act[t] = 0, Q.slot[t] = 0;
+        q = 0;
+        __syncthreads();
+      }
+      if (q > 0) {
       // (d) multipliers u = E (b - N x_u); rows with a negative multiplier do not belong to the working set: remove the
       //     most negative one, update E by the Schur complement, repeat
       active_residual(Q.xu);
@@ -1085,6 +1124,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
         rmatvec(Q.w);
         if (is_v) Q.x[tid] = Q.xu[tid] + Q.z[tid];
         __syncthreads();
+      }
       }
     }
   }
@@ -1319,6 +1359,16 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
     const double xv = (rmp == 255) ? 0.0 : Q.x[rmp];
     args.forces[(size_t)inst * U * h + t] = (float)xv;
     if (args.x64) args.x64[(size_t)inst * U * h + t] = xv;
+  }
+  if (args.wset) {
+    // the final working set in original row numbering (rows of eliminated leg-steps and failed solves: 0)
+    for (int t = tid; t < C8 * h; t += NT) {
+      const int st = t / C8, cc = (t % C8) >> 3, rr = t & 7;
+      const int rmp = S.rmap[U * st + 3 * cc];
+      signed char av = 0;
+      if (rmp != 255 && code == S_OK) av = Q.act[8 * (rmp / GS) + rr];
+      args.wset[(size_t)inst * C8 * h + t] = av;
+    }
   }
   if (tid == 0) {
     args.status[inst] = (uint32_t)code | ((uint32_t)(iters & 0xfff) << 8) | ((uint32_t)(q & 0xfff) << 20);

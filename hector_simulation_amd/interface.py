@@ -112,6 +112,14 @@ class BatchedMPC:
     def set_warm_start(self, on: bool) -> None:
         _check(self.L.hmpc_set_warm_start(self.h, 1 if on else 0), "hmpc_set_warm_start")
 
+    def set_tick_warm_start(self, on: bool, horizon_shift: int = 0) -> None:
+        """Carry each instance's final working set to the next solve of this handle (off by default: the reference
+        cold-starts every tick).  ``horizon_shift`` = steps the gait table advanced since the previous solve."""
+        _check(self.L.hmpc_set_tick_warm_start(self.h, 1 if on else 0, int(horizon_shift)), "hmpc_set_tick_warm_start")
+
+    def reset_tick_warm_start(self) -> None:
+        _check(self.L.hmpc_reset_tick_warm_start(self.h), "hmpc_reset_tick_warm_start")
+
     def set_auto_resolve(self, on: bool) -> None:
         _check(self.L.hmpc_set_auto_resolve(self.h, 1 if on else 0), "hmpc_set_auto_resolve")
 

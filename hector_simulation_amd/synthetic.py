@@ -106,6 +106,46 @@ def make_batch(batch: int, horizon: int = 10, gait: str = "walking", seed: int =
                 Alpha_K=np.tile(ALPHA, (b, 1)), traj=traj.reshape(b, 12 * h), gait=g)
 
 
+def rpy_from_quat(q):
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    return np.stack([np.arctan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y)),
+                     np.arcsin(np.clip(2 * (w * y - x * z), -1, 1)),
+                     np.arctan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z))], -1)
+
+
+def advance_tick(fields: dict, horizon: int, seed: int = 0, dt_tick: float = 0.005, noise: float = 1.0) -> dict:
+    """The same instances one MPC tick later (the reference re-solves every 5 ms, ConvexMPCLocomotion.cpp:277, while
+    a horizon step is 40 ms): the body moved by v dt and rotated by w dt, velocities drifted, the stance feet stayed
+    where they were in the world (so r shrinks by the body motion), the joints crept, and the reference trajectory
+    is re-anchored at the new position exactly as ``make_batch`` builds it.  Gait table unchanged (replace
+    ``out["gait"]`` to model a phase advance).  Used to exercise the warm start across ticks."""
+    rng = np.random.default_rng(seed + 104729)
+    b, h = np.asarray(fields["p"]).shape[0], horizon
+    nz = lambda sc, *sh: noise * sc * rng.standard_normal((b,) + sh)
+    out = {k: np.array(v, copy=True) for k, v in fields.items()}
+    dp = fields["v"] * dt_tick
+    out["p"] = fields["p"] + dp
+    out["v"] = fields["v"] + nz(0.02, 3)
+    out["w"] = fields["w"] + nz(0.03, 3)
+    rpy = rpy_from_quat(np.asarray(fields["q"], dtype=np.float64)) + fields["w"] * dt_tick + nz(5e-4, 3)
+    out["q"] = quat_from_rpy(rpy[:, 0], rpy[:, 1], rpy[:, 2])
+    out["yaw"] = rpy[:, 2]
+    nc = np.asarray(fields["r"]).shape[1] // 3
+    out["r"] = (np.asarray(fields["r"]).reshape(b, 3, nc) - dp[:, :, None]).reshape(b, 3 * nc)
+    out["joint_angles"] = fields["joint_angles"] + nz(2e-3, 10)
+    old = np.asarray(fields["traj"]).reshape(b, h, 12)
+    traj = old.copy()
+    vx = old[:, 0, 9]
+    traj[:, 0, 0:3] = rpy
+    traj[:, 0, 3:6] = out["p"]
+    traj[:, :, 3] = out["p"][:, 0:1] + np.arange(h)[None, :] * DT_MPC * vx[:, None]
+    traj[:, 1:, 4] = out["p"][:, 1:2]
+    if np.any(old[:, :, 8] != 0):
+        traj[:, 1:, 2] = rpy[:, 2:3] + np.arange(1, h)[None, :] * DT_MPC * old[:, 1:, 8]
+    out["traj"] = traj.reshape(b, 12 * h)
+    return out
+
+
 ALPHA3 = np.array([1e-4, 1e-4, 5e-4] * 3 + [1e-2] * 9, dtype=np.float64)
 F_MAX_HAND = 150.0
 

@@ -139,6 +139,16 @@ int hmpc_set_max_reduced_vars(hmpc_handle *h, int n_reduced);
  * unconstrained minimiser enters at once (block warm start); on = 0: cold start from the empty set, one row per
  * iteration, as the reference's qpOASES call does.  Same optimum either way (strictly convex QP). */
 int hmpc_set_warm_start(hmpc_handle *h, int on);
+/* Warm start ACROSS ticks (the reference cold-starts every tick, SolverMPC.cpp:702).
+ * Default off.  When on, every solve leaves each instance's final working set in HBM (one signed byte per constraint
+ * row) and the next solve of the same handle starts instance k from the set instance k ended with: its Schur matrix
+ * is formed and inverted at once, rows whose multiplier comes out negative are released, and the dual active-set
+ * iteration continues from there.  horizon_shift = how many horizon steps the gait table advanced between the two
+ * solves (rows of step i start from saved step i + shift).  Same optimum as a cold start (the QP is strictly convex);
+ * only the iteration count changes.  A saved set that has become rank deficient under the new data is discarded for
+ * that instance.  hmpc_reset_tick_warm_start forgets all saved sets (e.g. before an unrelated batch). */
+int hmpc_set_tick_warm_start(hmpc_handle *h, int on, int horizon_shift);
+int hmpc_reset_tick_warm_start(hmpc_handle *h);
 /* Safe pass: waits for the last solve, then re-solves every instance whose status is working-set-full / max-iter /
  * infeasible / KKT with the large-working-set kernel variant (capacity = number of variables: cannot overflow; cold
  * start) and overwrites its forces and status in place.  *n_resolved (may be NULL) = how many were re-solved.

@@ -1,0 +1,127 @@
+"""Warm start across ticks.  The reference cold-starts every tick (SolverMPC.cpp:702), so
+the feature is off by default; when on it must return the same optimum (strictly convex QP -> unique) in fewer
+active-set iterations.  Checked against qpOASES on the second and third tick of synthetic tick sequences."""
+import numpy as np
+import pytest
+
+from hector_simulation_amd import interface, records, synthetic
+
+pytestmark = pytest.mark.gpu
+H = 10
+TOL = 1e-4
+
+
+def rel_inf(a, b):
+    return np.abs(a - b).max(axis=1) / np.maximum(1.0, np.abs(b).max(axis=1))
+
+
+def _sequence(gait, nb, seed, nticks, **kw):
+    f = synthetic.make_batch(nb, H, gait, seed=seed, **kw)
+    seq = [f]
+    for t in range(1, nticks):
+        seq.append(synthetic.advance_tick(seq[-1], H, seed=seed + t))
+    return seq
+
+
+@pytest.mark.parametrize("gait,kw", [("standing", {}), ("mixed", dict(phase="random")), ("walking", dict(phase="random"))])
+def test_tick_warm_start_same_optimum_fewer_iterations(oracle, gait, kw):
+    nb = 96
+    seq = _sequence(gait, nb, 40, 3, **kw)
+    cold = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb)
+    warm = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb)
+    warm.set_tick_warm_start(True)
+    it_cold, it_warm = [], []
+    for t, f in enumerate(seq):
+        rec = records.pack_records(f, H)
+        ref = oracle.solve_records(rec, H, synthetic.DT_MPC, synthetic.F_MAX)
+        assert ref["n_bad"] == 0
+        out = []
+        for mpc in (cold, warm):
+            mpc.upload(rec)
+            mpc.solve()
+            forces, status = mpc.download()
+            assert (interface.status_code(status) == 0).all(), (t, interface.status_code(status))
+            assert rel_inf(forces.astype(np.float64), ref["q_soln"]).max() < TOL
+            out.append(interface.status_iters(status))
+        it_cold.append(out[0])
+        it_warm.append(out[1])
+    # first tick: nothing saved yet -> identical path
+    np.testing.assert_array_equal(it_cold[0], it_warm[0])
+    # later ticks: the inherited working set is (nearly) the final one
+    for t in (1, 2):
+        assert it_warm[t].sum() < 0.5 * max(1, it_cold[t].sum()), (t, it_warm[t].sum(), it_cold[t].sum())
+    cold.close()
+    warm.close()
+
+
+def test_tick_warm_start_with_gait_phase_advance(oracle):
+    """The gait table advances by one horizon step between the two solves: saved rows are shifted by one step, rows of
+    leg-steps that left / entered stance are dropped / start empty."""
+    nb = 64
+    f0 = synthetic.make_batch(nb, H, "walking", seed=50, phase=3)
+    f1 = synthetic.advance_tick(f0, H, seed=51)
+    f1["gait"] = synthetic.make_batch(nb, H, "walking", seed=50, phase=4)["gait"]
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb)
+    mpc.set_tick_warm_start(True, horizon_shift=0)
+    mpc.upload_fields(f0)
+    mpc.solve()
+    mpc.download()
+    mpc.set_tick_warm_start(True, horizon_shift=1)
+    rec1 = records.pack_records(f1, H)
+    mpc.upload(rec1)
+    mpc.solve()
+    forces, status = mpc.download()
+    ref = oracle.solve_records(rec1, H, synthetic.DT_MPC, synthetic.F_MAX)
+    assert (interface.status_code(status) == 0).all()
+    assert rel_inf(forces.astype(np.float64), ref["q_soln"]).max() < TOL
+    mpc.close()
+
+
+def test_tick_warm_start_survives_unrelated_batch(oracle):
+    """Saved sets that do not fit the new data at all (a different random batch) must cost iterations, never accuracy;
+    reset_tick_warm_start restores the cold path exactly."""
+    nb = 64
+    a = records.pack_records(synthetic.make_batch(nb, H, "standing", seed=60), H)
+    b = records.pack_records(synthetic.make_batch(nb, H, "mixed", seed=61, phase="random"), H)
+    ref = oracle.solve_records(b, H, synthetic.DT_MPC, synthetic.F_MAX)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb)
+    mpc.set_tick_warm_start(True)
+    mpc.upload(a)
+    mpc.solve()
+    mpc.download()
+    mpc.upload(b)
+    mpc.solve()
+    forces, status = mpc.download()
+    assert (interface.status_code(status) == 0).all()
+    assert rel_inf(forces.astype(np.float64), ref["q_soln"]).max() < TOL
+    mpc.reset_tick_warm_start()
+    mpc.upload(b)
+    mpc.solve()
+    f2, s2 = mpc.download()
+    cold = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb)
+    cold.upload(b)
+    cold.solve()
+    f3, s3 = cold.download()
+    np.testing.assert_array_equal(f2, f3)
+    np.testing.assert_array_equal(s2, s3)
+    mpc.close()
+    cold.close()
+
+
+def test_tick_warm_start_three_contacts(oracle):
+    nb = 32
+    f0 = synthetic.make_batch3(nb, H, "standing", seed=70, hand="contact")
+    f1 = synthetic.advance_tick(f0, H, seed=71)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb, contacts=3)
+    mpc.set_tick_warm_start(True)
+    mpc.upload_fields(f0)
+    mpc.solve()
+    _, s0 = mpc.download()
+    rec1 = records.pack_records(f1, H, 3)
+    mpc.upload(rec1)
+    mpc.solve()
+    forces, s1 = mpc.download()
+    ref = oracle.solve_records(rec1, H, synthetic.DT_MPC, synthetic.F_MAX, nc=3)
+    assert (interface.status_code(s1) == 0).all()
+    assert rel_inf(forces.astype(np.float64), ref["q_soln"]).max() < TOL
+    assert interface.status_iters(s1).sum() < 0.5 * interface.status_iters(s0).sum()
