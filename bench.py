@@ -282,6 +282,27 @@ def main() -> None:
                 extra[name] = {"solves_per_s": bb / (ms3 * 1e-3), "kernel_ms": ms3,
                                "failed": int((interface.status_code(st3) != 0).sum())}
                 m3.close()
+            # warm start across ticks (off in the headline): second tick of a synthetic tick pair, each timed launch
+            # starts from the sets the FIRST tick left (the sequence is replayed per repetition)
+            rec1 = records.pack_records(synthetic.advance_tick(fields, h, seed=7 + 1000 * rank), h)
+            rec0 = rec
+            mt = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, B, device=local_rank)
+            res = {}
+            for mode in ("cold", "tick_warm"):
+                mt.set_tick_warm_start(mode == "tick_warm")
+                tms = []
+                for _ in range(4):
+                    mt.upload(rec0)
+                    mt.solve(stream)
+                    torch.cuda.synchronize()
+                    mt.upload(rec1)
+                    tms.append(mt.time_solve(1, stream))
+                _, stt = mt.download()
+                res[mode] = {"solves_per_s": B / (min(tms) * 1e-3), "kernel_ms": min(tms),
+                             "iters_mean": float(interface.status_iters(stt).mean()),
+                             "failed": int((interface.status_code(stt) != 0).sum())}
+            mt.close()
+            extra["second_tick_%s_b%d" % (args.gait, B)] = res
         except Exception as exc:  # never let the side measurements break the headline line
             extra["error"] = repr(exc)
         out["other_configs"] = extra
