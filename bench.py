@@ -42,7 +42,8 @@ def cpu_worker(path: str, horizon: int, first: int, count: int) -> None:
     r = oracle_py.solve_records(rec, horizon, synthetic.DT_MPC, synthetic.F_MAX, first=first, count=count)
     t1 = time.perf_counter()
     print(json.dumps(dict(count=count, wall=t1 - t0, t_assemble=r["t_assemble"], t_solve=r["t_solve"],
-                          n_bad=int(r["n_bad"]), nwsr_med=float(np.median(r["nwsr"])), nwsr_max=int(r["nwsr"].max()))))
+                          n_bad=int(r["n_bad"]), nwsr_med=float(np.median(r["nwsr"])), nwsr_max=int(r["nwsr"].max()),
+                          nwsr_hist=np.bincount(np.minimum(r["nwsr"] // 10, 9), minlength=10).tolist())))
 
 
 def cpu_baseline(rec: np.ndarray, horizon: int, per_core: int) -> dict:
@@ -71,6 +72,7 @@ def cpu_baseline(rec: np.ndarray, horizon: int, per_core: int) -> dict:
                 single_core_value=per_core / max(r["t_assemble"] + r["t_solve"] for r in res),
                 assemble_ms=1e3 * t_asm / total, solve_ms=1e3 * t_sol / total,
                 nwsr_median=float(np.median([r["nwsr_med"] for r in res])), nwsr_max=max(r["nwsr_max"] for r in res),
+                nwsr_hist_by_10=np.sum([r["nwsr_hist"] for r in res], axis=0).tolist(),  # bins [0,10) .. [90,inf)
                 n_failed=sum(r["n_bad"] for r in res), wall_s=wall)
 
 
@@ -138,6 +140,8 @@ def main() -> None:
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--gait", default="standing", help="standing = the metric's 2-contact case")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="wrench", choices=["wrench", "full"],
+                    help="N>1: what the ranks all_gather per solve (wrench = step-0 wrench + status, SURVEY 8e)")
     ap.add_argument("--cpu-per-core", type=int, default=384)
     ap.add_argument("--path", default="solve", choices=["solve", "builder"],
                     help="solve = the metric (default); builder = rows f1-f3 only (record builder + wrench kernels)")
@@ -180,13 +184,24 @@ def main() -> None:
     mpc.set_device_outputs(d_forces.data_ptr(), d_status.data_ptr(), keepalive=(d_forces, d_status))
     stream = torch.cuda.current_stream().cuda_stream
 
+    # the path's only exchange: all_gather of the step-0 wrenches + status words, posted after every
+    # solve on the communicator's stream so that it overlaps the next solve; --exchange full gathers all 12h forces
+    # synchronously instead
+    xch = sharding.WrenchExchange(B, 12, dev) if (world > 1 and args.exchange == "wrench") else None
+    nstep = [0]
+
     def step():
         mpc.solve(stream)
-        if world > 1:
-            sharding.gather_forces(d_forces, world * B)   # the path's only exchange: gather of solved forces
+        if xch is not None:
+            xch.post(nstep[0] & 1, d_forces, d_status)
+        elif world > 1:
+            sharding.gather_forces(d_forces, world * B)
+        nstep[0] += 1
 
     for _ in range(args.warmup):
         step()
+    if xch is not None:
+        xch.wait_all()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -196,6 +211,8 @@ def main() -> None:
     ev0.record()
     for _ in range(args.steps):
         step()
+    if xch is not None:
+        xch.wait_all()   # every posted exchange is complete inside the timed region
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -241,7 +258,9 @@ def main() -> None:
             "config": {"workload": f"{'2-contact standing' if args.gait == 'standing' else args.gait} randomized MPC ticks, "
                                    f"horizon {h}, reduced QP up to {n_red}x{n_red // 6 * 8}",
                        "batch_per_gpu": B, "global_batch": world * B, "horizon": h,
-                       "parallelism": f"batch shards x{world}, all_gather of forces" if world > 1 else "single GPU"},
+                       "parallelism": (f"batch shards x{world}, all_gather of "
+                                       f"{'step-0 wrench + status (overlapped with the next solve)' if xch is not None else 'all forces'}")
+                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "hmpc_kernel (fused assembly + QP solve)", "kernel_ms": kernel_ms,

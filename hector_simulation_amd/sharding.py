@@ -35,3 +35,57 @@ def gather_forces(local, global_batch: int, group=None):
     buf = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(buf, pad, group=group)
     return torch.cat([b[:s] for b, s in zip(buf, sizes)], dim=0)
+
+
+class WrenchExchange:
+    """The path's one exchange step as SURVEY.md section 8(e) defines it: every rank ends up with the step-0 wrench
+    (the 6*contacts floats the controller reads through ``get_solution(0..)``, ConvexMPCLocomotion.cpp:428-429) and
+    the status word of every instance of the global batch, in instance order.
+
+    One all_gather of a packed [shard, width+1] float32 block per solve (last column = the status word's bits), with
+    ``depth`` slots so that the collective of solve k runs on the communicator's stream while solve k+1 computes:
+    ``post(slot, forces, status)`` enqueues pack + all_gather without blocking, ``wait(slot)`` orders the caller's
+    stream (nccl) / the host (gloo) after it.  Equal shards only (the bench's weak-scaling layout); ragged batches use
+    ``gather_forces``."""
+
+    def __init__(self, shard: int, width: int, device, depth: int = 2, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.shard, self.width, self.depth = int(shard), int(width), int(depth)
+        self.local = [torch.zeros((shard, width + 1), dtype=torch.float32, device=device) for _ in range(depth)]
+        self.out = [torch.zeros((self.world * shard, width + 1), dtype=torch.float32, device=device) for _ in range(depth)]
+        self.work = [None] * depth
+
+    def post(self, slot: int, forces, status):
+        """forces [shard, >= width] float32 and status [shard] int32 of this rank, both on ``device``."""
+        import torch
+
+        self.wait(slot)  # the slot's buffers are free again only once its previous collective is done
+        loc = self.local[slot]
+        loc[:, : self.width].copy_(forces[:, : self.width])
+        loc.view(torch.int32)[:, self.width].copy_(status.view(torch.int32))
+        if self.world == 1:
+            self.out[slot].copy_(loc)
+            return
+        self.work[slot] = self.dist.all_gather_into_tensor(self.out[slot], loc, group=self.group, async_op=True)
+
+    def wait(self, slot: int):
+        w = self.work[slot]
+        if w is not None:
+            w.wait()
+            self.work[slot] = None
+
+    def wait_all(self):
+        for s in range(self.depth):
+            self.wait(s)
+
+    def result(self, slot: int):
+        """(wrench [global, width] float32, status [global] int32) gathered by the slot's last ``post``."""
+        import torch
+
+        self.wait(slot)
+        o = self.out[slot]
+        return o[:, : self.width], o.view(torch.int32)[:, self.width]

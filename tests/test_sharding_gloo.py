@@ -59,3 +59,42 @@ def test_two_rank_gather_matches_single_process(oracle, tmp_path, gb):
     got = np.load(path + ".out.npy")
     want = oracle.solve_records(rec, 10, synthetic.DT_MPC, synthetic.F_MAX)["q_soln"].astype(np.float32)
     np.testing.assert_array_equal(got, want)
+
+
+def _xch_worker(rank, world, port, shard, path):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    allf = torch.from_numpy(np.load(path))            # [steps, world*shard, 120]
+    xch = sharding.WrenchExchange(shard, 12, "cpu")
+    got = []
+    for k in range(allf.shape[0]):                    # pipelined exactly as bench.py posts it
+        mine = allf[k, rank * shard:(rank + 1) * shard]
+        status = (torch.arange(shard, dtype=torch.int32) + 1000 * rank + 100000 * k) | (1 << 30)
+        xch.post(k & 1, mine, status)
+        if k >= 1:
+            w, s = xch.result((k - 1) & 1)
+            got.append((w.clone(), s.clone()))
+    xch.wait_all()
+    w, s = xch.result((allf.shape[0] - 1) & 1)
+    got.append((w.clone(), s.clone()))
+    if rank == 1:
+        torch.save(got, path + ".xch.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_wrench_exchange_pipelined_two_ranks(tmp_path):
+    """The exchange bench.py runs for N > 1: step-0 wrench + status word of every instance on every rank, double
+    buffered (post k+1 while k is in flight)."""
+    steps, world, shard = 4, 2, 5
+    rng = np.random.default_rng(3)
+    allf = rng.standard_normal((steps, world * shard, 120)).astype(np.float32)
+    path = str(tmp_path / "f.npy")
+    np.save(path, allf)
+    mp.spawn(_xch_worker, args=(world, _free_port(), shard, path), nprocs=world, join=True)
+    got = torch.load(path + ".xch.pt")
+    assert len(got) == steps
+    for k, (w, s) in enumerate(got):
+        np.testing.assert_array_equal(w.numpy(), allf[k, :, :12])
+        want = np.concatenate([(np.arange(shard) + 1000 * r + 100000 * k) | (1 << 30) for r in range(world)])
+        np.testing.assert_array_equal(s.numpy(), want.astype(np.int32))
