@@ -21,6 +21,10 @@
 #pragma once
 #include <stdint.h>
 
+#ifndef HMPC_MFMA_SWEEP
+#define HMPC_MFMA_SWEEP 0  // 1: experimental panel-blocked inversion on the fp64 matrix cores (hmpc_sweep_mfma.h)
+#endif
+
 #include "hmpc_math.h"
 
 namespace hmpc {
@@ -47,7 +51,7 @@ struct KernelArgs {
   signed char *wset;
   int wset_shift;
 };
-constexpr int NPROF = 24;
+constexpr int NPROF = 32;
 enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A };
 #ifdef HMPC_PROFILE
 #define PROF_DECL long long _pt = clock64(), _pt0 = _pt; long long _pacc[NPROF] = {0}
@@ -197,6 +201,12 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) Rt[k * 3 + i] = R[i * 3 + k];
 }
+
+}  // namespace hmpc
+#if HMPC_MFMA_SWEEP
+#include "hmpc_sweep_mfma.h"
+#endif
+namespace hmpc {
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC = 2>
@@ -616,6 +626,9 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
   const bool diag = (e0 == e1);
   const int i0 = GS * e0, j0 = GS * e1;
   double a[GS][GS];
+#if HMPC_MFMA_SWEEP
+  sweep_mfma<NMAX, NT>(S, a, n, ng, tid, wv, ln, owner, e1, i0, j0, diag);
+#else
 #pragma unroll
   for (int ii = 0; ii < GS; ++ii)
 #pragma unroll
@@ -707,6 +720,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
   for (int ii = 1; ii < GS; ++ii)
 #pragma unroll
     for (int jj = 0; jj < ii; ++jj) a[ii][jj] = diag ? a[jj][ii] : a[ii][jj];
+#endif
   PROF_MARK(P_SWEEP);
 
   // ---- products with the register blocks --------------------------------------------------------------------------

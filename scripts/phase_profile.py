@@ -30,7 +30,7 @@ def main():
     mpc.upload(rec)
     mpc.solve()
     _, status = mpc.download()
-    cyc = np.zeros((nb, 24), dtype=np.int64)
+    cyc = np.zeros((nb, 32), dtype=np.int64)
     interface._check(mpc.L.hmpc_debug_phase_cycles(mpc.h, cyc.ctypes.data), "phase_cycles")
     it = interface.status_iters(status)
     mean = cyc.mean(axis=0)
