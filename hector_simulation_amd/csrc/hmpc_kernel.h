@@ -17,10 +17,13 @@
 //      multiplier comes out negative are removed again -> a valid Goldfarb-Idnani state, ~20 iterations saved.
 //   Q  dual active set (Goldfarb-Idnani, range-space form) from that state: Schur inverse E = (N M N')^-1 kept
 //      explicitly (bordering / Schur-complement downdates: no triangular solves), M applied in place from the register
-//      blocks with a fixed-order staged reduction (deterministic).  Two refinement steps of the multipliers at the end.
+//      blocks with a fixed-order staged reduction (deterministic).  One refinement step of the multipliers at the end (HMPC_REFINE).
 #pragma once
 #include <stdint.h>
 
+#ifndef HMPC_REFINE
+#define HMPC_REFINE 1  // corrections u += E (b_W - N_W x(u)) applied to the multipliers of the final working set
+#endif
 #ifndef HMPC_MFMA_SWEEP
 #define HMPC_MFMA_SWEEP 0  // 1: experimental panel-blocked inversion on the fp64 matrix cores (hmpc_sweep_mfma.h)
 #endif
@@ -1322,13 +1325,13 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
     if (pass > 0 && iters == iters_at_entry) break;  // the refined point is feasible: done
 
     // ---- refinement of the multipliers on the final working set: u += E (b_W - N_W x(u)), x(u) = x_u + M N_W' u ----
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it <= HMPC_REFINE; ++it) {
       gather_w(Q.u, 1.0, 0.0);
       __syncthreads();
       rmatvec(Q.w);
       if (is_v) Q.x[tid] = Q.xu[tid] + Q.z[tid];
       __syncthreads();
-      if (it == 2) break;
+      if (it == HMPC_REFINE) break;
       active_residual(Q.x);
       __syncthreads();
       double dmy = INF;
