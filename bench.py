@@ -55,6 +55,10 @@ def cpu_baseline(rec: np.ndarray, horizon: int, per_core: int) -> dict:
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "records.npy")
         np.save(path, rec[:total])
+        # P = 1: one process alone on the box (the reference's own operating point: one controller, one core)
+        solo_n = min(96, total)
+        solo = json.loads(subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(horizon),
+                                          "0", str(solo_n)], stdout=subprocess.PIPE, text=True).stdout.strip().splitlines()[-1])
         t0 = time.perf_counter()
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(horizon),
                                    str(c * per_core), str(per_core)], stdout=subprocess.PIPE, text=True)
@@ -69,7 +73,9 @@ def cpu_baseline(rec: np.ndarray, horizon: int, per_core: int) -> dict:
                 sample=f"{total} of the bench's 2-contact h={horizon} instances ({per_core}/process x {cores} processes); "
                        f"oracle C restatement of the fp32 assembly + the reference's own vendored qpOASES 3.2.0 "
                        f"(oracle/_ref), setToMPC, cold start; prints removed",
-                single_core_value=per_core / max(r["t_assemble"] + r["t_solve"] for r in res),
+                single_process_alone_value=solo_n / (solo["t_assemble"] + solo["t_solve"]),
+                single_process_alone_ms={"assemble": 1e3 * solo["t_assemble"] / solo_n, "solve": 1e3 * solo["t_solve"] / solo_n},
+                per_process_value_under_full_load=per_core / max(r["t_assemble"] + r["t_solve"] for r in res),
                 assemble_ms=1e3 * t_asm / total, solve_ms=1e3 * t_sol / total,
                 nwsr_median=float(np.median([r["nwsr_med"] for r in res])), nwsr_max=max(r["nwsr_max"] for r in res),
                 nwsr_hist_by_10=np.sum([r["nwsr_hist"] for r in res], axis=0).tolist(),  # bins [0,10) .. [90,inf)
@@ -140,6 +146,8 @@ def main() -> None:
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--gait", default="standing", help="standing = the metric's 2-contact case")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="skip the other_configs side measurements (profiling runs: only the headline kernel launches)")
     ap.add_argument("--exchange", default="wrench", choices=["wrench", "full"],
                     help="N>1: what the ranks all_gather per solve (wrench = step-0 wrench + status, SURVEY 8e)")
     ap.add_argument("--cpu-per-core", type=int, default=384)
@@ -275,6 +283,8 @@ def main() -> None:
         # the other BASELINE.json shapes on the same kernel family, a few launches each (not the headline value)
         extra = {}
         try:
+            if args.no_side_configs:
+                raise StopIteration
             for name, gait2, hh, bb in (("cfg2_walking_b1024_fixed_phase", "walking", 10, 1024),
                                         ("metric_2contact_b1024", "standing", 10, 1024),
                                         ("cfg3_walking_sweep_b8192_per_gpu", "walking", 10, 8192),
@@ -322,6 +332,8 @@ def main() -> None:
                              "failed": int((interface.status_code(stt) != 0).sum())}
             mt.close()
             extra["second_tick_%s_b%d" % (args.gait, B)] = res
+        except StopIteration:
+            extra["skipped"] = True
         except Exception as exc:  # never let the side measurements break the headline line
             extra["error"] = repr(exc)
         out["other_configs"] = extra
