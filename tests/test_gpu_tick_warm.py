@@ -125,3 +125,34 @@ def test_tick_warm_start_three_contacts(oracle):
     assert (interface.status_code(s1) == 0).all()
     assert rel_inf(forces.astype(np.float64), ref["q_soln"]).max() < TOL
     assert interface.status_iters(s1).sum() < 0.5 * interface.status_iters(s0).sum()
+
+
+@pytest.mark.parametrize("gait", ["walking", "mixed"])
+def test_tick_warm_start_long_sequence_with_phase_advance(oracle, gait):
+    """Ten consecutive ticks; the gait table advances by one horizon step on every second tick (shift 1, else 0) and the
+    state drifts with 3x the nominal tick noise.  Every tick must match qpOASES and report ok."""
+    nb = 48
+    f = synthetic.make_batch(nb, H, gait, seed=80, phase=0)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb)
+    phase = 0
+    total_it = 0
+    for t in range(10):
+        shift = 0
+        if t > 0:
+            f = synthetic.advance_tick(f, H, seed=80 + t, noise=3.0)
+            if t % 2 == 0:
+                phase += 1
+                shift = 1
+                f["gait"] = synthetic.make_batch(nb, H, gait, seed=80, phase=phase)["gait"]
+        mpc.set_tick_warm_start(True, horizon_shift=shift)
+        rec = records.pack_records(f, H)
+        mpc.upload(rec)
+        mpc.solve()
+        forces, status = mpc.download()
+        ref = oracle.solve_records(rec, H, synthetic.DT_MPC, synthetic.F_MAX)
+        assert ref["n_bad"] == 0
+        assert (interface.status_code(status) == 0).all(), (t, interface.status_code(status))
+        assert rel_inf(forces.astype(np.float64), ref["q_soln"]).max() < TOL, t
+        total_it += int(interface.status_iters(status).sum())
+    mpc.close()
+    assert total_it > 0
