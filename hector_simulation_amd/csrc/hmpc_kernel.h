@@ -55,7 +55,7 @@ struct KernelArgs {
   int wset_shift;
 };
 constexpr int NPROF = 32;
-enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A };
+enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A, P_A0, P_A1, P_A2, P_G };
 #ifdef HMPC_PROFILE
 #define PROF_DECL long long _pt = clock64(), _pt0 = _pt; long long _pacc[NPROF] = {0}
 #define PROF_MARK(ph) do { long long _n = clock64(); _pacc[ph] += _n - _pt; _pt = _n; } while (0)
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
     for (int t = tid; t < nwords; t += NT) A.rec[t] = src[t];
   }
   __syncthreads();
+  PROF_MARK(P_A0);
   const float *rf = reinterpret_cast<const float *>(A.rec);
   const unsigned char *gait = reinterpret_cast<const unsigned char *>(A.rec + RL::NF + 12 * h);
   const float *in_p = rf + RL::P, *in_v = rf + RL::V, *in_q = rf + RL::Q, *in_w = rf + RL::W, *in_r = rf + RL::R,
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
     for (int t = tid; t < U * h; t += NT) S.rmap[t] = 255;
   }
   __syncthreads();
+  PROF_MARK(P_A1);
 
   // ---------------- A2: scalar algebra (RobotState.cpp:17-47, SolverMPC.cpp:65-89,302-331,420-433,488-548): body on a
   // lane of wave 0, one foot per lane of two other waves (different waves, so the three run concurrently)
@@ -473,6 +475,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
   // identity power
   for (int t = tid; t < 169; t += NT) A.Apow[t] = (t % 14 == 0) ? 1.0f : 0.0f;
   __syncthreads();
+  PROF_MARK(P_A2);
 
   const int n = uni(S.n), m = uni(S.m), ng = uni(S.nls);
   if (ng > NG) {  // uniform
@@ -489,34 +492,67 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
   // ---------------- A3/A4: Acd^k by repeated right-multiplication from the identity (SolverMPC.cpp:148-158), and from each
   // power as it appears: Phi_k = Acd^k Bcd (:161-178), SPhi = fl(w_s Phi) (B'S first, as B'*S*B evaluates left to right),
   // tracking error e_i = Acd^(i+1) x0 - X_d (:457-461, :570).  Only two powers are kept (ping-pong).
+  // The fmaf chains run over the structurally non-zero terms only, in ascending index order: a term whose factor is an
+  // exact structural zero (fl(dt*0), the off-diagonal zeros of the identity, the zero pattern of Acd^k) adds +-0 to the
+  // running sum, which leaves it bit for bit unchanged (HMPC-A1), so the result equals the dense 13-term chain.
+  //   Acd  = I + dt A_ct:  column j has its diagonal 1 and  rows 0..2 (j = 6..8),  row j-6 (j = 9..11),  row 11 (j = 12);
+  //   Bcd:                 column of a force component c has rows 6..8 and row 9+c, a moment column rows 6..8;
+  //   Acd^k:               row s has its diagonal and  columns 6..8 (s < 3),  s+6 (s = 3, 4),  11 and 12 (s = 5),  12 (s = 11).
+  // Every lane runs the same four-term chain; a lane with fewer live terms pads with a term whose factor is a
+  // structural zero (row 12 / row 0 of Acd, row 0 of Bcd, column 0 of Acd^k), so there is no divergence.
+  // The work items (an entry of the next power, of Phi_k, of e) and their operand addresses do not depend on k: they
+  // are set up once, so that a step of the loop is 8 LDS reads, 4 fmaf and the store(s) per item.
+  constexpr int NITEM = 169 + PS + 13, NTRIP = (NITEM + NT - 1) / NT;
+  int it_p[NTRIP][4];            // offsets of the four Acd^k factors inside the 13x13 power
+  const float *it_c[NTRIP][4];   // the four right-hand factors
+  int it_kind[NTRIP], it_out[NTRIP];
+#pragma unroll
+  for (int u = 0; u < NTRIP; ++u) {
+    const int t = tid + u * NT;
+    int row, cs, m0, m1, m2, m3, kind, out;
+    const float *cf;
+    if (t < 169) {
+      const int i = t / 13, j = t % 13, pad = (j == 12) ? 0 : 12;
+      const bool w3 = j >= 6 && j < 9;
+      row = i, cf = A.Acd + j, cs = 13, kind = 0, out = t;
+      m0 = w3 ? 0 : ((j >= 9 && j < 12) ? j - 6 : (j == 12 ? 11 : pad));
+      m1 = w3 ? 1 : pad, m2 = w3 ? 2 : pad, m3 = j;
+    } else if (t < 169 + PS) {
+      const int rem = t - 169, i = rem / U, j = rem % U;
+      row = i, cf = A.Bcd + j, cs = U, kind = 1, out = rem;
+      m0 = 6, m1 = 7, m2 = 8, m3 = (j < 3 * NC) ? 9 + j % 3 : 0;
+    } else {
+      const int s = (t < NITEM) ? t - (169 + PS) : 0;
+      row = s, cf = A.x0, cs = 1, kind = (t < NITEM) ? 2 : 3, out = s;
+      m0 = s;
+      m1 = (s < 3) ? 6 : ((s < 5) ? s + 6 : ((s == 5) ? 11 : ((s == 11) ? 12 : 0)));
+      m2 = (s < 3) ? 7 : ((s == 5) ? 12 : 0);
+      m3 = (s < 3) ? 8 : 0;
+    }
+    it_p[u][0] = row * 13 + m0, it_p[u][1] = row * 13 + m1, it_p[u][2] = row * 13 + m2, it_p[u][3] = row * 13 + m3;
+    it_c[u][0] = cf + m0 * cs, it_c[u][1] = cf + m1 * cs, it_c[u][2] = cf + m2 * cs, it_c[u][3] = cf + m3 * cs;
+    it_kind[u] = kind, it_out[u] = out;
+  }
   for (int k = 0; k <= h; ++k) {
     const float *Pk = A.Apow + (k & 1) * 169;
     float *Pn = A.Apow + ((k + 1) & 1) * 169;
-    for (int t = tid; t < 169 + PS + 13; t += NT) {
-      if (t < 169) {
+#pragma unroll
+    for (int u = 0; u < NTRIP; ++u) {
+      float acc = ffma(Pk[it_p[u][0]], *it_c[u][0], 0.0f);
+      acc = ffma(Pk[it_p[u][1]], *it_c[u][1], acc);
+      acc = ffma(Pk[it_p[u][2]], *it_c[u][2], acc);
+      acc = ffma(Pk[it_p[u][3]], *it_c[u][3], acc);
+      const int kind = it_kind[u], out = it_out[u];
+      if (kind == 0) {
+        if (k < h) Pn[out] = acc;
+      } else if (kind == 1) {
         if (k < h) {
-          const int i = t / 13, j = t % 13;
-          float acc = 0.0f;
-#pragma unroll
-          for (int mm = 0; mm < 13; ++mm) acc = ffma(Pk[i * 13 + mm], A.Acd[mm * 13 + j], acc);
-          Pn[t] = acc;
+          A.Phi[k * PS + out] = acc;
+          A.SPhi[k * PS + out] = A.W[out / U] * acc;
         }
-      } else if (t < 169 + PS) {
-        if (k < h) {
-          const int rem = t - 169, i = rem / U, j = rem % U;
-          float acc = 0.0f;
-#pragma unroll
-          for (int mm = 0; mm < 13; ++mm) acc = ffma(Pk[i * 13 + mm], A.Bcd[mm * U + j], acc);
-          A.Phi[k * PS + rem] = acc;
-          A.SPhi[k * PS + rem] = A.W[i] * acc;
-        }
-      } else if (k >= 1) {
-        const int s = t - (169 + PS), i = k - 1;
-        float acc = 0.0f;
-#pragma unroll
-        for (int mm = 0; mm < 13; ++mm) acc = ffma(Pk[s * 13 + mm], A.x0[mm], acc);
-        const float xd = (s < 12) ? in_traj[12 * i + s] : 0.0f;
-        A.e[13 * i + s] = acc - xd;
+      } else if (kind == 2 && k >= 1) {
+        const float xd = (out < 12) ? in_traj[12 * (k - 1) + out] : 0.0f;
+        A.e[13 * (k - 1) + out] = acc - xd;
       }
     }
     __syncthreads();
@@ -535,6 +571,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
     }
     S.g[S.o2s[tid]] = (double)(2.0f * acc);
   }
+  PROF_MARK(P_G);
   {
     // matrix cores: 16x16 output tiles over the reduced variables, K runs over (step i ascending, state row s ascending).
     // Rows of B_qp above the block diagonal are exact zeros, which are bitwise neutral in an fmaf chain started at +0,
@@ -544,35 +581,72 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
     const int nti = (n + 15) >> 4;
     const int ntiles = nti * (nti + 1) / 2;
     const int l15 = ln & 15, kq = ln >> 4;
-    for (int idx = wv; idx < ntiles; idx += NW) {
+    // Two tiles per pass (independent accumulators hide the MFMA dependency latency) and the operands of step i+1 are
+    // fetched while the matrix instructions of step i run.  A tile's steps before its first live one only add exact zeros.
+    struct Tile {
+      bool rav, cbv, live;
+      int sa, ca, sb, cc, I, J;
+    };
+    auto setup = [&](int idx, Tile &T) {
+      T.live = idx < ntiles;
       int J = 0;
       while ((J + 1) * (J + 2) / 2 <= idx) ++J;
-      const int I = idx - J * (J + 1) / 2;
-      const int ra = 16 * I + l15, cb = 16 * J + l15;
-      const bool rav = ra < n, cbv = cb < n;
-      const int sa = rav ? S.vstep[ra] : 0, ca = rav ? S.vcomp[ra] : 0;
-      const int sb = cbv ? S.vstep[cb] : 0, cc = cbv ? S.vcomp[cb] : 0;
-      const int istart = S.vstep[16 * J];
-      f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 2
-      for (int i = istart; i < h; ++i) {
-        const bool la = rav && i >= sa, lb = cbv && i >= sb;
-        const float *pa = A.SPhi + (la ? (i - sa) * PS + ca : 0) + kq * U;
-        const float *pb = A.Phi + (lb ? (i - sb) * PS + cc : 0) + kq * U;
-        const float a0 = pa[0], a1 = pa[4 * U], a2 = pa[8 * U], b0 = pb[0], b1 = pb[4 * U], b2 = pb[8 * U];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la ? a0 : 0.0f, lb ? b0 : 0.0f, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la ? a1 : 0.0f, lb ? b1 : 0.0f, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la ? a2 : 0.0f, lb ? b2 : 0.0f, acc, 0, 0, 0);
+      T.J = J, T.I = idx - J * (J + 1) / 2;
+      const int ra = 16 * T.I + l15, cb = 16 * J + l15;
+      T.rav = T.live && ra < n, T.cbv = T.live && cb < n;
+      T.sa = T.rav ? S.vstep[ra] : 0, T.ca = T.rav ? S.vcomp[ra] : 0;
+      T.sb = T.cbv ? S.vstep[cb] : 0, T.cc = T.cbv ? S.vcomp[cb] : 0;
+    };
+    auto fetch = [&](const Tile &T, int i, float (&o)[6]) {
+      const bool la = T.rav && i >= T.sa, lb = T.cbv && i >= T.sb;
+      const float *pa = A.SPhi + (la ? (i - T.sa) * PS + T.ca : 0) + kq * U;
+      const float *pb = A.Phi + (lb ? (i - T.sb) * PS + T.cc : 0) + kq * U;
+      const float a0 = pa[0], a1 = pa[4 * U], a2 = pa[8 * U], b0 = pb[0], b1 = pb[4 * U], b2 = pb[8 * U];
+      o[0] = la ? a0 : 0.0f, o[1] = la ? a1 : 0.0f, o[2] = la ? a2 : 0.0f;
+      o[3] = lb ? b0 : 0.0f, o[4] = lb ? b1 : 0.0f, o[5] = lb ? b2 : 0.0f;
+    };
+    auto store = [&](const Tile &T, const f4 &acc) {
+      if (!T.live) return;
+      // alpha enters on the diagonal only: looked up (two dependent LDS reads) by the diagonal lanes of diagonal tiles
+      float al[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (T.I == T.J) {  // uniform
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int Rr = 16 * T.I + kq * 4 + rg;
+          if (kq * 4 + rg == l15 && Rr < n) al[rg] = in_al[S.vcomp[Rr]];
+        }
       }
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int Rr = 16 * I + kq * 4 + rg, Cc = 16 * J + l15;
-        if (Rr <= Cc && Cc < n) {
-          const float al = (Rr == Cc) ? in_al[S.vcomp[Rr]] : 0.0f;
-          const float hv = 2.0f * (acc[rg] + al);
-          A.Hs[hs_index<NMAX>(Rr, Cc)] = hv;
-        }
+        const int Rr = 16 * T.I + kq * 4 + rg, Cc = 16 * T.J + l15;
+        if (Rr <= Cc && Cc < n) A.Hs[hs_index<NMAX>(Rr, Cc)] = 2.0f * (acc[rg] + al[rg]);
       }
+    };
+    for (int idx = wv; idx < ntiles; idx += 2 * NW) {
+      Tile T0, T1;
+      setup(idx, T0);
+      setup(idx + NW, T1);
+      const int istart = S.vstep[16 * T0.J];  // the second tile lies further right: its first live step is not earlier
+      f4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+      float c0[6], c1[6], n0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, n1[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      fetch(T0, istart, c0);
+      fetch(T1, istart, c1);
+      for (int i = istart; i < h; ++i) {
+        if (i + 1 < h) {
+          fetch(T0, i + 1, n0);
+          fetch(T1, i + 1, n1);
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[0], c0[3], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[0], c1[3], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[1], c0[4], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[1], c1[4], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[2], c0[5], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[2], c1[5], acc1, 0, 0, 0);
+#pragma unroll
+        for (int q2 = 0; q2 < 6; ++q2) c0[q2] = n0[q2], c1[q2] = n1[q2];
+      }
+      store(T0, acc0);
+      store(T1, acc1);
     }
   }
   __syncthreads();

@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_assembly.py tests/test_gpu_contacts3.py tests/test_gpu_solve.py -m gpu -x -q 2>&1 | tail -8
+timeout 300 python scripts/phase_profile.py standing 10 2048 2>&1 | grep -E "asm|H\+g|TOTAL"
