@@ -332,6 +332,19 @@ def main() -> None:
                              "failed": int((interface.status_code(stt) != 0).sum())}
             mt.close()
             extra["second_tick_%s_b%d" % (args.gait, B)] = res
+            # the reference's own call sequence for ONE robot (setup_problem / update_problem_data / get_solution,
+            # ConvexMPCLocomotion.cpp:410-429): host-to-host latency of a blocking tick through the legacy interface
+            row = {k2: np.asarray(v2)[0] for k2, v2 in fields.items()}
+            lat = []
+            for rep in range(60):
+                tl0 = time.perf_counter()
+                interface.setup_problem(synthetic.DT_MPC, h, 0.25, synthetic.F_MAX)
+                interface.update_problem_data(row["p"], row["v"], row["q"], row["w"], row["r"], row["joint_angles"],
+                                              float(row["yaw"]), row["weights"], row["traj"], row["Alpha_K"], row["gait"])
+                u0 = [interface.get_solution(i2) for i2 in range(12)]
+                lat.append(time.perf_counter() - tl0)
+            extra["legacy_single_tick"] = {"median_ms": 1e3 * float(np.median(lat[10:])), "min_ms": 1e3 * float(min(lat[10:])),
+                                           "note": "blocking host call incl. H2D record, launch, D2H forces (ctypes overhead included)"}
         except StopIteration:
             extra["skipped"] = True
         except Exception as exc:  # never let the side measurements break the headline line
