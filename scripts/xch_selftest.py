@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Developer check: WrenchExchange on the nccl (RCCL) backend with two ranks sharing one GPU, if RCCL allows it."""
+"""Developer check: WrenchExchange on the nccl (RCCL) backend, one rank per GPU (RCCL refuses two ranks on one device,
+so this needs a node with at least two GPUs)."""
 import os
 import sys
 
@@ -13,10 +14,11 @@ from hector_simulation_amd import sharding  # noqa: E402
 
 def worker(rank, world, port):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    dev = torch.device("cuda", rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     shard = 1024
-    xch = sharding.WrenchExchange(shard, 12, torch.device("cuda", 0))
+    xch = sharding.WrenchExchange(shard, 12, dev)
     ok = True
     for k in range(6):
         f = torch.full((shard, 120), float(10 * k + rank), device="cuda")
@@ -36,4 +38,4 @@ def worker(rank, world, port):
 
 
 if __name__ == "__main__":
-    mp.spawn(worker, args=(2, 29533), nprocs=2, join=True)
+    mp.spawn(worker, args=(2, 29533), nprocs=2, join=True)  # one rank per GPU: edit worker() device indices accordingly
