@@ -470,7 +470,7 @@ int hmpc_debug_assemble(hmpc_handle *h, int index, int *n, int *m, int *var_ind,
   return HMPC_OK;
 }
 
-int hmpc_debug_phase_cycles(hmpc_handle *h, long long *cycles /*[batch][24]*/) {
+int hmpc_debug_phase_cycles(hmpc_handle *h, long long *cycles /*[batch][NPROF = 32]*/) {
 #ifndef HMPC_PROFILE
   (void)h;
   (void)cycles;

@@ -31,7 +31,7 @@ extern "C" {
 
 #define K_MAX_GAIT_SEGMENTS 36 /* convexMPC_interface.h:3 */
 #define HMPC_MAX_HORIZON 20    /* device scratch is sized for this (reference: 10 hard-coded, cap 19) */
-#define HMPC_MAX_VARS 120      /* reduced QP variables (6 per stance leg-step) the LDS-resident solver holds */
+#define HMPC_MAX_VARS 120      /* reduced QP variables (6 per stance leg-step) the on-chip solver holds (two contacts; 180 with three) */
 
 /* ---- reference PODs (convexMPC_interface.h:11-37), same field order and types ---- */
 struct problem_setup {
@@ -206,7 +206,7 @@ int hmpc_debug_assemble(hmpc_handle *h, int index, int *n, int *m, int *var_ind,
 int hmpc_download_f64(hmpc_handle *h, double *x, double *obj);
 
 /* Developer hook (only in builds with -DHMPC_PROFILE, scripts/phase_profile.py): per-phase shader-clock cycles of
- * one more launch of the current batch, [batch][24] (phase ids: hmpc_kernel.h P_*). */
+ * one more launch of the current batch, [batch][32] (phase ids: hmpc_kernel.h P_*). */
 int hmpc_debug_phase_cycles(hmpc_handle *h, long long *cycles);
 
 const char *hmpc_last_hip_error(void);
