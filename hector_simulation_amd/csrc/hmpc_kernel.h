@@ -1111,8 +1111,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
       __syncthreads();
       PROF_MARK(P_B_S0);
       // (c) inversion of the k0 x k0 Schur matrix by symmetric sweeps with the packed triangle spread over the threads'
-      //     registers (<= EPT entries each); the pivot column for sweep s+1 is published right after sweep s into a
-      //     double-buffered LDS vector -> one barrier per pivot, as in the big sweep
+      //     registers (<= EPT entries each)
       {
         const int npair = k0 * (k0 + 1) / 2;
         const int nept = (npair + NT - 1) / NT;
@@ -1135,28 +1134,66 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
           }
           er[u] = v, ei[u] = i, ej[u] = j;
         }
-        double *cb0 = Q.col, *cb1 = Q.z;
+        // Two pivots per barrier: K = {s, s+1}, D = A(K,K), G = D^-1 in closed form (one reciprocal),
+        //     A(K,K) <- -G,   A(i,K) <- P_i G,   A(i,j) <- A(i,j) - P_i G P_j'      with P_i = [A(i,s), A(i,s+1)].
+        // The two pivot columns of the next step are published right after the update (two pairs of LDS vectors,
+        // alternating); an odd last pivot takes one scalar sweep.
+        auto publish = [&](double *buf, int c, int i, int j, double v) {
+          if (j == c) buf[i] = v;
+          else if (i == c) buf[j] = v;
+        };
 #pragma unroll
-        for (int u = 0; u < EPT; ++u)
-          if (ej[u] == 0) cb0[ei[u]] = er[u];
+        for (int u = 0; u < EPT; ++u) {
+          if (ei[u] >= 0) {
+            publish(Q.col, 0, ei[u], ej[u], er[u]);
+            publish(Q.z, 1, ei[u], ej[u], er[u]);
+          }
+        }
         __syncthreads();
-        for (int s = 0; s < k0; ++s) {
-          const double *cs = (s & 1) ? cb1 : cb0;
-          double *cn = (s & 1) ? cb0 : cb1;
+        int s = 0, par = 0;
+        for (; s + 1 < k0; s += 2, par ^= 1) {
+          const double *ca = par ? Q.w : Q.col, *cb = par ? Q.d : Q.z;
+          double *na = par ? Q.col : Q.w, *nb = par ? Q.z : Q.d;
+          const double a00 = ca[s], a01 = ca[s + 1], a11 = cb[s + 1];
+          const double det = dfma(a00, a11, -(a01 * a01));
+          // both pivots of a positive definite Schur matrix are >= ~2e-3 |n|^2 (the second one is det / a00)
+          bad_start = bad_start || !(a00 > 1e-7) || !(det > 1e-7 * a00);
+          double idet = __builtin_amdgcn_rcp(det);
+          idet = dfma(dfma(-det, idet, 1.0), idet, idet);
+          idet = dfma(dfma(-det, idet, 1.0), idet, idet);
+          const double g00 = a11 * idet, g01 = -a01 * idet, g11 = a00 * idet;
+#pragma unroll
+          for (int u = 0; u < EPT; ++u) {
+            if (u < nept) {  // uniform: only the register slots this k0 actually uses
+              const int i = ei[u], j = ej[u];
+              const int ic = i < 0 ? 0 : i, jc = j < 0 ? 0 : j;
+              const double pi0 = ca[ic], pi1 = cb[ic], pj0 = ca[jc], pj1 = cb[jc];
+              const double ti0 = dfma(pi0, g00, pi1 * g01), ti1 = dfma(pi0, g01, pi1 * g11);
+              const double tj0 = dfma(pj0, g00, pj1 * g01), tj1 = dfma(pj0, g01, pj1 * g11);
+              const double upd = dfma(-ti1, pj1, dfma(-ti0, pj0, er[u]));
+              const bool iK = (i == s) || (i == s + 1), jK = (j == s) || (j == s + 1);
+              const double vkk = (i == s) ? -g00 : ((j == s) ? -g01 : -g11);  // i >= j inside K
+              er[u] = iK ? (jK ? vkk : ((i == s) ? tj0 : tj1)) : (jK ? ((j == s) ? ti0 : ti1) : upd);
+              publish(na, s + 2, i, j, er[u]);
+              publish(nb, s + 3, i, j, er[u]);
+            }
+          }
+          __syncthreads();
+        }
+        if (s < k0) {
+          const double *cs = par ? Q.w : Q.col;
           const double dv = cs[s];
-          bad_start = bad_start || !(dv > 1e-7);  // a pivot of a positive definite Schur matrix is >= ~2e-3 |n|^2
+          bad_start = bad_start || !(dv > 1e-7);
           double idv = __builtin_amdgcn_rcp(dv);
           idv = dfma(dfma(-dv, idv, 1.0), idv, idv);
           idv = dfma(dfma(-dv, idv, 1.0), idv, idv);
 #pragma unroll
           for (int u = 0; u < EPT; ++u) {
-            if (u < nept) {  // uniform: only the register slots this k0 actually uses
+            if (u < nept) {
               const int i = ei[u], j = ej[u];
               const double ci = cs[i < 0 ? 0 : i] * idv, cj = cs[j < 0 ? 0 : j];
               const double upd = dfma(-ci, cj, er[u]);
               er[u] = (i == s) ? ((j == s) ? -idv : cj * idv) : ((j == s) ? ci : upd);
-              if (j == s + 1) cn[i] = er[u];
-              else if (i == s + 1) cn[j] = er[u];
             }
           }
           __syncthreads();
