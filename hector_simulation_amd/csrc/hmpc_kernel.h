@@ -978,9 +978,11 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
   };
   // Schur-complement downdate of E when slot l leaves (row/column l are read-only during the pass), then the last slot
   // moves into l.  Two barriers inside.
-  auto drop_slot = [&](int l) {
+  // With follow_u the multipliers of the remaining rows follow the removal, u_R <- u_R - E(R,l) u_l / E(l,l)  (= E' d_R).
+  auto drop_slot = [&](int l, bool follow_u = false, double ul = 0.0) {
     const double iel = 1.0 / Eref(S, l, l);
     const int ti = tid >> 4, tj = tid & 15;
+    if (follow_u && tid < q && tid != l) Q.u[tid] = dfma(-(Eref(S, tid, l) * iel), ul, Q.u[tid]);
     for (int ib = 0; ib < q; ib += NT / 16) {
       const int i = ib + ti;
       if (i < q && i != l) {
@@ -1216,11 +1218,13 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
       //     most negative one, update E by the Schur complement, repeat
       active_residual(Q.xu);
       __syncthreads();
-      while (true) {
+      {
         double dmy = INF;
         int dj = 0;
         e_times(Q.d, Q.u, false, dmy, dj, false);
-        __syncthreads();
+      }
+      __syncthreads();
+      while (true) {
         double um = (tid < q) ? Q.u[tid] : INF;
         const double wmin = wave_min(um);
         const unsigned long long b2 = __ballot(um == wmin);
@@ -1237,11 +1241,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
         l = uni(l);
         if (ub(!(umin < -1e-12))) break;
         ++iters;
-        // remove slot l: the residual vector follows the slot renumbering
-        const int last = q - 1;
-        __syncthreads();
-        if (tid == 0 && l != last) Q.d[l] = Q.d[last];
-        drop_slot(l);
+        drop_slot(l, true, Q.u[l]);  // the multipliers follow the downdate: no second product with E
         if (q == 0) break;
       }
       PROF_MARK(P_B_DROP);
