@@ -116,7 +116,7 @@ static const Variant &pick_variant(const hmpc_handle *h, int *index) {
 }
 
 static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int dbg_index, const int *d_index_list = nullptr,
-                  int n_list = 0) {
+                  int n_list = 0, double relax = 0.0) {
   int vi = 0;
   const Variant *pv = &pick_variant(h, &vi);
   if (d_index_list) {  // safe variant: working set as large as the variable count
@@ -149,6 +149,7 @@ static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int db
   a.index_list = d_index_list;
   a.wset = (h->tick_warm && !assemble_only) ? h->d_wset : nullptr;
   a.wset_shift = h->tick_shift;
+  a.relax = relax;
   const int grid = assemble_only ? 1 : (d_index_list ? n_list : h->batch);
   hipLaunchKernelGGL(fn, dim3(grid), dim3(v.nt), v.smem, stream, a);
   HIP_TRY(hipGetLastError());
@@ -378,10 +379,25 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
   const int warm = h->warm;
   h->warm = 0;  // the safe pass starts cold, as the reference does
   int rc = launch(h, h->last_stream, false, 0, d_idx, (int)idx.size());
-  h->warm = warm;
-  if (rc == HMPC_OK) HIP_TRY(hipStreamSynchronize(h->last_stream));
-  hipFree(d_idx);
+  if (rc == HMPC_OK) rc = (hipStreamSynchronize(h->last_stream) == hipSuccess) ? HMPC_OK : HMPC_E_HIP;
   if (n_resolved) *n_resolved = (int)idx.size();
+  // last resort for instances that cycle at a degenerate vertex even with the full-size working set: bounds moved outward
+  // by 1e-7, then 1e-6 (a different amount per row), reported as HMPC_S_OK_RELAXED
+  const double relax_levels[2] = {1e-7, 1e-6};
+  for (int lvl = 0; lvl < 2 && rc == HMPC_OK; ++lvl) {
+    std::vector<int> still;
+    HIP_TRY(hipMemcpy(st.data(), h->d_status, (size_t)h->batch * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int i : idx) {
+      const uint32_t c = HMPC_STATUS_CODE(st[i]);
+      if (c == HMPC_S_MAXITER || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT) still.push_back(i);
+    }
+    if (still.empty()) break;
+    HIP_TRY(hipMemcpy(d_idx, still.data(), still.size() * sizeof(int), hipMemcpyHostToDevice));
+    rc = launch(h, h->last_stream, false, 0, d_idx, (int)still.size(), relax_levels[lvl]);
+    if (rc == HMPC_OK) rc = (hipStreamSynchronize(h->last_stream) == hipSuccess) ? HMPC_OK : HMPC_E_HIP;
+  }
+  h->warm = warm;
+  hipFree(d_idx);
   return rc;
 }
 

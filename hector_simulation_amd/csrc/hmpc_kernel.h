@@ -53,6 +53,9 @@ struct KernelArgs {
   // overwritten at the end.  nullptr = off.
   signed char *wset;
   int wset_shift;
+  // Last-resort pass for instances stuck at a degenerate vertex (hmpc_resolve_failed): every bound is moved outward by
+  // relax * (1 + frac(0.618 row)) -- a different amount per row, which separates the coinciding vertices.  0 = exact.
+  double relax;
 };
 constexpr int NPROF = 32;
 enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A, P_A0, P_A1, P_A2, P_G };
@@ -81,7 +84,7 @@ struct RecLayout {
                        RH = AL + 6 * NC, FMH = RH + 9, NF = (NC == 2) ? RH : FMH + 1;
 };
 
-enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT = 4, S_WORKSET = 5 };
+enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT = 4, S_WORKSET = 5, S_OK_RELAXED = 6 };
 
 constexpr int GS = 6;  // variables per stance leg-step: force (3) then moment (3)
 
@@ -878,7 +881,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
   const double INF = __builtin_huge_val();
   const double FEAS_TOL = 1e-9;
   const int c_e = tid >> 3, c_rr = tid & 7;
-  double c_ub = INF, c_scale = 1.0;
+  double c_ub = INF, c_lo = 0.0, c_scale = 1.0;
   bool c_hasl = false, c_hasu = false;
   const double *c_cn = S.Cn[0][0];  // this row's 6 coefficients (LDS; re-read where used: cheaper than 12 live VGPRs)
   if (is_c) {
@@ -888,6 +891,12 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
     c_hasu = (c_rr >= 4);
     c_ub = (c_rr == 4) ? (double)0.01f : (c_rr == 7 ? S.ub7[c_e] : 0.0);
     c_scale = (c_rr == 7 && c_ub > 1.0) ? 1.0 / c_ub : 1.0;  // the Fz cap is O(f_max): compare it on a unit scale
+    if (args.relax != 0.0) {
+      const double fr = 0.6180339887498949 * (double)(tid + 1);
+      const double dl = args.relax * (1.0 + (fr - __builtin_floor(fr)));
+      c_lo = -dl;
+      c_ub += dl * ((c_rr == 7 && c_ub > 1.0) ? c_ub : 1.0);
+    }
   }
   const int v_e = tid / GS, v_k = tid % GS;
   const int v_leg = is_v ? S.ls_leg[v_e] : 0;
@@ -908,7 +917,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
   PROF_MARK(P_XU);
 
   int q = 0, iters = 0, code = S_OK;
-  const int itmax = 4 * m + 16;
+  const int itmax = (QCAP >= NMAX || QCAP >= 140) ? 10 * m + 64 : 4 * m + 16;  // the safe variants may take as long as a cold qpOASES run (nWSR up to ~330 seen)
   bool c_ignored = false;  // this thread's row was found redundant at a degenerate vertex (violated by round-off only)
 
   // slack of this thread's constraint row on its tighter side at xv (unit-scaled); side = +1 lower, -1 upper
@@ -920,7 +929,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
 #pragma unroll
     for (int k = 0; k < 3; ++k) s1 = dfma(c_cn[3 + k], xp[3 + k], s1);
     const double s = s0 + s1;
-    const double sl = c_hasl ? s : INF;
+    const double sl = c_hasl ? (s - c_lo) : INF;
     const double su = c_hasu ? (c_ub - s) : INF;
     const double ssu = su * c_scale;
     side = (sl <= ssu) ? 1 : -1;
@@ -1023,7 +1032,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
         const double *xp = xv + GS * c_e;
 #pragma unroll
         for (int k = 0; k < 6; ++k) s = dfma(c_cn[k], xp[k], s);
-        const double bnd = (ac > 0) ? 0.0 : c_ub;
+        const double bnd = (ac > 0) ? c_lo : c_ub;
         Q.d[Q.slot[tid]] = (double)ac * (bnd - s);
       }
     }
@@ -1479,6 +1488,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
     for (int w = 0; w < NW; ++w) xmax = (-Q.redw[w] > xmax) ? -Q.redw[w] : xmax;
     constexpr double KKT_TOL = (QCAP >= NMAX && NMAX >= 120) ? 2e-5 : 2e-6;
     if (code == S_OK && (val < -KKT_TOL * xmax || umin < -1e-6 * xmax)) code = S_KKT;  // relative to the force scale
+    if (code == S_OK && args.relax != 0.0) code = S_OK_RELAXED;
   }
 
   // ---------------- output: scatter to the reference's 12h layout, eliminated variables exactly 0 (SolverMPC.cpp:720-732)

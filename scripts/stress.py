@@ -20,7 +20,8 @@ for gait,h in (("standing",10),("walking",10),("mixed",10),("single",20)):
     print('   fast-pass codes', dict(zip(*np.unique(interface.status_code(status0),return_counts=True))), 're-solved', nres)
     code = interface.status_code(status)
     ref = O.solve_records(rec,h,synthetic.DT_MPC,synthetic.F_MAX)
-    ok = (code==0)
+    ok = (code==0) | (code==6)
+    rel = (code==6)
     q = ref["q_soln"]; err = np.abs(forces-q).max(axis=1)/np.maximum(1,np.abs(q).max(axis=1))
     # per-instance qpOASES status unknown (n_bad total); report
-    print(gait,h,"scale",scale,"gpu codes",dict(zip(*np.unique(code,return_counts=True))),"qpoases bad",ref["n_bad"],"nwsr max",ref["nwsr"].max(),"iters max",interface.status_iters(status).max(),"act max",interface.status_nactive(status).max(),"max err(ok)",err[ok].max() if ok.any() else None, "n err>1e-4", int((err[ok]>1e-4).sum()))
+    print(gait,h,"scale",scale,"gpu codes",dict(zip(*np.unique(code,return_counts=True))),"qpoases bad",ref["n_bad"],"nwsr max",ref["nwsr"].max(),"iters max",interface.status_iters(status).max(),"act max",interface.status_nactive(status).max(),"max err(ok)",err[ok].max() if ok.any() else None, "n err>1e-4", int((err[ok]>1e-4).sum()), "max err(relaxed)", err[rel].max() if rel.any() else None)

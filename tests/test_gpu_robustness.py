@@ -1,7 +1,8 @@
 """Robustness outside the nominal input distribution: 3x the SURVEY 8d ranges must solve 100 %; at 6x (roll/pitch up
 to 0.6 rad, 3 rad/s body rates: far outside what the controller lets happen) working sets outgrow the fast kernel's 80
-rows -> the safe pass (hmpc_resolve_failed, capacity = variable count, cold start) must pick those up, and whatever is
-left must be FLAGGED, never silently wrong."""
+rows -> the safe pass (hmpc_resolve_failed, capacity = variable count, cold start) must pick those up; instances that
+still cycle at a degenerate vertex get the last-resort pass with bounds relaxed by 1e-7 / 1e-6 (status OK_RELAXED, still
+within 1e-4 of qpOASES), and whatever is left must be FLAGGED, never silently wrong."""
 import numpy as np
 import pytest
 
@@ -25,7 +26,7 @@ def hard_batch(nb, h, gait, seed, scale):
 
 
 @pytest.mark.parametrize("gait,h,scale,min_ok", [("standing", 10, 3, 1.0), ("walking", 10, 3, 1.0), ("single", 20, 3, 1.0),
-                                                  ("standing", 10, 6, 0.97), ("single", 20, 6, 0.97)])
+                                                  ("standing", 10, 6, 0.99), ("single", 20, 6, 0.99)])
 def test_hard_inputs(oracle, gait, h, scale, min_ok):
     nb = 192
     rec = records.pack_records(hard_batch(nb, h, gait, 17, scale), h)
@@ -38,7 +39,10 @@ def test_hard_inputs(oracle, gait, h, scale, min_ok):
     assert mpc.resolve_failed() == n_flagged
     forces, status = mpc.download()
     mpc.close()
-    ok = interface.status_code(status) == 0
+    code = interface.status_code(status)
+    ok = (code == 0) | (code == 6)  # 6 = solved with bounds relaxed by <= 2e-6 (hmpc_status_code HMPC_S_OK_RELAXED)
+    if scale <= 3:
+        assert (code == 0).all()
     assert ok.mean() >= min_ok, (ok.mean(), np.unique(interface.status_code(status), return_counts=True))
     if scale >= 6:
         assert n_flagged > 0  # the regime really exercises the safe pass
