@@ -1459,6 +1459,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
       e_times(Q.d, Q.u, true, dmy, dj, false);
       __syncthreads();
     }
+    PROF_MARK(P_POLISH);
     // a refinement that moved x across another constraint sends us back into the main loop (rare)
   }
 
