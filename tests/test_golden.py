@@ -56,3 +56,85 @@ def test_hip_matches_golden(gold, name):
         np.testing.assert_array_equal(d["Fc"].view(np.uint32), gold[f"{name}/{k}/Fc"].view(np.uint32))
         np.testing.assert_array_equal(d["x0"].view(np.uint32), gold[f"{name}/{k}/x0"].view(np.uint32))
     mpc.close()
+
+
+# ---- three-contact extension and the rows either side of the solve (tests/golden/make_golden.py: main_three_contacts, main_ticks)
+GOLD3 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mpc_golden_3c.npz")
+GOLDT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tick_golden.npz")
+NAMES3 = ["stand_hand", "walk_window"]
+NAMEST = ["walk", "stand"]
+
+
+@pytest.mark.parametrize("name", NAMES3)
+def test_oracle_reproduces_three_contact_golden(oracle, name):
+    g = np.load(GOLD3)
+    rec = g[f"{name}/records"]
+    sol = oracle.solve_records(rec, 10, synthetic.DT_MPC, synthetic.F_MAX, nc=3)
+    assert sol["n_bad"] == 0
+    np.testing.assert_allclose(sol["q_soln"], g[f"{name}/q_soln"], rtol=0, atol=1e-9)
+    for k in range(rec.shape[0]):
+        a = oracle.assemble_record(rec[k], 10, synthetic.DT_MPC, synthetic.F_MAX, nc=3)
+        np.testing.assert_array_equal(a["var_ind"], g[f"{name}/{k}/var_ind"])
+        np.testing.assert_array_equal(a["H_red"].astype(np.float32).view(np.uint32), g[f"{name}/{k}/H_red"].view(np.uint32))
+        np.testing.assert_array_equal(a["g_red"].astype(np.float32).view(np.uint32), g[f"{name}/{k}/g_red"].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES3)
+def test_hip_matches_three_contact_golden(name):
+    g = np.load(GOLD3)
+    rec = g[f"{name}/records"]
+    nb = rec.shape[0]
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, 10, synthetic.F_MAX, nb, contacts=3)
+    mpc.upload(rec)
+    mpc.solve()
+    forces, status = mpc.download()
+    assert (interface.status_code(status) == 0).all()
+    q = g[f"{name}/q_soln"]
+    assert (np.abs(forces - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))).max() < 1e-4
+    for k in range(nb):
+        d = mpc.debug_assemble(k)
+        np.testing.assert_array_equal(d["var_ind"], g[f"{name}/{k}/var_ind"])
+        np.testing.assert_array_equal(d["H"].view(np.uint32), g[f"{name}/{k}/H_red"].view(np.uint32))
+        np.testing.assert_array_equal(d["g"].view(np.uint32), g[f"{name}/{k}/g_red"].view(np.uint32))
+        np.testing.assert_array_equal(d["Fc"].view(np.uint32), g[f"{name}/{k}/Fc"].view(np.uint32))
+    mpc.close()
+
+
+def _ticks(g, name):
+    raw = np.ascontiguousarray(g[f"{name}/ticks"])
+    return raw.view(interface.TICK_DTYPE).reshape(-1)
+
+
+@pytest.mark.parametrize("name", NAMEST)
+def test_oracle_reproduces_tick_golden(oracle, name):
+    g = np.load(GOLDT)
+    t, h = _ticks(g, name), int(g[f"{name}/horizon"])
+    rec, wpd = oracle.build_records(t, h, synthetic.DT_MPC)
+    np.testing.assert_array_equal(rec, g[f"{name}/records"])
+    np.testing.assert_array_equal(wpd.view(np.uint64), g[f"{name}/wpd"].view(np.uint64))
+    f_ff = oracle.body_wrench(g[f"{name}/q_soln"].astype(np.float32).astype(np.float64), t["rBody"])
+    np.testing.assert_array_equal(f_ff.view(np.uint64), g[f"{name}/f_ff"].view(np.uint64))
+    np.testing.assert_array_equal(oracle.leg_torques(f_ff, t["leg_q"]).view(np.uint64), g[f"{name}/tau"].view(np.uint64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMEST)
+def test_hip_matches_tick_golden(name):
+    g = np.load(GOLDT)
+    t, h = _ticks(g, name), int(g[f"{name}/horizon"])
+    nb = t.shape[0]
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb)
+    wpd = mpc.build_records(t, synthetic.DT_MPC)
+    np.testing.assert_array_equal(mpc.download_records(), g[f"{name}/records"])
+    np.testing.assert_array_equal(wpd.view(np.uint64), g[f"{name}/wpd"].view(np.uint64))
+    mpc.solve()
+    forces, status = mpc.download()
+    assert (interface.status_code(status) == 0).all()
+    q = g[f"{name}/q_soln"]
+    assert (np.abs(forces - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))).max() < 1e-4
+    f_ff, tau = mpc.leg_torques(t["rBody"], t["leg_q"])
+    # the wrench is a linear map of the float32 forces: compare at the forces' own accuracy
+    np.testing.assert_allclose(f_ff, g[f"{name}/f_ff"], rtol=0, atol=2e-4 * max(1.0, np.abs(q).max()))
+    np.testing.assert_allclose(tau, g[f"{name}/tau"], rtol=0, atol=2e-4 * max(1.0, np.abs(q).max()))
+    mpc.close()
