@@ -382,7 +382,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
   {
     // foot rotation Rz(q0)Rx(q1)Ry(q2)Ry(q3)Ry(q4) and this leg's 8 rows of the 16x12 constraint block
     // (SolverMPC.cpp:426-433, 488-548)
-    const int leg_lane0 = (NT >= 256) ? 128 : 1, leg_lane1 = (NT >= 256) ? 192 : 2, leg_lane2 = (NC == 3) ? 256 : -1;
+    const int leg_lane0 = (NT >= 256) ? 128 : 64, leg_lane1 = (NT >= 256) ? 192 : 65, leg_lane2 = (NC == 3) ? 256 : -1;
     if (tid == leg_lane0 || tid == leg_lane1 || tid == leg_lane2) {
       const int leg = (tid == leg_lane0) ? 0 : (tid == leg_lane1 ? 1 : 2);
       float R[9], Rt[9];
