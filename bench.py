@@ -249,12 +249,14 @@ def main() -> None:
         ach_gbs = B * bps / (kernel_ms * 1e-3) / 1e9
         ach_tf = B * mfl * 1e6 / (kernel_ms * 1e-3) / 1e12
         traffic = None
+        counters = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):  # PMC-measured HBM bytes per solve from the committed rocprofv3 passes
             try:
                 tj = json.load(open(tpath))
                 if tj.get("horizon") == h and tj.get("gait") == args.gait:
                     traffic = tj["bytes_per_solve"] * B
+                    counters = tj.get("counters")
             except Exception:
                 traffic = None
         out = {
@@ -271,6 +273,7 @@ def main() -> None:
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "counters_from_committed_pmc_passes": counters,
                          "kernel": "hmpc_kernel (fused assembly + QP solve)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_solve": bps,
                          "note": "neither HBM nor MFMA binds this path (SURVEY.md 8d): the limiter is the serial "

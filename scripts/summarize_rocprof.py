@@ -43,8 +43,24 @@ def main():
         batch = 8192
         raw = (means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024 / batch
         cor = (2 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024 / batch
+        ctr = {}
+        if "SQ_WAVE_CYCLES" in means:
+            wc = means["SQ_WAVE_CYCLES"]
+            ctr = {
+                "sq_wait_any_frac_of_wave_cycles": means.get("SQ_WAIT_ANY", 0) / wc,
+                "sq_active_inst_any_frac_of_wave_cycles": means.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+                "valu_insts_per_solve": means.get("SQ_INSTS_VALU", 0) / batch,
+                "salu_insts_per_solve": means.get("SQ_INSTS_SALU", 0) / batch,
+                "lds_insts_per_solve": means.get("SQ_INSTS_LDS", 0) / batch,
+                "mfma_insts_per_solve": means.get("SQ_INSTS_MFMA", 0) / batch,
+                "lds_bank_conflict_frac_of_lds_active": means.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, means.get("SQ_LDS_IDX_ACTIVE", 1.0)),
+            }
+            if "GRBM_GUI_ACTIVE" in means and "SQ_VALU_MFMA_BUSY_CYCLES" in means:
+                cyc = means["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+                ctr["kernel_cycles_per_launch"] = cyc
+                ctr["mfma_pipe_busy_frac"] = means["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)  # 256 CUs x 4 SIMDs
         json.dump({
-            "horizon": 10, "gait": "standing", "batch": batch,
+            "horizon": 10, "gait": "standing", "batch": batch, "counters": ctr,
             "FETCH_SIZE_KB_per_launch": means["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": means["WRITE_SIZE"],
             "bytes_per_solve_raw": raw, "bytes_per_solve": cor,
             "correction": "FETCH_SIZE doubled (gfx950 rocprofv3 reports half the bytes of a coalesced stream, "
