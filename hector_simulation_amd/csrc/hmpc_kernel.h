@@ -126,7 +126,10 @@ struct Smem {
   };
   struct Sol {
     alignas(16) double x[NMAX], xu[NMAX], z[NMAX], w[NMAX];
-    alignas(16) double ST[NG][NMAX];  // staged partials of the in-place mat-vec: ST[source leg-step][variable]
+    // staged partials of the in-place mat-vec: ST[source leg-step][variable]; rows padded by two doubles so that the
+    // 16-byte writes of blocks with consecutive e1 (same e0) land in different LDS banks (row stride 240 words = 16 mod 32
+    // would put them on two bank groups only)
+    alignas(16) double ST[NG][NMAX + 2];
     alignas(16) double piv[2][NMAX];
     double u[NMAX], d[NMAX], r[NMAX], col[NMAX];
     double redv[NW], redw[NW];
