@@ -335,6 +335,48 @@ def main() -> None:
                              "failed": int((interface.status_code(stt) != 0).sum())}
             mt.close()
             extra["second_tick_%s_b%d" % (args.gait, B)] = res
+            # host records in, host forces out through the blocking batched API (PCIe-inclusive; never the headline value)
+            mh = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, B, device=local_rank)
+            th = []
+            for _ in range(5):
+                th0 = time.perf_counter()
+                mh.upload(rec)
+                mh.solve(stream)
+                mh.download()
+                th.append(time.perf_counter() - th0)
+            mh.close()
+            extra["host_in_host_out_b%d" % B] = {"solves_per_s": B / min(th[1:]), "ms": 1e3 * min(th[1:]),
+                                                 "note": "hmpc_upload_records + hmpc_solve + hmpc_download, pageable host memory, no overlap"}
+            # the same host-to-host work pipelined: two handles on two streams, pinned host buffers, the copies of one
+            # batch under the solve of the other (hmpc_upload_records_async / hmpc_download_async)
+            nbuf = 2
+            streams = [torch.cuda.Stream(device=dev) for _ in range(nbuf)]
+            hs = [interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, B, device=local_rank) for _ in range(nbuf)]
+            h_rec = [torch.from_numpy(rec.copy()).pin_memory() for _ in range(nbuf)]
+            h_for = [torch.empty((B, 12 * h), dtype=torch.float32).pin_memory() for _ in range(nbuf)]
+            h_st = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(nbuf)]
+
+            def pipelined(nrounds):
+                for r in range(nrounds):
+                    k2 = r % nbuf
+                    st2 = streams[k2].cuda_stream
+                    hs[k2].upload_async(h_rec[k2].data_ptr(), B, st2)
+                    hs[k2].solve(st2)
+                    hs[k2].download_async(h_for[k2].data_ptr(), h_st[k2].data_ptr(), st2)
+                for st3 in streams:
+                    st3.synchronize()
+
+            pipelined(4)
+            tp0 = time.perf_counter()
+            nr = 12
+            pipelined(nr)
+            tp = time.perf_counter() - tp0
+            okp = int((interface.status_code(h_st[0].numpy().astype(np.uint32)) != 0).sum())
+            for hh2 in hs:
+                hh2.close()
+            extra["host_in_host_out_pipelined_b%d" % B] = {"solves_per_s": nr * B / tp, "ms_per_batch": 1e3 * tp / nr,
+                                                           "failed": okp,
+                                                           "note": "two handles / two streams, pinned host buffers, copies overlapped with the other batch's solve"}
             # the reference's own call sequence for ONE robot (setup_problem / update_problem_data / get_solution,
             # ConvexMPCLocomotion.cpp:410-429): host-to-host latency of a blocking tick through the legacy interface
             row = {k2: np.asarray(v2)[0] for k2, v2 in fields.items()}

@@ -16,7 +16,7 @@ EXPORTS = [
     "hmpc_solve", "hmpc_download", "hmpc_get_device_outputs", "hmpc_batch", "hmpc_horizon", "hmpc_time_solve",
     "hmpc_build_records", "hmpc_build_records_device", "hmpc_body_wrench", "hmpc_body_wrench_device", "hmpc_leg_torques", "hmpc_leg_torques_device",
     "hmpc_download_records", "hmpc_debug_assemble", "hmpc_debug_phase_cycles", "hmpc_download_f64", "hmpc_last_hip_error", "hmpc_version",
-    "hmpc_set_tick_warm_start", "hmpc_reset_tick_warm_start", "hmpc_create_ex", "hmpc_contacts", "hmpc_record_stride_ex", "hmpc_pack_record_ex",
+    "hmpc_upload_records_async", "hmpc_download_async", "hmpc_set_tick_warm_start", "hmpc_reset_tick_warm_start", "hmpc_create_ex", "hmpc_contacts", "hmpc_record_stride_ex", "hmpc_pack_record_ex",
 ]
 
 
@@ -84,6 +84,8 @@ def load():
     L.hmpc_set_device_records.argtypes = [vp, vp, ci]
     L.hmpc_set_max_reduced_vars.argtypes = [vp, ci]
     L.hmpc_set_warm_start.argtypes = [vp, ci]
+    L.hmpc_upload_records_async.argtypes = [vp, vp, ci, vp]
+    L.hmpc_download_async.argtypes = [vp, vp, vp, vp]
     L.hmpc_set_tick_warm_start.argtypes = [vp, ci, ci]
     L.hmpc_reset_tick_warm_start.argtypes = [vp]
     L.hmpc_resolve_failed.argtypes = [vp, C.POINTER(ci)]

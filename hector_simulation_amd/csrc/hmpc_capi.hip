@@ -267,11 +267,14 @@ int hmpc_destroy(hmpc_handle *h) {
   return HMPC_OK;
 }
 
-int hmpc_upload_records(hmpc_handle *h, const void *host_records, int batch) {
+static int upload_common(hmpc_handle *h, const void *host_records, int batch, bool async, hipStream_t stream) {
   if (!h || !host_records || batch < 0) return HMPC_E_ARG;
   if (batch > h->max_batch) return HMPC_E_BATCH;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipMemcpy(h->d_records_own, host_records, (size_t)batch * h->stride, hipMemcpyHostToDevice));
+  if (async)
+    HIP_TRY(hipMemcpyAsync(h->d_records_own, host_records, (size_t)batch * h->stride, hipMemcpyHostToDevice, stream));
+  else
+    HIP_TRY(hipMemcpy(h->d_records_own, host_records, (size_t)batch * h->stride, hipMemcpyHostToDevice));
   h->d_records = h->d_records_own;
   h->batch = batch;
   // host-side scan of the gait tables: the widest reduced QP in the batch picks the kernel variant (LDS footprint)
@@ -292,6 +295,25 @@ int hmpc_upload_records(hmpc_handle *h, const void *host_records, int batch) {
     if (cnt > mx) mx = cnt;
   }
   h->max_stance = 6 * mx;
+  return HMPC_OK;
+}
+
+int hmpc_upload_records(hmpc_handle *h, const void *host_records, int batch) {
+  return upload_common(h, host_records, batch, false, nullptr);
+}
+
+int hmpc_upload_records_async(hmpc_handle *h, const void *host_records, int batch, void *stream) {
+  return upload_common(h, host_records, batch, true, (hipStream_t)stream);
+}
+
+int hmpc_download_async(hmpc_handle *h, float *forces, uint32_t *status, void *stream) {
+  if (!h) return HMPC_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t nf = (size_t)h->batch * 6 * h->nc * h->setup.horizon;
+  if (forces && nf)
+    HIP_TRY(hipMemcpyAsync(forces, h->d_forces, nf * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  if (status && h->batch)
+    HIP_TRY(hipMemcpyAsync(status, h->d_status, (size_t)h->batch * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
   return HMPC_OK;
 }
 

@@ -96,6 +96,16 @@ class BatchedMPC:
         assert recs.ndim == 2 and recs.shape[1] == self.stride, (recs.shape, self.stride)
         _check(self.L.hmpc_upload_records(self.h, recs.ctypes.data, recs.shape[0]), "hmpc_upload_records")
 
+    def upload_async(self, host_ptr: int, batch: int, stream: int = 0) -> None:
+        """Stream-ordered upload from a (pinned) host buffer of ``batch`` packed records."""
+        _check(self.L.hmpc_upload_records_async(self.h, C.c_void_p(host_ptr), int(batch), C.c_void_p(stream)),
+               "hmpc_upload_records_async")
+
+    def download_async(self, forces_ptr: int, status_ptr: int, stream: int = 0) -> None:
+        """Stream-ordered download into (pinned) host buffers; no safe pass (see include/hector_mpc.h)."""
+        _check(self.L.hmpc_download_async(self.h, C.c_void_p(forces_ptr), C.c_void_p(status_ptr), C.c_void_p(stream)),
+               "hmpc_download_async")
+
     def upload_fields(self, fields: dict) -> None:
         self.upload(records.pack_records(fields, self.horizon, self.contacts))
 

@@ -157,6 +157,12 @@ int hmpc_reset_tick_warm_start(hmpc_handle *h);
  * hmpc_download does this automatically unless hmpc_set_auto_resolve(h, 0). */
 int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved);
 int hmpc_set_auto_resolve(hmpc_handle *h, int on);
+/* Stream-ordered variants for pipelining host batches (two handles on two streams: the copies of one overlap the solve
+ * of the other).  The host buffers should be pinned (hipHostMalloc / hipHostRegister) for the copies to be asynchronous
+ * and must stay valid until the stream reaches them.  hmpc_download_async does not run the safe pass: check the status
+ * words after synchronising and call hmpc_resolve_failed + hmpc_download for a batch that has flagged instances. */
+int hmpc_upload_records_async(hmpc_handle *h, const void *host_records, int batch, void *stream);
+int hmpc_download_async(hmpc_handle *h, float *forces, uint32_t *status, void *stream);
 int hmpc_get_device_outputs(hmpc_handle *h, float **device_forces, uint32_t **device_status);
 int hmpc_batch(const hmpc_handle *h);
 int hmpc_horizon(const hmpc_handle *h);
