@@ -54,6 +54,18 @@ def load():
     path = _build.build()
     if not os.path.exists(path):
         raise RuntimeError("libhector_mpc_hip.so is missing and could not be built; the solver has no fallback path")
+    # PyTorch-ROCm ships its own libamdhip64; this library links the system one.  When both end up in one Python process
+    # the order matters: torch's runtime first is the combination that works (bench.py's order); ours first has been seen
+    # to leave torch with "no ROCm-capable device".  So if torch is installed, let it come up first.  (A C++ host such as
+    # the reference controller has no torch in the process and none of this applies.)
+    if os.environ.get("HMPC_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
     L = C.CDLL(path)
     vp, ci, cd, cf = C.c_void_p, C.c_int, C.c_double, C.c_float
     L.setup_problem.argtypes = [cd, ci, cd, cd]
