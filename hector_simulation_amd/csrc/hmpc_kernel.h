@@ -1445,7 +1445,9 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
       if (code != S_OK) break;
     }
     if (code != S_OK || q == 0) break;
-    if (pass > 0 && iters == iters_at_entry) break;  // the refined point is feasible: done
+    // nothing happened in this pass: either the refined point of the previous pass is feasible, or (first pass) the block
+    // start already is the optimum -- its x, u, E come straight from the inversion, there is nothing to refine
+    if (iters == iters_at_entry) break;
 
     // ---- refinement of the multipliers on the final working set: u += E (b_W - N_W x(u)), x(u) = x_u + M N_W' u ----
     for (int it = 0; it <= HMPC_REFINE; ++it) {
