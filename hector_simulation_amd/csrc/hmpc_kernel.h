@@ -254,6 +254,7 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
   // wave builds the swing-leg elimination tables meanwhile (SolverMPC.cpp:589-637)
   {
     const double PI = 3.14159265359, PI2 = 2 * PI;
+    constexpr int L_ROLL = (NT >= 256) ? 65 : 65, L_PITCH = (NT >= 256) ? 128 : 66, L_YAW = (NT >= 256) ? 192 : 12;
     auto joint = [&](int i) -> float {
       float a = in_ja[i];
       const int k = i % 5;
@@ -262,25 +263,24 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
       const double ad = (double)a;
       return (float)((__builtin_fabs(ad) < PI2) ? ad : fmod(ad, PI2));  // fmod(x,y) == x exactly when |x| < y
     };
-    if (tid < 10) {
-      double s, c;
-      det_sincos((double)joint(tid), s, c);
-      A.sc[tid][0] = (float)s;
-      A.sc[tid][1] = (float)c;
-    } else if (tid < 12) {
+    if (tid < 12) {
+      // lanes 0..9: the joint angles; lanes 10, 11: q2+q3+q4 of each leg -- one sincos evaluation for all twelve
       const int b = 5 * (tid - 10);
-      float q234 = (joint(b + 2) + joint(b + 3)) + joint(b + 4);
+      const float ang = (tid < 10) ? joint(tid) : (joint(b + 2) + joint(b + 3)) + joint(b + 4);
       double s, c;
-      det_sincos((double)q234, s, c);
-      A.sc234[tid - 10][0] = (float)s;
-      A.sc234[tid - 10][1] = (float)c;
-    } else if (tid < 15) {
+      det_sincos((double)ang, s, c);
+      float *dst = (tid < 10) ? A.sc[tid] : A.sc234[tid - 10];
+      dst[0] = (float)s;
+      dst[1] = (float)c;
+    } else if (tid == L_ROLL || tid == L_PITCH || tid == L_YAW) {
+      // the three Euler angles are the longest scalar chains of the stage (two binary64 divisions, a square root and a
+      // sincos each): one lane each in different waves, so that they run side by side instead of one after the other
       const float qw = in_q[0], qx = in_q[1], qy = in_q[2], qz = in_q[3];
-      if (tid == 12) {
+      if (tid == L_ROLL) {
         float n0 = 2.0f * (qw * qx + qy * qz);
         double d0 = 1.0 - (double)(2.0f * (qx * qx + qy * qy));
         A.rpy[0] = (float)det_atan2((double)n0, d0);
-      } else if (tid == 13) {
+      } else if (tid == L_PITCH) {
         float t = qw * qy - qx * qz;
         double asd = 2.0 * (double)t;
         if (!(asd < 0.99999)) asd = 0.99999;
