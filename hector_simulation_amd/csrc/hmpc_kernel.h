@@ -755,8 +755,10 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
         const double2 t2 = *reinterpret_cast<const double2 *>(pv + j0 + jj);
         pj[jj] = t2.x, pj[jj + 1] = t2.y;
       }
-      double invd = __builtin_amdgcn_rcp(d);  // v_rcp_f64 + two Newton steps (the solver half is not bit-pinned)
-      invd = dfma(dfma(-d, invd, 1.0), invd, invd);
+      // v_rcp_f64 is good to 2^-24 (scripts/micro/rcp64_accuracy.hip); one Newton step brings 2e-15, a second one would
+      // bring the last bit -- not worth two more fp64 instructions per pivot here: the sweeps' own round-off (cond(H) eps
+      // ~ 3e-10) is five orders above it and the substituted multipliers stay consistent with whatever invd is used
+      double invd = __builtin_amdgcn_rcp(d);
       invd = dfma(dfma(-d, invd, 1.0), invd, invd);
       double qi[GS];
 #pragma unroll
