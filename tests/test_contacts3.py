@@ -11,6 +11,8 @@ import pytest
 
 from hector_simulation_amd import records, synthetic
 
+import numpy_mirror
+
 H = 10
 
 
@@ -103,3 +105,27 @@ def test_three_contact_solution_is_kkt_point(oracle, gait, hand, seed):
         np.testing.assert_array_equal(Fc[16 + 6, 15:18], -Fc[16 + 5, 15:18])
         np.testing.assert_array_equal(Fc[6, 9:12], -Fc[5, 9:12])
         np.testing.assert_array_equal(Fc[8 + 6, 12:15], Fc[8 + 5, 12:15])
+
+
+@pytest.mark.parametrize("gait,hand,seed", [("standing", "contact", 5), ("walking", "window", 6), ("mixed", "contact", 8)])
+def test_three_contact_oracle_matches_numpy_mirror(oracle, gait, hand, seed):
+    """Second, independent implementation of the extension (tests/numpy_mirror.py with nc = 3: float64, dense, libm),
+    written from its specification in SURVEY.md section 8d: agreement with the oracle at binary32 round-off."""
+    f = synthetic.make_batch3(3, H, gait, seed=seed, hand=hand, phase="random")
+    rec = records.pack_records(f, H, 3)
+    u = records.unpack_records(rec, H, 3)
+    for k in range(3):
+        row = {name: np.asarray(v)[k] for name, v in u.items()}
+        o = oracle.assemble_record(rec[k], H, synthetic.DT_MPC, synthetic.F_MAX, nc=3)
+        m = numpy_mirror.assemble(row, H, float(np.float32(synthetic.DT_MPC)), synthetic.F_MAX, nc=3)
+        np.testing.assert_array_equal(o["var_ind"], m["var_ind"])
+        np.testing.assert_array_equal(o["con_ind"], m["con_ind"])
+        np.testing.assert_allclose(o["Bcd"], m["Bcd"], rtol=2e-5, atol=1e-8)
+        np.testing.assert_allclose(o["Fc"], m["Fc"], atol=5e-7)
+        np.testing.assert_array_equal(o["lb_red"], m["lb_red"])
+        np.testing.assert_array_equal(o["ub_red"], m["ub_red"])
+        np.testing.assert_allclose(o["A_red"], m["A_red"], atol=5e-7)
+        scale = np.abs(m["H_red"]).max()
+        assert np.abs(o["H_red"] - m["H_red"]).max() < 2e-5 * scale
+        assert np.abs(o["g_red"] - m["g_red"]).max() < 2e-4 * max(1.0, np.abs(m["g_red"]).max())
+        assert np.linalg.eigvalsh(o["H_red"])[0] > 1.9e-4
