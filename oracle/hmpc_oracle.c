@@ -184,12 +184,25 @@ static void inverse3(const float m[9], float inv[9]) {
     for (int c = 0; c < 3; ++c) inv[r * 3 + c] = cof[c * 3 + r] * invdet;
 }
 
+/* Study switch (tests only): 1 = every chain step rounds the product and the sum separately, acc = fl(acc + fl(a*b)),
+ * as an SSE2 build without FMA -- the reference's own CMake flags -- does, instead of the contract's fused step.  Used
+ * to measure how far the optimal forces move between the two arithmetics (tests/test_oracle.py); never the default. */
+static int g_unfused = 0;
+void orc_set_unfused_chain(int on) { g_unfused = on; }
+static inline float chain_step(float a, float b, float acc) {
+  if (g_unfused) {
+    volatile float p = a * b; /* volatile: keep the product a separately rounded binary32 value */
+    return acc + p;
+  }
+  return fmaf(a, b, acc);
+}
+
 /* k-ascending fmaf chain: out(MxN) = A(MxK) * B(KxN), row-major, acc starts at +0 */
 ORC_CLONES static void chain_matmul(const float *A, const float *B, float *out, int M, int K, int N) {
   for (int i = 0; i < M; ++i)
     for (int j = 0; j < N; ++j) {
       float acc = 0.0f;
-      for (int k = 0; k < K; ++k) acc = fmaf(A[i * K + k], B[k * N + j], acc);
+      for (int k = 0; k < K; ++k) acc = chain_step(A[i * K + k], B[k * N + j], acc);
       out[i * N + j] = acc;
     }
 }
@@ -378,7 +391,7 @@ ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_q
         for (int s = 0; s < 13; ++s) {
           float sb = (i >= a) ? SPhi[(i - a) * PS + s * U + r] : 0.0f;
           float bb = (i >= b) ? o->Phi[(i - b) * PS + s * U + c] : 0.0f;
-          acc = fmaf(sb, bb, acc);
+          acc = chain_step(sb, bb, acc);
         }
       }
       float hv = 2.0f * (acc + ((I == J) ? u->Alpha_K[r] : 0.0f));
@@ -393,7 +406,7 @@ ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_q
     for (int i = i0; i < h; ++i)
       for (int s = 0; s < 13; ++s) {
         float sb = (i >= b) ? SPhi[(i - b) * PS + s * U + c] : 0.0f;
-        acc = fmaf(sb, e[13 * i + s], acc);
+        acc = chain_step(sb, e[13 * i + s], acc);
       }
     o->g[J] = 2.0f * acc;
   }
