@@ -396,19 +396,23 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
       const float s2 = A.sc[b + 2][0], c2 = A.sc[b + 2][1], s3 = A.sc[b + 3][0], c3 = A.sc[b + 3][1];
       const float s4 = A.sc[b + 4][0], c4 = A.sc[b + 4][1];
       const float s234 = A.sc234[leg & 1][0], c234 = A.sc234[leg & 1][1];
-      float a = c0 * s2 + (c2 * s0) * s1;
-      float bb = c0 * c2 - (s0 * s1) * s2;
-      float d = c2 * s0 + (c0 * s1) * s2;
-      float e = s0 * s2 - (c0 * c2) * s1;
-      float ca3 = c3 * a + s3 * bb, sa3 = s3 * a - c3 * bb;
-      float cd3 = c3 * d - s3 * e, sd3 = s3 * d + c3 * e;
+      // every operation in the type C++ gives it at SolverMPC.cpp:428-433: the "1.0" / "-1.0" literals promote the
+      // product they start, and whatever that product is combined with, to binary64; one narrowing per entry
+      const float a = c0 * s2 + (c2 * s0) * s1;
+      const double bb = (double)(c0 * c2) - (((double)s0 * (double)s1) * (double)s2);
+      const float d = c2 * s0 + (c0 * s1) * s2;
+      const double e = (double)(s0 * s2) - (((double)c0 * (double)c2) * (double)s1);
+      const double X = (double)(c3 * a) + (double)s3 * bb;
+      const double Y = ((double)s3 * (double)a) - (double)c3 * bb;
+      const double P = (double)(c3 * d) - ((double)s3) * e;
+      const double Q = (double)(s3 * d) + (double)c3 * e;
       float Rf[9];
-      Rf[0] = -(s4 * ca3) - c4 * sa3;
+      Rf[0] = (float)((-(double)s4) * X - (double)c4 * Y);
       Rf[1] = -(c1 * s0);
-      Rf[2] = c4 * ca3 - s4 * sa3;
-      Rf[3] = c4 * cd3 - s4 * sd3;
+      Rf[2] = (float)((double)c4 * X - (double)s4 * Y);
+      Rf[3] = (float)((double)c4 * P - (double)s4 * Q);
       Rf[4] = c0 * c1;
-      Rf[5] = c4 * sd3 + s4 * cd3;
+      Rf[5] = (float)((double)c4 * Q + (double)s4 * P);
       Rf[6] = -(s234 * c1);
       Rf[7] = s1;
       Rf[8] = c234 * c1;

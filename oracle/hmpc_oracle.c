@@ -207,30 +207,45 @@ ORC_CLONES static void chain_matmul(const float *A, const float *B, float *out, 
     }
 }
 
-/* foot rotation = Rz(q0) Rx(q1) Ry(q2) Ry(q3) Ry(q4), written in the expanded sin/cos form the reference uses
- * (SolverMPC.cpp:428-433) with the common factors named.  All products/sums binary32 except the last row's
- * angle sum, which the reference also forms in binary32 before one sin/cos. */
+/* Study switch (tests only): 1 = take sin/cos/asin/atan2 from the host's libm with the overloads the reference's
+ * C++ selects (sinf/cosf/asinf for float arguments, SolverMPC.cpp:74-85, 340, 428-433; double atan2 for the mixed
+ * float/double arguments of :339,:341) instead of the contract's deterministic binary64 routines rounded once.  With
+ * this and orc_set_unfused_chain(1) the oracle reproduces, bit for bit, the reference's own sources compiled against
+ * oracle/mini_eigen (tests/test_reference_source.py); never the default, because libm's float routines are not
+ * reproducible on the GPU (glibc's sinf is within 1 ulp, not correctly rounded: the test states how often they differ). */
+static int g_libm_trig = 0;
+void orc_set_libm_trig(int on) { g_libm_trig = on; }
+static inline float sin_f(float a) { return g_libm_trig ? sinf(a) : sinf_orc(a); }
+static inline float cos_f(float a) { return g_libm_trig ? cosf(a) : cosf_orc(a); }
+
+/* foot rotation = Rz(q0) Rx(q1) Ry(q2) Ry(q3) Ry(q4) in the expanded sin/cos form of SolverMPC.cpp:428-433, with the
+ * common factors named and EVERY operation in the type C++ gives it there: sin()/cos() of a float are float; the
+ * literals "1.0" / "-1.0" are double and promote the product they start and everything that product is combined with
+ * ("cos(q0)*cos(q2) - 1.0*sin(q0)*sin(q1)*sin(q2)" is a double difference of a float product and a double triple
+ * product); each matrix entry is narrowed to float once, by the comma initialiser. */
 static void foot_rotation(const float q[5], float Rf[9]) {
-  float s0 = sinf_orc(q[0]), c0 = cosf_orc(q[0]);
-  float s1 = sinf_orc(q[1]), c1 = cosf_orc(q[1]);
-  float s2 = sinf_orc(q[2]), c2 = cosf_orc(q[2]);
-  float s3 = sinf_orc(q[3]), c3 = cosf_orc(q[3]);
-  float s4 = sinf_orc(q[4]), c4 = cosf_orc(q[4]);
-  float a = c0 * s2 + (c2 * s0) * s1; /* Rz*Rx*Ry(q2) column terms */
-  float b = c0 * c2 - (s0 * s1) * s2;
-  float d = c2 * s0 + (c0 * s1) * s2;
-  float e = s0 * s2 - (c0 * c2) * s1;
-  float ca3 = c3 * a + s3 * b, sa3 = s3 * a - c3 * b;
-  float cd3 = c3 * d - s3 * e, sd3 = s3 * d + c3 * e;
-  float q234 = (q[2] + q[3]) + q[4];
-  float s234 = sinf_orc(q234), c234 = cosf_orc(q234);
-  Rf[0] = -(s4 * ca3) - c4 * sa3;
-  Rf[1] = -(c1 * s0);
-  Rf[2] = c4 * ca3 - s4 * sa3;
-  Rf[3] = c4 * cd3 - s4 * sd3;
+  const float s0 = sin_f(q[0]), c0 = cos_f(q[0]);
+  const float s1 = sin_f(q[1]), c1 = cos_f(q[1]);
+  const float s2 = sin_f(q[2]), c2 = cos_f(q[2]);
+  const float s3 = sin_f(q[3]), c3 = cos_f(q[3]);
+  const float s4 = sin_f(q[4]), c4 = cos_f(q[4]);
+  const float a = c0 * s2 + (c2 * s0) * s1;                                      /* float */
+  const double b = (double)(c0 * c2) - (((double)s0 * (double)s1) * (double)s2); /* ... - 1.0*s0*s1*s2 */
+  const float d = c2 * s0 + (c0 * s1) * s2;                                      /* float */
+  const double e = (double)(s0 * s2) - (((double)c0 * (double)c2) * (double)s1); /* ... - 1.0*c0*c2*s1 */
+  const double X = (double)(c3 * a) + (double)s3 * b;            /* cos(q3)*(a) + sin(q3)*(b) */
+  const double Y = ((double)s3 * (double)a) - (double)c3 * b;    /* 1.0*sin(q3)*(a) - cos(q3)*(b) */
+  const double P = (double)(c3 * d) - ((double)s3) * e;          /* cos(q3)*(d) - 1.0*sin(q3)*(e) */
+  const double Q = (double)(s3 * d) + (double)c3 * e;            /* sin(q3)*(d) + cos(q3)*(e) */
+  const float q234 = (q[2] + q[3]) + q[4];
+  const float s234 = sin_f(q234), c234 = cos_f(q234);
+  Rf[0] = (float)((-(double)s4) * X - (double)c4 * Y); /* - 1.0*sin(q4)*(X) - cos(q4)*(Y) */
+  Rf[1] = -(c1 * s0);                                  /* -1.0*cos(q1)*sin(q0): an exact double product, rounded once */
+  Rf[2] = (float)((double)c4 * X - (double)s4 * Y);    /* cos(q4)*(X) - sin(q4)*(Y) */
+  Rf[3] = (float)((double)c4 * P - (double)s4 * Q);    /* cos(q4)*(P) - 1.0*sin(q4)*(Q) */
   Rf[4] = c0 * c1;
-  Rf[5] = c4 * sd3 + s4 * cd3;
-  Rf[6] = -(s234 * c1);
+  Rf[5] = (float)((double)c4 * Q + (double)s4 * P);    /* cos(q4)*(Q) + sin(q4)*(P) */
+  Rf[6] = -(s234 * c1);                                /* -1.0*sin(q2+q3+q4)*cos(q1): exact double product, rounded once */
   Rf[7] = s1;
   Rf[8] = c234 * c1;
 }
@@ -288,17 +303,23 @@ ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_q
     double d0 = 1.0 - (double)(2.0f * (qx * qx + qy * qy));
     float n2 = 2.0f * (qw * qz + qx * qy);
     double d2 = 1.0 - (double)(2.0f * (qy * qy + qz * qz));
-    rpy[0] = (float)orc_atan2((double)n0, d0);
-    rpy[1] = (float)orc_asin((double)as);
-    rpy[2] = (float)orc_atan2((double)n2, d2);
+    if (g_libm_trig) { /* study switch: atan2(float, double) is the double overload, asin(float) the float one */
+      rpy[0] = (float)atan2((double)n0, d0);
+      rpy[1] = asinf(as);
+      rpy[2] = (float)atan2((double)n2, d2);
+    } else {
+      rpy[0] = (float)orc_atan2((double)n0, d0);
+      rpy[1] = (float)orc_asin((double)as);
+      rpy[2] = (float)orc_atan2((double)n2, d2);
+    }
   }
   memcpy(o->rpy, rpy, sizeof rpy);
 
   /* 4. inverse Euler-rate map (SolverMPC.cpp:65-89, used at :417) */
   float Rbi[9];
   {
-    float cy = cosf_orc(rpy[2]), sy = sinf_orc(rpy[2]);
-    float cp = cosf_orc(rpy[1]), sp = sinf_orc(rpy[1]);
+    float cy = cos_f(rpy[2]), sy = sin_f(rpy[2]);
+    float cp = cos_f(rpy[1]), sp = sin_f(rpy[1]);
     float Rb[9] = {cy * cp, -sy, 0.0f, sy * cp, cy, 0.0f, -sp, 0.0f, 1.0f};
     inverse3(Rb, Rbi);
   }

@@ -105,6 +105,7 @@ double orc_get_solution(int index);
 
 void orc_set_dense_chain(int on); /* 1: run every cost chain over all 13h rows (test of zero-block neutrality) */
 void orc_set_unfused_chain(int on); /* study switch, see hmpc_oracle.c */
+void orc_set_libm_trig(int on);     /* study switch, see hmpc_oracle.c */
 void orc_unpack_record(const unsigned char *rec, int horizon, orc_update_t *u);
 void orc_unpack_record3(const unsigned char *rec, int horizon, orc_update_t *u); /* extension records (nc = 3) */
 void orc_set_records_nc(int nc); /* record flavour orc_solve_records parses: 2 (reference) or 3 (extension) */

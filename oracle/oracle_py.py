@@ -93,6 +93,7 @@ def lib():
         L.orc_unpack_record3.argtypes = [C.c_void_p, C.c_int, C.POINTER(Update)]
         L.orc_set_records_nc.argtypes = [C.c_int]
         L.orc_set_unfused_chain.argtypes = [C.c_int]
+        L.orc_set_libm_trig.argtypes = [C.c_int]
         L.orc_mpc_gait.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_build_record.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         L.orc_body_wrench.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

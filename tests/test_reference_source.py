@@ -1,0 +1,287 @@
+"""The assembly half of the oracle, pinned against an EXECUTION OF THE REFERENCE'S OWN SOURCE.
+
+``oracle/_ref/libsolvempc_ref.so`` is ``ConvexMPC/SolverMPC.cpp`` + ``RobotState.cpp`` + ``convexMPC_interface.cpp``
+compiled unmodified from /root/reference against the Eigen stand-in ``oracle/mini_eigen`` (recipe ``oracle/Makefile``)
+and driven through the reference's own C interface.  Three statements are tested:
+
+1. structure -- ``new_vars/new_cons``, the elimination pattern (``SolverMPC.cpp:589-637``), ``lb/ub``, the body rotation --
+   is IDENTICAL between the reference's source and ``orc_assemble``/``orc_reduce`` under the default contract;
+2. with the oracle's two study switches on (separately rounded chain steps as the reference's SSE2 build performs
+   them, libm's float trigonometry as the reference's C++ overloads select it) the oracle reproduces the reference's
+   source BIT FOR BIT in x_0, A_ct, every block of A_qp and B_qp, F_control/fmat, qg and the upper triangle of qH
+   (the reference's qH is not symmetric -- ``B'(S B)`` rounds (i,j) and (j,i) differently -- the contract mirrors the
+   upper triangle); so the only differences between the contract and the reference's text are those three, each a
+   documented, separately measurable choice;
+3. under the default contract (fused chains = what the MFMA computes, deterministic trigonometry) the QP data stay
+   within binary32 round-off of the reference's source -- the bounds asserted below are the measured ones with margin --
+   and the optimal forces within the sensitivity that cond(H) ~ 2.4e6 implies.
+
+Golden fixtures generated from the same library (``tests/golden/make_ref_golden.py``) carry the reference-source
+results to boxes without /root/reference; the GPU leg compares the HIP path with them.
+"""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from hector_simulation_amd import interface, records, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "ref_source_golden.npz")
+H = 10
+DT, MU, FMAX = synthetic.DT_MPC, 0.25, synthetic.F_MAX
+
+# the BASELINE shapes the reference itself can run (h = 10: its c2qp hard-codes 10 blocks, SolverMPC.cpp:148-186)
+SHAPES = {
+    "cfg1_stand_nominal": dict(batch=1, gait="standing", seed=1, randomize=False),
+    "cfg2_walk_phase0": dict(batch=24, gait="walking", seed=2, phase=0),
+    "cfg3_walk_random_phase": dict(batch=24, gait="walking", seed=3, phase="random"),
+    "metric_2contact": dict(batch=24, gait="standing", seed=6),
+    "mixed_support": dict(batch=24, gait="mixed", seed=11, phase="random"),
+}
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import ref_py
+
+    if not ref_py.available() and not os.path.isdir("/root/reference"):
+        pytest.skip("oracle/_ref/libsolvempc_ref.so not built and /root/reference absent")
+    ref_py.lib()
+    return ref_py
+
+
+def _rows(f, nb):
+    for k in range(nb):
+        yield k, {kk: np.asarray(v)[k] for kk, v in f.items()}
+
+
+def _biteq(a, b, msg):
+    a, b = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+    assert a.shape == b.shape, msg
+    # -0.0 == +0.0 is accepted (a chain that only ever adds signed zeros); everything else must agree in every bit
+    assert np.array_equal(a, b) and np.array_equal(np.isnan(a), np.isnan(b)), msg
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_structure_identical_to_reference_source(ref, oracle, shape):
+    kw = SHAPES[shape]
+    f = synthetic.make_batch(horizon=H, **kw)
+    rec = records.pack_records(f, H)
+    for k, row in _rows(f, kw["batch"]):
+        r = ref.tick(row, H, DT, MU, FMAX, setup=(k == 0))
+        o = oracle.assemble_record(rec[k], H, DT, FMAX)
+        assert (r["n"], r["m"]) == (o["n"], o["m"])
+        np.testing.assert_array_equal(r["var_ind"], o["var_ind"])
+        np.testing.assert_array_equal(r["con_ind"], o["con_ind"])
+        _biteq(r["L_b"].ravel(), o["lb"], "L_b")
+        _biteq(r["U_b"].ravel(), o["ub"], "U_b")
+        assert np.array_equal(r["lb_red"], o["lb_red"]) and np.array_equal(r["ub_red"], o["ub_red"])
+        _biteq(r["R"], o["R"], "R (Quaternionf::toRotationMatrix)")
+        # the reference's get_solution is its q_soln, eliminated variables are exact zeros
+        assert np.array_equal(r["q_soln"], r["get_solution"])
+        assert np.all(r["q_soln"][r["var_elim"] != 0] == 0.0)
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_study_switches_reproduce_the_reference_source_bitwise(ref, oracle, shape):
+    kw = SHAPES[shape]
+    f = synthetic.make_batch(horizon=H, **kw)
+    rec = records.pack_records(f, H)
+    L = oracle.lib()
+    L.orc_set_unfused_chain(1)
+    L.orc_set_libm_trig(1)
+    try:
+        iu = np.triu_indices(12 * H)
+        for k, row in _rows(f, kw["batch"]):
+            r = ref.tick(row, H, DT, MU, FMAX, setup=(k == 0))
+            o = oracle.assemble_record(rec[k], H, DT, FMAX)
+            _biteq(r["x_0"].ravel(), o["x0"], "x_0")
+            _biteq(np.eye(13, dtype=np.float32) + np.float32(DT) * r["A_ct"], o["Acd"], "Acd")
+            _biteq(np.float32(DT) * r["B_ct_r"], o["Bcd"], "Bcd")
+            _biteq(r["A_qp"].reshape(H, 13, 13), o["Apow"][1:], "A_qp blocks = Acd^(i+1)")
+            Bq = r["B_qp"].reshape(H, 13, H, 12)
+            for i in range(H):
+                for j in range(H):
+                    if j <= i:
+                        _biteq(Bq[i, :, j, :], o["Phi"][i - j], f"B_qp block ({i},{j})")
+                    else:
+                        assert not Bq[i, :, j, :].any()
+            fm = r["fmat"].reshape(H, 16, H, 12)
+            for i in range(H):
+                for j in range(H):
+                    if i == j:
+                        _biteq(fm[i, :, j, :], o["Fc"], "fmat diagonal block = F_control")
+                    else:
+                        assert not fm[i, :, j, :].any()
+            _biteq(r["qg"].ravel(), o["g"], "qg")
+            _biteq(r["qH"][iu], o["H"][iu], "qH upper triangle")
+            assert np.array_equal(r["A_red"], o["A_red"]) and np.array_equal(r["g_red"], o["g_red"])
+            ir = np.triu_indices(r["n"])
+            assert np.array_equal(r["H_red"][ir], o["H_red"][ir])
+            # the reference's own H is NOT symmetric (the contract mirrors the upper triangle): size of that effect
+            asym = np.abs(r["qH"] - r["qH"].T).max() / np.abs(r["qH"]).max()
+            assert asym < 1.2e-7
+    finally:
+        L.orc_set_unfused_chain(0)
+        L.orc_set_libm_trig(0)
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_default_contract_within_binary32_roundoff_of_reference_source(ref, oracle, shape):
+    """Measured over these shapes: |dH|/max|H| <= 4.7e-7, |dg|/max|g| <= 3.4e-7, |dA| <= 6e-8, x_0 within one ulp in
+    ~1.5 % of the instances (glibc's sinf/cosf/asinf are within 1 ulp, not correctly rounded; the contract's
+    routines are the correctly rounded values).  Asserted with a 2x margin."""
+    kw = SHAPES[shape]
+    f = synthetic.make_batch(horizon=H, **kw)
+    rec = records.pack_records(f, H)
+    for k, row in _rows(f, kw["batch"]):
+        r = ref.tick(row, H, DT, MU, FMAX, setup=(k == 0))
+        o = oracle.assemble_record(rec[k], H, DT, FMAX)
+        assert np.abs(r["H_red"] - o["H_red"]).max() <= 1e-6 * np.abs(r["H_red"]).max()
+        assert np.abs(r["g_red"] - o["g_red"]).max() <= 1e-6 * max(1.0, np.abs(r["g_red"]).max())
+        assert np.abs(r["A_red"] - o["A_red"]).max() <= 1.2e-7
+        x0r, x0o = r["x_0"].ravel(), o["x0"]
+        assert np.all(np.abs(x0r - x0o) <= np.spacing(np.abs(x0r).astype(np.float32)))
+
+
+def test_forces_end_to_end_against_the_reference_source(ref, oracle):
+    """update_problem_data -> get_solution on the reference's own code vs the oracle (restated assembly + the same
+    qpOASES).  The two QPs differ by binary32 round-off (previous test) and cond(H) ~ 2.4e6 turns that into up to a few
+    1e-4 in the forces (measured: 3.3e-4 max / 8e-5 median standing, 6e-5 max walking) -- with the study switches on,
+    where only the lower triangle of H differs (by 2e-8), still 1.4e-4.  That is the sensitivity DESIGN.md section 3
+    documents; north_star's 1e-4 is therefore asserted on bit-identical QP data (tests/test_gpu_solve.py)."""
+    nb = 96
+    for gait, bound in (("standing", 1.5e-3), ("walking", 5e-4)):
+        f = synthetic.make_batch(nb, H, gait, seed=6, phase="random")
+        rec = records.pack_records(f, H)
+        qr = ref.solve_fields(f, H, DT, MU, FMAX)
+        qo = oracle.solve_records(rec, H, DT, FMAX)["q_soln"]
+        err = np.abs(qo - qr).max(axis=1) / np.maximum(1.0, np.abs(qr).max(axis=1))
+        assert err.max() < bound, (gait, err.max())
+        assert np.median(err) < bound / 5
+
+
+def test_reference_interface_semantics_in_a_fresh_process(ref):
+    """convexMPC_interface.cpp:105-110: get_solution returns 0 before the first solve; afterwards q_soln[index]."""
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        import numpy as np
+        from oracle import ref_py
+        from hector_simulation_amd import synthetic
+        L = ref_py.lib()
+        with ref_py.quiet():
+            ref_py.setup_problem({DT}, {H}, {MU}, {FMAX})
+        assert L.get_solution(2) == 0.0
+        f = synthetic.make_batch(1, {H}, "standing", seed=1, randomize=False)
+        row = {{k: np.asarray(v)[0] for k, v in f.items()}}
+        t = ref_py.tick(row, {H}, {DT}, {MU}, {FMAX})
+        fz = L.get_solution(2)
+        assert 40.0 < fz < 60.0, fz   # nominal standing: about half of 9 kg * 9.81 per foot (mass 9.0, SolverMPC.cpp:423)
+        print("fz", fz)
+    """)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "fz" in out.stdout
+
+
+# ---- golden fixtures generated from the reference's source (travel to boxes without /root/reference) ----
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def _gold_fields(gold, name):
+    return {k: gold[f"{name}/in/{k}"] for k in ("p", "v", "q", "w", "r", "joint_angles", "yaw", "weights", "Alpha_K",
+                                               "traj", "gait")}
+
+
+def test_reference_source_reproduces_its_goldens(ref, gold):
+    for name in gold["shapes"]:
+        f = _gold_fields(gold, name)
+        for k, row in _rows(f, int(gold[f"{name}/batch"])):
+            t = ref.tick(row, H, DT, MU, FMAX, setup=(k == 0))
+            p = f"{name}/{k}/"
+            np.testing.assert_array_equal(t["var_ind"], gold[p + "var_ind"])
+            for key in ("H_red", "g_red", "A_red", "lb_red", "ub_red"):
+                assert np.array_equal(t[key], gold[p + key].astype(np.float64)), key
+            np.testing.assert_allclose(t["q_soln"], gold[p + "q_soln"], rtol=0, atol=1e-9)
+
+
+def test_oracle_against_reference_source_goldens(oracle, gold):
+    """Runs wherever the fixture is (no reference library needed): structure identical, data within round-off."""
+    for name in gold["shapes"]:
+        f = _gold_fields(gold, name)
+        rec = records.pack_records(f, H)
+        for k in range(int(gold[f"{name}/batch"])):
+            o = oracle.assemble_record(rec[k], H, DT, FMAX)
+            p = f"{name}/{k}/"
+            np.testing.assert_array_equal(o["var_ind"], gold[p + "var_ind"])
+            np.testing.assert_array_equal(o["con_ind"], gold[p + "con_ind"])
+            assert np.array_equal(o["lb_red"], gold[p + "lb_red"].astype(np.float64))
+            assert np.array_equal(o["ub_red"], gold[p + "ub_red"].astype(np.float64))
+            _biteq(o["R"], gold[p + "R"], "R")
+            Hg = gold[p + "H_red"].astype(np.float64)
+            assert np.abs(o["H_red"] - Hg).max() <= 1e-6 * np.abs(Hg).max()
+            assert np.abs(o["g_red"] - gold[p + "g_red"]).max() <= 1e-6 * max(1.0, np.abs(gold[p + "g_red"]).max())
+            assert np.abs(o["A_red"] - gold[p + "A_red"]).max() <= 1.2e-7
+
+
+@pytest.mark.gpu
+def test_hip_against_reference_source_goldens(gold):
+    """The HIP path against results computed by the reference's own source: same reduced structure, QP data within
+    binary32 round-off, forces within the cond(H) sensitivity (see test_forces_end_to_end_...)."""
+    for name in gold["shapes"]:
+        f = _gold_fields(gold, name)
+        nb = int(gold[f"{name}/batch"])
+        rec = records.pack_records(f, H)
+        mpc = interface.BatchedMPC(DT, H, FMAX, nb)
+        mpc.upload(rec)
+        mpc.solve()
+        forces, status = mpc.download()
+        assert (interface.status_code(status) == 0).all()
+        for k in range(nb):
+            d = mpc.debug_assemble(k)
+            p = f"{name}/{k}/"
+            np.testing.assert_array_equal(d["var_ind"], gold[p + "var_ind"])
+            assert d["n"] == len(gold[p + "var_ind"]) and d["m"] == len(gold[p + "con_ind"])
+            Hg = gold[p + "H_red"].astype(np.float64)
+            assert np.abs(d["H"] - Hg).max() <= 1e-6 * np.abs(Hg).max()
+            assert np.abs(d["g"] - gold[p + "g_red"]).max() <= 1e-6 * max(1.0, np.abs(gold[p + "g_red"]).max())
+            assert np.abs(d["Fc"] - gold[p + "F_control"]).max() <= 1.2e-7
+            _biteq(d["lb"][: 16 * H][gold[p + "con_ind"]], gold[p + "lb_red"], "lb")
+            _biteq(d["ub"][: 16 * H][gold[p + "con_ind"]], gold[p + "ub_red"], "ub")
+            q = gold[p + "q_soln"]
+            err = np.abs(forces[k] - q).max() / max(1.0, np.abs(q).max())
+            assert err < 1.5e-3, (name, k, err)
+        mpc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["cfg2_walk_1024", "metric_2contact_1024"])
+def test_hip_full_batch_against_the_reference_source(cfg):
+    """ALL 1 024 instances of BASELINE config 2 and of the metric's 2-contact case: the HIP path end to end against the
+    reference's own update_problem_data/get_solution (the prebuilt oracle/_ref library travels to the GPU box)."""
+    from oracle import ref_py
+
+    if not ref_py.available():
+        pytest.skip("oracle/_ref/libsolvempc_ref.so not on this box")
+    kw = synthetic.CONFIGS[cfg]
+    f = synthetic.make_batch(**kw)
+    nb = kw["batch"]
+    rec = records.pack_records(f, H)
+    mpc = interface.BatchedMPC(DT, H, FMAX, nb)
+    mpc.upload(rec)
+    mpc.solve()
+    forces, status = mpc.download()
+    mpc.close()
+    assert (interface.status_code(status) == 0).all()
+    qr = ref_py.solve_fields(f, H, DT, MU, FMAX)
+    err = np.abs(forces - qr).max(axis=1) / np.maximum(1.0, np.abs(qr).max(axis=1))
+    print(f"{cfg}: force error vs the reference's own source: max {err.max():.2e}, median {np.median(err):.2e}")
+    assert err.max() < (1.5e-3 if "2contact" in cfg else 5e-4)
+    assert np.median(err) < 2e-4
