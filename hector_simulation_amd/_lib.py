@@ -17,6 +17,11 @@ EXPORTS = [
     "hmpc_build_records", "hmpc_build_records_device", "hmpc_body_wrench", "hmpc_body_wrench_device", "hmpc_leg_torques", "hmpc_leg_torques_device",
     "hmpc_download_records", "hmpc_debug_assemble", "hmpc_debug_phase_cycles", "hmpc_download_f64", "hmpc_last_hip_error", "hmpc_version",
     "hmpc_upload_records_async", "hmpc_download_async", "hmpc_set_tick_warm_start", "hmpc_reset_tick_warm_start", "hmpc_create_ex", "hmpc_contacts", "hmpc_record_stride_ex", "hmpc_pack_record_ex",
+    "hmpc_enable_f64_output",
+    "hmpc_shard_bounds", "hmpc_group_create", "hmpc_group_destroy", "hmpc_group_size", "hmpc_group_transport",
+    "hmpc_group_batch", "hmpc_group_member", "hmpc_group_upload_records", "hmpc_group_set_device_records",
+    "hmpc_group_solve", "hmpc_group_post_gather", "hmpc_group_wait_gather", "hmpc_group_device_gathered",
+    "hmpc_group_gather_wrench", "hmpc_group_download", "hmpc_group_synchronize", "hmpc_group_last_error",
 ]
 
 
@@ -118,6 +123,19 @@ def load():
     L.hmpc_download_records.argtypes = [vp, vp]
     L.hmpc_leg_torques.argtypes = [vp, vp, vp, vp, vp]
     L.hmpc_leg_torques_device.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.hmpc_enable_f64_output.argtypes = [vp]
+    L.hmpc_shard_bounds.argtypes = [ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]
+    L.hmpc_group_create.argtypes = [C.POINTER(vp), C.POINTER(ProblemSetup), vp, ci, ci, ci]
+    for name in ("hmpc_group_destroy", "hmpc_group_size", "hmpc_group_transport", "hmpc_group_batch", "hmpc_group_solve",
+                 "hmpc_group_post_gather", "hmpc_group_wait_gather", "hmpc_group_synchronize"):
+        getattr(L, name).argtypes = [vp]
+    L.hmpc_group_member.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(vp)]
+    L.hmpc_group_upload_records.argtypes = [vp, vp, ci]
+    L.hmpc_group_set_device_records.argtypes = [vp, vp, ci, ci]
+    L.hmpc_group_device_gathered.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(ci)]
+    L.hmpc_group_gather_wrench.argtypes = [vp, vp, vp]
+    L.hmpc_group_download.argtypes = [vp, vp, vp]
+    L.hmpc_group_last_error.restype = C.c_char_p
     L.hmpc_debug_phase_cycles.argtypes = [vp, vp]
     L.hmpc_last_hip_error.restype = C.c_char_p
     L.hmpc_version.restype = C.c_char_p

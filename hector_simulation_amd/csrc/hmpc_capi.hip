@@ -94,6 +94,41 @@ struct hmpc_handle {
   int max_stance;  // max reduced variables of the current batch (known only for host-uploaded records; else -1)
   hipStream_t last_stream;
   bool attrs_set[N_VARIANTS];
+  // persistent device scratch for the host-pointer convenience entry points (grown on demand, freed in hmpc_destroy):
+  // no hipMalloc/hipFree per call and nothing to leak on an early error return
+  void *d_scratch;
+  size_t scratch_bytes;
+  // number of instances the solve kernels have flagged (working set full / max-iter / infeasible / KKT) since the handle
+  // was created; monotonically increasing device counter, hmpc_download compares it with the value it saw last and
+  // skips the status scan of the safe pass when nothing new was flagged
+  unsigned int *d_flagged;
+  unsigned int flagged_seen;
+};
+
+// returns a device buffer of at least `bytes` owned by the handle (contents undefined)
+static int scratch(hmpc_handle *h, size_t bytes, void **out) {
+  if (bytes > h->scratch_bytes) {
+    if (h->d_scratch) {
+      HIP_TRY(hipDeviceSynchronize());  // a previous user of the old buffer may still be in flight
+      HIP_TRY(hipFree(h->d_scratch));
+      h->d_scratch = nullptr;
+      h->scratch_bytes = 0;
+    }
+    const size_t want = (bytes + 4095) & ~(size_t)4095;
+    HIP_TRY(hipMalloc(&h->d_scratch, want));
+    h->scratch_bytes = want;
+  }
+  *out = h->d_scratch;
+  return HMPC_OK;
+}
+
+// RAII for the two timing events of hmpc_time_solve
+struct EventPair {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~EventPair() {
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+  }
 };
 
 static const Variant &pick_variant(const hmpc_handle *h, int *index) {
@@ -115,8 +150,10 @@ static const Variant &pick_variant(const hmpc_handle *h, int *index) {
   return v[best];
 }
 
+// warm: -1 = the handle's setting, 0/1 = override for this launch (the safe pass starts cold without touching the handle);
+// carry_wset = false keeps a repeated launch of the same batch from consuming/advancing the tick-to-tick working sets
 static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int dbg_index, const int *d_index_list = nullptr,
-                  int n_list = 0, double relax = 0.0) {
+                  int n_list = 0, double relax = 0.0, int warm = -1, bool carry_wset = true) {
   int vi = 0;
   const Variant *pv = &pick_variant(h, &vi);
   if (d_index_list) {  // safe variant: working set as large as the variable count
@@ -145,12 +182,14 @@ static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int db
   a.dbg_f = h->d_dbg_f;
   a.dbg_i = h->d_dbg_i;
   a.prof = h->d_prof;
-  a.warm = h->warm;
+  a.warm = (warm < 0) ? h->warm : warm;
   a.index_list = d_index_list;
-  a.wset = (h->tick_warm && !assemble_only) ? h->d_wset : nullptr;
+  a.wset = (h->tick_warm && !assemble_only && carry_wset) ? h->d_wset : nullptr;
+  a.flagged = h->d_flagged;
   a.wset_shift = h->tick_shift;
   a.relax = relax;
   const int grid = assemble_only ? 1 : (d_index_list ? n_list : h->batch);
+  if (grid < 1) return HMPC_OK;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(v.nt), v.smem, stream, a);
   HIP_TRY(hipGetLastError());
   return HMPC_OK;
@@ -244,6 +283,12 @@ int hmpc_create_ex(hmpc_handle **out, const struct problem_setup *setup, int max
     hmpc_destroy(h);
     return HMPC_E_HIP;
   }
+  if (hipMalloc(&h->d_flagged, sizeof(unsigned int)) != hipSuccess ||
+      hipMemset(h->d_flagged, 0, sizeof(unsigned int)) != hipSuccess) {
+    g_hip_err = "hipMalloc failed in hmpc_create";
+    hmpc_destroy(h);
+    return HMPC_E_HIP;
+  }
   h->d_records = h->d_records_own;
   h->d_forces = h->d_forces_own;
   h->d_status = h->d_status_own;
@@ -263,6 +308,8 @@ int hmpc_destroy(hmpc_handle *h) {
   if (h->d_dbg_i) hipFree(h->d_dbg_i);
   if (h->d_prof) hipFree(h->d_prof);
   if (h->d_wset) hipFree(h->d_wset);
+  if (h->d_scratch) hipFree(h->d_scratch);
+  if (h->d_flagged) hipFree(h->d_flagged);
   delete h;
   return HMPC_OK;
 }
@@ -395,18 +442,23 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
     if (c == HMPC_S_WORKSET || c == HMPC_S_MAXITER || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT) idx.push_back(i);
   }
   if (idx.empty()) return HMPC_OK;
-  int *d_idx = nullptr;
-  HIP_TRY(hipMalloc(&d_idx, idx.size() * sizeof(int)));
+  int *d_idx = nullptr;  // lives in the handle's scratch: nothing to free on the error paths below
+  {
+    void *sp = nullptr;
+    const int rc = scratch(h, idx.size() * sizeof(int), &sp);
+    if (rc != HMPC_OK) return rc;
+    d_idx = (int *)sp;
+  }
   HIP_TRY(hipMemcpy(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
-  const int warm = h->warm;
-  h->warm = 0;  // the safe pass starts cold, as the reference does
-  int rc = launch(h, h->last_stream, false, 0, d_idx, (int)idx.size());
-  if (rc == HMPC_OK) rc = (hipStreamSynchronize(h->last_stream) == hipSuccess) ? HMPC_OK : HMPC_E_HIP;
+  // the safe pass starts cold, as the reference does (launch parameter; the handle's own setting is not touched)
+  int rc = launch(h, h->last_stream, false, 0, d_idx, (int)idx.size(), 0.0, /*warm=*/0);
+  if (rc != HMPC_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
   if (n_resolved) *n_resolved = (int)idx.size();
   // last resort for instances that cycle at a degenerate vertex even with the full-size working set: bounds moved outward
   // by 1e-7, then 1e-6 (a different amount per row), reported as HMPC_S_OK_RELAXED
   const double relax_levels[2] = {1e-7, 1e-6};
-  for (int lvl = 0; lvl < 2 && rc == HMPC_OK; ++lvl) {
+  for (int lvl = 0; lvl < 2; ++lvl) {
     std::vector<int> still;
     HIP_TRY(hipMemcpy(st.data(), h->d_status, (size_t)h->batch * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (int i : idx) {
@@ -415,20 +467,32 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
     }
     if (still.empty()) break;
     HIP_TRY(hipMemcpy(d_idx, still.data(), still.size() * sizeof(int), hipMemcpyHostToDevice));
-    rc = launch(h, h->last_stream, false, 0, d_idx, (int)still.size(), relax_levels[lvl]);
-    if (rc == HMPC_OK) rc = (hipStreamSynchronize(h->last_stream) == hipSuccess) ? HMPC_OK : HMPC_E_HIP;
+    rc = launch(h, h->last_stream, false, 0, d_idx, (int)still.size(), relax_levels[lvl], /*warm=*/0);
+    if (rc != HMPC_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->last_stream));
   }
-  h->warm = warm;
-  hipFree(d_idx);
-  return rc;
+  return HMPC_OK;
+}
+
+// the safe pass of hmpc_download / hmpc_download_f64: one 4-byte read of the device's flagged counter decides whether
+// the status words need to be scanned at all (they almost never do: nominal inputs flag nothing)
+static int resolve_if_flagged(hmpc_handle *h) {
+  unsigned int now = 0;
+  HIP_TRY(hipMemcpy(&now, h->d_flagged, sizeof(now), hipMemcpyDeviceToHost));
+  if (now == h->flagged_seen) return HMPC_OK;
+  const int rc = hmpc_resolve_failed(h, nullptr);
+  if (rc != HMPC_OK) return rc;
+  HIP_TRY(hipMemcpy(&now, h->d_flagged, sizeof(now), hipMemcpyDeviceToHost));  // the safe pass may have flagged again
+  h->flagged_seen = now;
+  return HMPC_OK;
 }
 
 int hmpc_download(hmpc_handle *h, float *forces, uint32_t *status) {
   if (!h) return HMPC_E_ARG;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->last_stream));
-  if (h->auto_resolve) {
-    int rc = hmpc_resolve_failed(h, nullptr);
+  if (h->auto_resolve && h->batch) {
+    int rc = resolve_if_flagged(h);
     if (rc != HMPC_OK) return rc;
   }
   const size_t nf = (size_t)h->batch * 6 * h->nc * h->setup.horizon;
@@ -450,23 +514,23 @@ int hmpc_horizon(const hmpc_handle *h) { return h ? h->setup.horizon : HMPC_E_AR
 
 int hmpc_time_solve(hmpc_handle *h, void *stream, int reps, float *ms_per_launch) {
   if (!h || reps < 1 || !ms_per_launch) return HMPC_E_ARG;
+  *ms_per_launch = 0.f;
+  if (h->batch == 0) return HMPC_OK;
   HIP_TRY(hipSetDevice(h->device));
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  EventPair ev;  // destroyed on every return path
+  HIP_TRY(hipEventCreate(&ev.e0));
+  HIP_TRY(hipEventCreate(&ev.e1));
   hipStream_t s = (hipStream_t)stream;
   h->last_stream = s;
-  HIP_TRY(hipEventRecord(e0, s));
+  HIP_TRY(hipEventRecord(ev.e0, s));
   for (int i = 0; i < reps; ++i) {
-    int rc = launch(h, s, false, 0);
+    int rc = launch(h, s, false, 0, nullptr, 0, 0.0, -1, /*carry_wset=*/false);
     if (rc != HMPC_OK) return rc;
   }
-  HIP_TRY(hipEventRecord(e1, s));
-  HIP_TRY(hipEventSynchronize(e1));
+  HIP_TRY(hipEventRecord(ev.e1, s));
+  HIP_TRY(hipEventSynchronize(ev.e1));
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
   *ms_per_launch = ms / (float)reps;
   return HMPC_OK;
 }
@@ -556,19 +620,19 @@ int hmpc_build_records(hmpc_handle *h, const struct hmpc_tick_inputs *host_ticks
   if (!h || !host_ticks || batch < 0) return HMPC_E_ARG;
   if (batch > h->max_batch) return HMPC_E_BATCH;
   HIP_TRY(hipSetDevice(h->device));
-  hmpc_tick_inputs *d_t = nullptr;
-  double *d_w = nullptr;
-  HIP_TRY(hipMalloc(&d_t, sizeof(hmpc_tick_inputs) * (size_t)(batch > 0 ? batch : 1)));
-  HIP_TRY(hipMalloc(&d_w, sizeof(double) * 2 * (size_t)(batch > 0 ? batch : 1)));
+  const size_t nb = (size_t)(batch > 0 ? batch : 1);
+  const size_t off_w = (sizeof(hmpc_tick_inputs) * nb + 255) & ~(size_t)255;
+  void *sp = nullptr;
+  int rc = scratch(h, off_w + sizeof(double) * 2 * nb, &sp);
+  if (rc != HMPC_OK) return rc;
+  hmpc_tick_inputs *d_t = (hmpc_tick_inputs *)sp;
+  double *d_w = (double *)((char *)sp + off_w);
   HIP_TRY(hipMemcpy(d_t, host_ticks, sizeof(hmpc_tick_inputs) * (size_t)batch, hipMemcpyHostToDevice));
-  int rc = hmpc_build_records_device(h, d_t, batch, dtMPC, d_w, nullptr);
-  if (rc == HMPC_OK) {
-    HIP_TRY(hipDeviceSynchronize());
-    if (wpd_out && batch) HIP_TRY(hipMemcpy(wpd_out, d_w, sizeof(double) * 2 * (size_t)batch, hipMemcpyDeviceToHost));
-  }
-  hipFree(d_t);
-  hipFree(d_w);
-  return rc;
+  rc = hmpc_build_records_device(h, d_t, batch, dtMPC, d_w, nullptr);
+  if (rc != HMPC_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  if (wpd_out && batch) HIP_TRY(hipMemcpy(wpd_out, d_w, sizeof(double) * 2 * (size_t)batch, hipMemcpyDeviceToHost));
+  return HMPC_OK;
 }
 
 int hmpc_body_wrench_device(hmpc_handle *h, const double *device_rBody, double *device_f_ff, void *stream) {
@@ -586,21 +650,20 @@ int hmpc_body_wrench_device(hmpc_handle *h, const double *device_rBody, double *
 
 int hmpc_body_wrench(hmpc_handle *h, const double *host_rBody, double *host_f_ff) {
   if (!h || !host_rBody || !host_f_ff) return HMPC_E_ARG;
+  if (h->batch == 0) return HMPC_OK;
   HIP_TRY(hipSetDevice(h->device));
-  const size_t b = (size_t)(h->batch > 0 ? h->batch : 1);
-  double *d_r = nullptr, *d_f = nullptr;
-  HIP_TRY(hipMalloc(&d_r, sizeof(double) * 9 * b));
-  HIP_TRY(hipMalloc(&d_f, sizeof(double) * 12 * b));
-  HIP_TRY(hipMemcpy(d_r, host_rBody, sizeof(double) * 9 * (size_t)h->batch, hipMemcpyHostToDevice));
+  const size_t b = (size_t)h->batch;
+  void *sp = nullptr;
+  int rc = scratch(h, sizeof(double) * (9 + 12) * b, &sp);
+  if (rc != HMPC_OK) return rc;
+  double *d_r = (double *)sp, *d_f = d_r + 9 * b;
+  HIP_TRY(hipMemcpy(d_r, host_rBody, sizeof(double) * 9 * b, hipMemcpyHostToDevice));
   HIP_TRY(hipStreamSynchronize(h->last_stream));
-  int rc = hmpc_body_wrench_device(h, d_r, d_f, nullptr);
-  if (rc == HMPC_OK) {
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(host_f_ff, d_f, sizeof(double) * 12 * (size_t)h->batch, hipMemcpyDeviceToHost));
-  }
-  hipFree(d_r);
-  hipFree(d_f);
-  return rc;
+  rc = hmpc_body_wrench_device(h, d_r, d_f, nullptr);
+  if (rc != HMPC_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipMemcpy(host_f_ff, d_f, sizeof(double) * 12 * b, hipMemcpyDeviceToHost));
+  return HMPC_OK;
 }
 
 int hmpc_leg_torques_device(hmpc_handle *h, const double *device_rBody, const double *device_leg_q, double *device_f_ff,
@@ -619,24 +682,22 @@ int hmpc_leg_torques_device(hmpc_handle *h, const double *device_rBody, const do
 
 int hmpc_leg_torques(hmpc_handle *h, const double *host_rBody, const double *host_leg_q, double *host_f_ff, double *host_tau) {
   if (!h || !host_rBody || !host_leg_q || !host_tau) return HMPC_E_ARG;
+  if (h->batch == 0) return HMPC_OK;
   HIP_TRY(hipSetDevice(h->device));
-  const size_t b = (size_t)(h->batch > 0 ? h->batch : 1), nb = (size_t)h->batch;
-  double *d_r = nullptr, *d_q = nullptr, *d_f = nullptr, *d_t = nullptr;
-  HIP_TRY(hipMalloc(&d_r, sizeof(double) * 9 * b));
-  HIP_TRY(hipMalloc(&d_q, sizeof(double) * 10 * b));
-  HIP_TRY(hipMalloc(&d_f, sizeof(double) * 12 * b));
-  HIP_TRY(hipMalloc(&d_t, sizeof(double) * 10 * b));
+  const size_t nb = (size_t)h->batch;
+  void *sp = nullptr;
+  int rc = scratch(h, sizeof(double) * (9 + 10 + 12 + 10) * nb, &sp);
+  if (rc != HMPC_OK) return rc;
+  double *d_r = (double *)sp, *d_q = d_r + 9 * nb, *d_f = d_q + 10 * nb, *d_t = d_f + 12 * nb;
   HIP_TRY(hipMemcpy(d_r, host_rBody, sizeof(double) * 9 * nb, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_q, host_leg_q, sizeof(double) * 10 * nb, hipMemcpyHostToDevice));
   HIP_TRY(hipStreamSynchronize(h->last_stream));
-  int rc = hmpc_leg_torques_device(h, d_r, d_q, d_f, d_t, nullptr);
-  if (rc == HMPC_OK) {
-    HIP_TRY(hipDeviceSynchronize());
-    if (host_f_ff) HIP_TRY(hipMemcpy(host_f_ff, d_f, sizeof(double) * 12 * nb, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(host_tau, d_t, sizeof(double) * 10 * nb, hipMemcpyDeviceToHost));
-  }
-  hipFree(d_r), hipFree(d_q), hipFree(d_f), hipFree(d_t);
-  return rc;
+  rc = hmpc_leg_torques_device(h, d_r, d_q, d_f, d_t, nullptr);
+  if (rc != HMPC_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  if (host_f_ff) HIP_TRY(hipMemcpy(host_f_ff, d_f, sizeof(double) * 12 * nb, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(host_tau, d_t, sizeof(double) * 10 * nb, hipMemcpyDeviceToHost));
+  return HMPC_OK;
 }
 
 int hmpc_download_records(hmpc_handle *h, void *host_records) {
@@ -647,18 +708,38 @@ int hmpc_download_records(hmpc_handle *h, void *host_records) {
   return HMPC_OK;
 }
 
-int hmpc_download_f64(hmpc_handle *h, double *x, double *obj) {
+int hmpc_enable_f64_output(hmpc_handle *h) {
   if (!h) return HMPC_E_ARG;
+  if (h->d_x64) return HMPC_OK;
   HIP_TRY(hipSetDevice(h->device));
   const size_t nf = (size_t)h->max_batch * 6 * h->nc * h->setup.horizon;
+  HIP_TRY(hipMalloc(&h->d_x64, nf * sizeof(double)));
+  if (hipMalloc(&h->d_obj64, (size_t)h->max_batch * sizeof(double)) != hipSuccess) {
+    hipFree(h->d_x64);
+    h->d_x64 = nullptr;
+    g_hip_err = "hipMalloc failed in hmpc_enable_f64_output";
+    return HMPC_E_HIP;
+  }
+  return HMPC_OK;
+}
+
+int hmpc_download_f64(hmpc_handle *h, double *x, double *obj) {
+  if (!h) return HMPC_E_ARG;
+  if (h->batch == 0) return HMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
   if (!h->d_x64) {
-    // first use: allocate and re-run the last batch with the binary64 copy-out enabled
-    HIP_TRY(hipMalloc(&h->d_x64, nf * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->d_obj64, (size_t)h->max_batch * sizeof(double)));
-    int rc = launch(h, h->last_stream, false, 0);
+    // the copy-out was not enabled before the solve: enable it and run the current batch once more -- without consuming
+    // the tick-to-tick working sets a second time -- then give flagged instances the same safe pass hmpc_download gives
+    int rc = hmpc_enable_f64_output(h);
+    if (rc != HMPC_OK) return rc;
+    rc = launch(h, h->last_stream, false, 0, nullptr, 0, 0.0, -1, /*carry_wset=*/false);
     if (rc != HMPC_OK) return rc;
   }
   HIP_TRY(hipStreamSynchronize(h->last_stream));
+  if (h->auto_resolve) {
+    const int rc = resolve_if_flagged(h);
+    if (rc != HMPC_OK) return rc;
+  }
   const size_t nb = (size_t)h->batch * 6 * h->nc * h->setup.horizon;
   if (x && nb) HIP_TRY(hipMemcpy(x, h->d_x64, nb * sizeof(double), hipMemcpyDeviceToHost));
   if (obj && h->batch) HIP_TRY(hipMemcpy(obj, h->d_obj64, (size_t)h->batch * sizeof(double), hipMemcpyDeviceToHost));
@@ -697,7 +778,10 @@ void setup_problem(double dt, int horizon, double mu, double f_max) {
     g_handle = nullptr;
   }
   if (!g_handle) {
-    int rc = hmpc_create(&g_handle, &g_setup, 1, 0);
+    // the reference has no notion of a device: HMPC_DEVICE (default 0) picks the GPU of the process-global solver
+    const char *env = getenv("HMPC_DEVICE");
+    const int dev = (env && *env) ? atoi(env) : 0;
+    int rc = hmpc_create(&g_handle, &g_setup, 1, dev);
     if (rc != HMPC_OK) {
       fprintf(stderr, "[hector_mpc_hip] setup_problem failed (%d): %s\n", rc, hmpc_last_hip_error());
       g_handle = nullptr;
@@ -736,7 +820,11 @@ static void solve_global(void) {
     return;
   }
   g_last_status = st;
-  if (HMPC_STATUS_CODE(st) != HMPC_S_OK) printf("failed to solve!\n");  // SolverMPC.cpp:714-715
+  // SolverMPC.cpp:714-715: the reference prints this line and scatters whatever qpOASES left in q_red all the same; so do
+  // we (the forces of a flagged instance are the last iterate; hmpc_last_status() tells the caller, which the reference
+  // cannot).  HMPC_S_OK_RELAXED is a solved instance.
+  const uint32_t code = HMPC_STATUS_CODE(st);
+  if (code != HMPC_S_OK && code != HMPC_S_OK_RELAXED) printf("failed to solve!\n");
   for (int i = 0; i < 12 * hz; ++i) g_q_soln[i] = (double)forces[i];
   g_has_solved = 1;
 }

@@ -1,0 +1,456 @@
+// hmpc_group.hip -- multi-device handle group behind the C ABI (include/hector_mpc.h, "device groups").
+//
+// SURVEY.md section 8(e), literally: every MPC instance is an independent QP, so a batch is cut into contiguous slices,
+// one per GPU of the node, solved with no data-path collective; the single exchange step is the gather of the step-0
+// wrenches (the 12 values ConvexMPCLocomotion.cpp:419-440 reads through get_solution(0..11)) and status words.
+// Single process, one communicator (ncclCommInitAll), grouped ncclAllGather on per-device streams, no host staging in
+// the collective; the host copy of the gathered block is one D2H from the first member.
+//
+// Built only from the public per-device C ABI (hmpc_create / hmpc_upload_records_async / hmpc_solve / ...): a group is
+// a composition of handles, it has no access to their internals.
+//
+// Transport of the gather:
+//   HMPC_GROUP_RCCL  librccl is dlopen'ed on first use (the library itself does not link it: a single-GPU user never
+//                    loads it, and the process may already hold another copy, e.g. the one PyTorch bundles).
+//   HMPC_GROUP_P2P   hipMemcpyPeerAsync of every member's packed slice into every member's gathered buffer
+//                    (G*(G-1) small copies over xGMI).  Required when a device is listed twice (RCCL refuses two ranks
+//                    on one GPU) -- which is how the slicing, packing, stream ordering and layout are exercised on a
+//                    one-GPU box (tests/test_gpu_group.py).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hector_mpc.h"
+
+namespace {
+
+// ---- the handful of RCCL entry points, resolved at run time (signatures: rccl.h of ROCm 7.2) ----
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;  // ncclSuccess == 0
+enum { NCCL_INT32 = 2 };   // ncclDataType_t: ncclInt8 0, ncclUint8 1, ncclInt32 2
+struct Rccl {
+  void *dl = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+  bool load() {
+    if (dl) return true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+      dl = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (dl) break;
+    }
+    if (!dl) {
+      err = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "not found");
+      return false;
+    }
+#define SYM(field, name)                                    \
+  *(void **)(&field) = dlsym(dl, name);                     \
+  if (!field) {                                             \
+    err = std::string("librccl lacks ") + name;             \
+    return false;                                           \
+  }
+    SYM(CommInitAll, "ncclCommInitAll")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(AllGather, "ncclAllGather")
+    SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    return true;
+  }
+};
+Rccl g_rccl;
+thread_local std::string g_group_err;
+
+#define GHIP(expr)                                                          \
+  do {                                                                      \
+    hipError_t _e = (expr);                                                 \
+    if (_e != hipSuccess) {                                                 \
+      g_group_err = std::string(#expr) + ": " + hipGetErrorString(_e);      \
+      return HMPC_E_HIP;                                                    \
+    }                                                                       \
+  } while (0)
+#define GNCCL(expr)                                                                      \
+  do {                                                                                   \
+    ncclResult_t _r = (expr);                                                            \
+    if (_r != 0) {                                                                       \
+      g_group_err = std::string(#expr) + ": " + g_rccl.GetErrorString(_r);               \
+      return HMPC_E_HIP;                                                                 \
+    }                                                                                    \
+  } while (0)
+
+constexpr int PACK_WORDS = 13;  // 12 step-0 values (F_L F_R M_L M_R) + the status word, per instance
+
+// forces [n][12h] float, status [n] -> packed [n][13] 32-bit words (one coalesced row per instance)
+__global__ void pack_step0_kernel(const float *__restrict__ forces, const uint32_t *__restrict__ status, int n, int width,
+                                  uint32_t *__restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * PACK_WORDS) return;
+  const int i = t / PACK_WORDS, c = t % PACK_WORDS;
+  out[t] = (c < 12) ? __float_as_uint(forces[(size_t)i * width + c]) : status[i];
+}
+
+struct Member {
+  int device = 0;
+  hmpc_handle *h = nullptr;
+  hipStream_t solve_stream = nullptr, comm_stream = nullptr;
+  hipEvent_t packed = nullptr, gathered_ev = nullptr;
+  uint32_t *d_pack = nullptr;      // [cap][13]
+  uint32_t *d_gathered = nullptr;  // [G][cap][13]
+  int lo = 0, n = 0;               // slice of the current batch
+};
+
+}  // namespace
+
+struct hmpc_group {
+  problem_setup setup;
+  int G = 0, cap = 0 /* instances per member buffer = largest possible slice */, max_batch = 0, batch = 0;
+  int transport = HMPC_GROUP_RCCL;
+  std::vector<Member> m;
+  std::vector<ncclComm_t> comms;
+  uint32_t *h_stage = nullptr;  // pinned [G][cap][13]
+  bool gather_posted = false;
+};
+
+extern "C" {
+
+const char *hmpc_group_last_error(void) { return g_group_err.empty() ? hmpc_last_hip_error() : g_group_err.c_str(); }
+
+int hmpc_shard_bounds(int global_batch, int n_shards, int index, int *lo, int *hi) {
+  if (global_batch < 0 || n_shards < 1 || index < 0 || index >= n_shards || !lo || !hi) return HMPC_E_ARG;
+  const int base = global_batch / n_shards, extra = global_batch % n_shards;
+  *lo = index * base + (index < extra ? index : extra);
+  *hi = *lo + base + (index < extra ? 1 : 0);
+  return HMPC_OK;
+}
+
+int hmpc_group_destroy(hmpc_group *g) {
+  if (!g) return HMPC_E_ARG;
+  for (Member &mb : g->m) {
+    hipSetDevice(mb.device);
+    if (mb.solve_stream) hipStreamSynchronize(mb.solve_stream);
+    if (mb.comm_stream) hipStreamSynchronize(mb.comm_stream);
+  }
+  for (ncclComm_t c : g->comms)
+    if (c) g_rccl.CommDestroy(c);
+  for (Member &mb : g->m) {
+    hipSetDevice(mb.device);
+    if (mb.h) hmpc_destroy(mb.h);
+    if (mb.d_pack) hipFree(mb.d_pack);
+    if (mb.d_gathered) hipFree(mb.d_gathered);
+    if (mb.packed) hipEventDestroy(mb.packed);
+    if (mb.gathered_ev) hipEventDestroy(mb.gathered_ev);
+    if (mb.solve_stream) hipStreamDestroy(mb.solve_stream);
+    if (mb.comm_stream) hipStreamDestroy(mb.comm_stream);
+  }
+  if (g->h_stage) hipHostFree(g->h_stage);
+  delete g;
+  return HMPC_OK;
+}
+
+int hmpc_group_create(hmpc_group **out, const struct problem_setup *setup, const int *devices, int n_devices,
+                      int max_batch, int transport) {
+  if (!out || !setup || n_devices < 1 || max_batch < 1) return HMPC_E_ARG;
+  if (transport != HMPC_GROUP_AUTO && transport != HMPC_GROUP_RCCL && transport != HMPC_GROUP_P2P) return HMPC_E_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    g_group_err = "no HIP device visible (libhector_mpc_hip has no CPU fallback)";
+    return HMPC_E_NO_DEVICE;
+  }
+  hmpc_group *g = new (std::nothrow) hmpc_group();
+  if (!g) return HMPC_E_ARG;
+  g->setup = *setup;
+  g->G = n_devices;
+  g->max_batch = max_batch;
+  g->cap = (max_batch + n_devices - 1) / n_devices;
+  g->m.resize(n_devices);
+  bool repeated = false;
+  for (int i = 0; i < n_devices; ++i) {
+    g->m[i].device = devices ? devices[i] : i;
+    if (g->m[i].device < 0 || g->m[i].device >= ndev) {
+      g_group_err = "device index outside hipGetDeviceCount()";
+      hmpc_group_destroy(g);
+      return HMPC_E_NO_DEVICE;
+    }
+    for (int j = 0; j < i; ++j) repeated |= (g->m[j].device == g->m[i].device);
+  }
+  if (transport == HMPC_GROUP_AUTO) transport = repeated ? HMPC_GROUP_P2P : HMPC_GROUP_RCCL;
+  if (transport == HMPC_GROUP_RCCL && repeated) {
+    g_group_err = "RCCL refuses two ranks on one device: list distinct devices or use HMPC_GROUP_P2P";
+    hmpc_group_destroy(g);
+    return HMPC_E_ARG;
+  }
+  g->transport = transport;
+#define GTRY(expr)                 \
+  do {                             \
+    int _rc = (expr);              \
+    if (_rc != HMPC_OK) {          \
+      hmpc_group_destroy(g);       \
+      return _rc;                  \
+    }                              \
+  } while (0)
+#define GHIPD(expr)                                                      \
+  do {                                                                   \
+    hipError_t _e = (expr);                                              \
+    if (_e != hipSuccess) {                                              \
+      g_group_err = std::string(#expr) + ": " + hipGetErrorString(_e);   \
+      hmpc_group_destroy(g);                                             \
+      return HMPC_E_HIP;                                                 \
+    }                                                                    \
+  } while (0)
+  const size_t slice_words = (size_t)g->cap * PACK_WORDS;
+  for (Member &mb : g->m) {
+    GHIPD(hipSetDevice(mb.device));
+    GTRY(hmpc_create(&mb.h, setup, g->cap, mb.device));
+    GHIPD(hipStreamCreateWithFlags(&mb.solve_stream, hipStreamNonBlocking));
+    GHIPD(hipStreamCreateWithFlags(&mb.comm_stream, hipStreamNonBlocking));
+    GHIPD(hipEventCreateWithFlags(&mb.packed, hipEventDisableTiming));
+    GHIPD(hipEventCreateWithFlags(&mb.gathered_ev, hipEventDisableTiming));
+    GHIPD(hipMalloc(&mb.d_pack, slice_words * sizeof(uint32_t)));
+    GHIPD(hipMalloc(&mb.d_gathered, slice_words * sizeof(uint32_t) * g->G));
+    GHIPD(hipMemset(mb.d_pack, 0, slice_words * sizeof(uint32_t)));
+    GHIPD(hipMemset(mb.d_gathered, 0, slice_words * sizeof(uint32_t) * g->G));
+  }
+  GHIPD(hipHostMalloc(&g->h_stage, slice_words * sizeof(uint32_t) * g->G, hipHostMallocDefault));
+  if (transport == HMPC_GROUP_P2P) {
+    for (int i = 0; i < g->G; ++i)
+      for (int j = 0; j < g->G; ++j) {
+        if (g->m[i].device == g->m[j].device) continue;
+        int can = 0;
+        GHIPD(hipDeviceCanAccessPeer(&can, g->m[i].device, g->m[j].device));
+        if (can) {
+          GHIPD(hipSetDevice(g->m[i].device));
+          hipError_t e = hipDeviceEnablePeerAccess(g->m[j].device, 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) GHIPD(e);
+          (void)hipGetLastError();
+        }
+      }
+  } else {
+    if (!g_rccl.load()) {
+      g_group_err = g_rccl.err;
+      hmpc_group_destroy(g);
+      return HMPC_E_HIP;
+    }
+    g->comms.assign(g->G, nullptr);
+    std::vector<int> devs(g->G);
+    for (int i = 0; i < g->G; ++i) devs[i] = g->m[i].device;
+    ncclResult_t r = g_rccl.CommInitAll(g->comms.data(), g->G, devs.data());
+    if (r != 0) {
+      g_group_err = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r);
+      g->comms.clear();
+      hmpc_group_destroy(g);
+      return HMPC_E_HIP;
+    }
+  }
+#undef GTRY
+#undef GHIPD
+  *out = g;
+  return HMPC_OK;
+}
+
+int hmpc_group_size(const hmpc_group *g) { return g ? g->G : HMPC_E_ARG; }
+int hmpc_group_transport(const hmpc_group *g) { return g ? g->transport : HMPC_E_ARG; }
+int hmpc_group_batch(const hmpc_group *g) { return g ? g->batch : HMPC_E_ARG; }
+
+int hmpc_group_member(hmpc_group *g, int member, hmpc_handle **handle, int *device, int *lo, int *n, void **solve_stream) {
+  if (!g || member < 0 || member >= g->G) return HMPC_E_ARG;
+  const Member &mb = g->m[member];
+  if (handle) *handle = mb.h;
+  if (device) *device = mb.device;
+  if (lo) *lo = mb.lo;
+  if (n) *n = mb.n;
+  if (solve_stream) *solve_stream = (void *)mb.solve_stream;
+  return HMPC_OK;
+}
+
+// contiguous slices of a host batch -> the members' record buffers (asynchronous on each member's solve stream)
+int hmpc_group_upload_records(hmpc_group *g, const void *host_records, int batch) {
+  if (!g || (!host_records && batch > 0) || batch < 0) return HMPC_E_ARG;
+  if (batch > g->max_batch) return HMPC_E_BATCH;
+  const size_t stride = hmpc_record_stride(g->setup.horizon);
+  static const unsigned char empty = 0;
+  if (!host_records) host_records = &empty;  // batch == 0
+  for (int i = 0; i < g->G; ++i) {
+    Member &mb = g->m[i];
+    int lo, hi;
+    hmpc_shard_bounds(batch, g->G, i, &lo, &hi);
+    mb.lo = lo, mb.n = hi - lo;
+    const int rc = hmpc_upload_records_async(mb.h, (const unsigned char *)host_records + (size_t)lo * stride, mb.n,
+                                             mb.solve_stream);
+    if (rc != HMPC_OK) return rc;
+  }
+  g->batch = batch;
+  return HMPC_OK;
+}
+
+// records already resident on each member's device: slice sizes are taken from the shard arithmetic, the caller supplies
+// one device pointer per member (device_records[i] points at that member's first record, on that member's device)
+int hmpc_group_set_device_records(hmpc_group *g, const void *const *device_records, int batch, int max_reduced_vars) {
+  if (!g || !device_records || batch < 0) return HMPC_E_ARG;
+  if (batch > g->max_batch) return HMPC_E_BATCH;
+  for (int i = 0; i < g->G; ++i) {
+    Member &mb = g->m[i];
+    int lo, hi;
+    hmpc_shard_bounds(batch, g->G, i, &lo, &hi);
+    mb.lo = lo, mb.n = hi - lo;
+    if (mb.n > 0 && !device_records[i]) return HMPC_E_ARG;
+    int rc = hmpc_set_device_records(mb.h, mb.n > 0 ? device_records[i] : (const void *)mb.d_pack, mb.n);
+    if (rc == HMPC_OK) rc = hmpc_set_max_reduced_vars(mb.h, max_reduced_vars);
+    if (rc != HMPC_OK) return rc;
+  }
+  g->batch = batch;
+  return HMPC_OK;
+}
+
+// enqueue the solve of every member's slice on its own stream; returns without waiting
+int hmpc_group_solve(hmpc_group *g) {
+  if (!g) return HMPC_E_ARG;
+  for (Member &mb : g->m) {
+    GHIP(hipSetDevice(mb.device));
+    const int rc = hmpc_solve(mb.h, mb.solve_stream);
+    if (rc != HMPC_OK) return rc;
+  }
+  return HMPC_OK;
+}
+
+// post the exchange step for the solves enqueued so far: pack on the solve stream (so the NEXT solve may overwrite the
+// force buffer at once), all-gather on the comm stream (so it runs under that next solve).  Does not block.
+int hmpc_group_post_gather(hmpc_group *g) {
+  if (!g) return HMPC_E_ARG;
+  const int width = 12 * g->setup.horizon;
+  for (Member &mb : g->m) {
+    GHIP(hipSetDevice(mb.device));
+    // the previous gather still reads this member's d_pack (RCCL: on its own comm stream; P2P: on every destination's):
+    // the pack below must not overtake it.  By now that gather has had a whole solve to run under.
+    if (g->transport == HMPC_GROUP_P2P)
+      for (Member &dst : g->m) GHIP(hipStreamWaitEvent(mb.solve_stream, dst.gathered_ev, 0));
+    else
+      GHIP(hipStreamWaitEvent(mb.solve_stream, mb.gathered_ev, 0));
+    if (mb.n > 0) {
+      float *d_forces = nullptr;
+      uint32_t *d_status = nullptr;
+      const int rc = hmpc_get_device_outputs(mb.h, &d_forces, &d_status);
+      if (rc != HMPC_OK) return rc;
+      const int total = mb.n * PACK_WORDS;
+      hipLaunchKernelGGL(pack_step0_kernel, dim3((total + 255) / 256), dim3(256), 0, mb.solve_stream, d_forces, d_status,
+                         mb.n, width, mb.d_pack);
+      GHIP(hipGetLastError());
+    }
+    GHIP(hipEventRecord(mb.packed, mb.solve_stream));
+    GHIP(hipStreamWaitEvent(mb.comm_stream, mb.packed, 0));
+  }
+  const size_t slice_words = (size_t)g->cap * PACK_WORDS;
+  if (g->transport == HMPC_GROUP_RCCL) {
+    GNCCL(g_rccl.GroupStart());
+    for (int i = 0; i < g->G; ++i) {
+      Member &mb = g->m[i];
+      ncclResult_t r = g_rccl.AllGather(mb.d_pack, mb.d_gathered, slice_words, NCCL_INT32, g->comms[i], mb.comm_stream);
+      if (r != 0) {
+        g_rccl.GroupEnd();
+        g_group_err = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r);
+        return HMPC_E_HIP;
+      }
+    }
+    GNCCL(g_rccl.GroupEnd());
+  } else {
+    // every member pushes its packed slice into slot i of every member's gathered buffer; a destination's comm stream
+    // first waits for the source's pack event
+    for (int j = 0; j < g->G; ++j) {
+      Member &dst = g->m[j];
+      GHIP(hipSetDevice(dst.device));
+      for (int i = 0; i < g->G; ++i) {
+        Member &src = g->m[i];
+        if (i != j) GHIP(hipStreamWaitEvent(dst.comm_stream, src.packed, 0));
+        uint32_t *slot = dst.d_gathered + (size_t)i * slice_words;
+        if (src.device == dst.device)
+          GHIP(hipMemcpyAsync(slot, src.d_pack, slice_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, dst.comm_stream));
+        else
+          GHIP(hipMemcpyPeerAsync(slot, dst.device, src.d_pack, src.device, slice_words * sizeof(uint32_t), dst.comm_stream));
+      }
+    }
+  }
+  for (Member &mb : g->m) {
+    GHIP(hipSetDevice(mb.device));
+    GHIP(hipEventRecord(mb.gathered_ev, mb.comm_stream));
+  }
+  g->gather_posted = true;
+  return HMPC_OK;
+}
+
+// gathered device copy held by `member`: wrench/status interleaved as [G][cap][13] words; slot s holds member s's
+// slice (instances lo_s .. lo_s + n_s - 1 in rows 0 .. n_s - 1).  Valid after hmpc_group_wait_gather.
+int hmpc_group_device_gathered(hmpc_group *g, int member, const uint32_t **gathered, int *slot_rows) {
+  if (!g || member < 0 || member >= g->G || !gathered) return HMPC_E_ARG;
+  *gathered = g->m[member].d_gathered;
+  if (slot_rows) *slot_rows = g->cap;
+  return HMPC_OK;
+}
+
+int hmpc_group_wait_gather(hmpc_group *g) {
+  if (!g) return HMPC_E_ARG;
+  for (Member &mb : g->m) {
+    GHIP(hipSetDevice(mb.device));
+    GHIP(hipStreamSynchronize(mb.comm_stream));
+  }
+  return HMPC_OK;
+}
+
+// the exchange step, blocking form: post (if not posted yet), wait, and copy the gathered block of the first member to
+// the host in instance order: wrench [batch][12] float, status [batch] (either may be NULL)
+int hmpc_group_gather_wrench(hmpc_group *g, float *host_wrench, uint32_t *host_status) {
+  if (!g) return HMPC_E_ARG;
+  if (!g->gather_posted) {
+    const int rc = hmpc_group_post_gather(g);
+    if (rc != HMPC_OK) return rc;
+  }
+  g->gather_posted = false;
+  Member &m0 = g->m[0];
+  GHIP(hipSetDevice(m0.device));
+  const size_t slice_words = (size_t)g->cap * PACK_WORDS;
+  GHIP(hipMemcpyAsync(g->h_stage, m0.d_gathered, slice_words * sizeof(uint32_t) * g->G, hipMemcpyDeviceToHost, m0.comm_stream));
+  GHIP(hipStreamSynchronize(m0.comm_stream));
+  for (int s = 0; s < g->G; ++s) {
+    const Member &mb = g->m[s];
+    const uint32_t *rows = g->h_stage + (size_t)s * slice_words;
+    for (int i = 0; i < mb.n; ++i) {
+      if (host_wrench) memcpy(host_wrench + (size_t)(mb.lo + i) * 12, rows + (size_t)i * PACK_WORDS, 12 * sizeof(float));
+      if (host_status) host_status[mb.lo + i] = rows[(size_t)i * PACK_WORDS + 12];
+    }
+  }
+  return HMPC_OK;
+}
+
+// every member's full force block [n][12h] and status words to the host, in instance order (no collective: G D2H copies);
+// flagged instances get the members' safe pass exactly as hmpc_download gives it
+int hmpc_group_download(hmpc_group *g, float *forces, uint32_t *status) {
+  if (!g) return HMPC_E_ARG;
+  const size_t width = (size_t)12 * g->setup.horizon;
+  for (Member &mb : g->m) {
+    const int rc = hmpc_download(mb.h, forces ? forces + (size_t)mb.lo * width : nullptr, status ? status + mb.lo : nullptr);
+    if (rc != HMPC_OK) return rc;
+  }
+  return HMPC_OK;
+}
+
+int hmpc_group_synchronize(hmpc_group *g) {
+  if (!g) return HMPC_E_ARG;
+  for (Member &mb : g->m) {
+    GHIP(hipSetDevice(mb.device));
+    GHIP(hipStreamSynchronize(mb.solve_stream));
+    GHIP(hipStreamSynchronize(mb.comm_stream));
+  }
+  return HMPC_OK;
+}
+
+}  // extern "C"

@@ -56,6 +56,9 @@ struct KernelArgs {
   // Last-resort pass for instances stuck at a degenerate vertex (hmpc_resolve_failed): every bound is moved outward by
   // relax * (1 + frac(0.618 row)) -- a different amount per row, which separates the coinciding vertices.  0 = exact.
   double relax;
+  // optional device counter: +1 for every instance this launch leaves flagged for the safe pass (working set full,
+  // max-iter, infeasible, KKT); lets hmpc_download skip the status scan when nothing was flagged
+  unsigned int *flagged;
 };
 constexpr int NPROF = 32;
 enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A, P_A0, P_A1, P_A2, P_G };
@@ -491,6 +494,8 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
   if (ng > NG) {  // uniform
     if (!ASM_ONLY) {
       for (int t = tid; t < U * h; t += NT) args.forces[(size_t)inst * U * h + t] = 0.0f;
+      if (args.wset)  // nothing to carry to the next tick from an instance that was not solved
+        for (int t = tid; t < C8 * h; t += NT) args.wset[(size_t)inst * C8 * h + t] = 0;
       if (tid == 0) args.status[inst] = S_TOO_LARGE;
     } else if (tid == 0) {
       args.dbg_i[0] = n;
@@ -1522,6 +1527,8 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArg
   }
   if (tid == 0) {
     args.status[inst] = (uint32_t)code | ((uint32_t)(iters & 0xfff) << 8) | ((uint32_t)(q & 0xfff) << 20);
+    if (args.flagged && (code == S_WORKSET || code == S_MAXITER || code == S_INFEASIBLE || code == S_KKT))
+      atomicAdd(args.flagged, 1u);
     if (args.obj64) {
       // objective through the KKT identity  0.5 x'Hx + g'x = 0.5 g'x + 0.5 u'b_W  (H itself was consumed by the sweeps)
       double o = 0.0;

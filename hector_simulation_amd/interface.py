@@ -218,6 +218,106 @@ class BatchedMPC:
                     Bcd=Bcd.reshape(13, 6 * nc))
 
 
+class DeviceGroup:
+    """``hmpc_group_*`` (include/hector_mpc.h, csrc/hmpc_group.hip): one process, several GPUs, contiguous slices, the
+    step-0 wrench + status gathered on every member and on the host.  ``devices`` may repeat an index with
+    ``transport="p2p"`` (one-GPU exercise of the multi-member path)."""
+
+    TRANSPORT = {"auto": 0, "rccl": 1, "p2p": 2}
+
+    def __init__(self, dt: float, horizon: int, f_max: float, max_batch: int, devices, transport: str = "auto",
+                 mu: float = 0.25):
+        self.L = _lib.load()
+        self.horizon, self.max_batch = int(horizon), int(max_batch)
+        self.setup = _lib.ProblemSetup(np.float32(dt), np.float32(mu), np.float32(f_max), int(horizon))
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        self.g = C.c_void_p()
+        rc = self.L.hmpc_group_create(C.byref(self.g), C.byref(self.setup), devs.ctypes.data, len(devs), self.max_batch,
+                                      self.TRANSPORT[transport])
+        if rc != 0:
+            raise HmpcError(f"hmpc_group_create failed with {rc}: {self.L.hmpc_group_last_error().decode()}")
+        self.size = int(self.L.hmpc_group_size(self.g))
+        self.stride = int(self.L.hmpc_record_stride(self.horizon))
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise HmpcError(f"{what} failed with {rc}: {self.L.hmpc_group_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.L.hmpc_group_destroy(self.g)
+            self.g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def transport(self) -> str:
+        return {1: "rccl", 2: "p2p"}[int(self.L.hmpc_group_transport(self.g))]
+
+    @property
+    def batch(self) -> int:
+        return int(self.L.hmpc_group_batch(self.g))
+
+    def member(self, i: int):
+        """(handle pointer, device, lo, n, solve stream) of member i."""
+        h, st = C.c_void_p(), C.c_void_p()
+        dev, lo, n = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(self.L.hmpc_group_member(self.g, int(i), C.byref(h), C.byref(dev), C.byref(lo), C.byref(n), C.byref(st)),
+                    "hmpc_group_member")
+        return h, dev.value, lo.value, n.value, st.value
+
+    def upload(self, recs: np.ndarray) -> None:
+        recs = np.ascontiguousarray(recs, dtype=np.uint8)
+        assert recs.ndim == 2 and recs.shape[1] == self.stride
+        self._check(self.L.hmpc_group_upload_records(self.g, recs.ctypes.data, recs.shape[0]), "hmpc_group_upload_records")
+
+    def solve(self) -> None:
+        self._check(self.L.hmpc_group_solve(self.g), "hmpc_group_solve")
+
+    def post_gather(self) -> None:
+        self._check(self.L.hmpc_group_post_gather(self.g), "hmpc_group_post_gather")
+
+    def wait_gather(self) -> None:
+        self._check(self.L.hmpc_group_wait_gather(self.g), "hmpc_group_wait_gather")
+
+    def gather_wrench(self):
+        b = self.batch
+        wrench = np.zeros((b, 12), dtype=np.float32)
+        status = np.zeros(b, dtype=np.uint32)
+        self._check(self.L.hmpc_group_gather_wrench(self.g, wrench.ctypes.data, status.ctypes.data), "hmpc_group_gather_wrench")
+        return wrench, status
+
+    def device_gathered(self, member: int):
+        """(device pointer of member's gathered block, rows per slot)."""
+        p, rows = C.c_void_p(), C.c_int(0)
+        self._check(self.L.hmpc_group_device_gathered(self.g, int(member), C.byref(p), C.byref(rows)),
+                    "hmpc_group_device_gathered")
+        return p.value, rows.value
+
+    def download(self):
+        b = self.batch
+        forces = np.zeros((b, 12 * self.horizon), dtype=np.float32)
+        status = np.zeros(b, dtype=np.uint32)
+        self._check(self.L.hmpc_group_download(self.g, forces.ctypes.data, status.ctypes.data), "hmpc_group_download")
+        return forces, status
+
+    def synchronize(self) -> None:
+        self._check(self.L.hmpc_group_synchronize(self.g), "hmpc_group_synchronize")
+
+
+def shard_bounds(global_batch: int, n_shards: int, index: int):
+    """``hmpc_shard_bounds`` of the C ABI (pure host arithmetic; works without a GPU)."""
+    lo, hi = C.c_int(0), C.c_int(0)
+    rc = _lib.load().hmpc_shard_bounds(int(global_batch), int(n_shards), int(index), C.byref(lo), C.byref(hi))
+    if rc != 0:
+        raise ValueError((global_batch, n_shards, index))
+    return lo.value, hi.value
+
+
 def status_code(status: np.ndarray) -> np.ndarray:
     return (np.asarray(status) & 0xFF).astype(np.int32)
 

@@ -69,7 +69,10 @@ void update_solver_settings(int max_iter, double rho, double sigma, double solve
 void hmpc_solve_mpc(struct update_data_t *update, struct problem_setup *setup);
 void solveDenseMPC(struct update_data_t *update, struct problem_setup *setup);
 double *hmpc_get_q_soln(void);
-/* extra: status word of the last legacy solve (see HMPC_STATUS_*), never part of the reference */
+/* extra: status word of the last legacy solve (see HMPC_STATUS_*), never part of the reference.
+ * The process-global solver behind the reference interface runs on the device named by the environment variable
+ * HMPC_DEVICE (default 0).  On a flagged solve it prints the reference's "failed to solve!" line and, like the
+ * reference (SolverMPC.cpp:714-732), still scatters the last iterate; HMPC_S_OK_RELAXED counts as solved. */
 uint32_t hmpc_last_status(void);
 
 /* ---- (2) batched interface ---- */
@@ -209,13 +212,57 @@ int hmpc_download_records(hmpc_handle *h, void *host_records);
  * block Fc, lb/ub[16h] (unreduced) and x0[13], Acd[169], Bcd[156].  Any output pointer may be NULL. */
 int hmpc_debug_assemble(hmpc_handle *h, int index, int *n, int *m, int *var_ind, float *H, float *g, float *Fc,
                         float *lb, float *ub, float *x0, float *Acd, float *Bcd);
-/* Parity hook: double-precision primal solution [batch][12h] and per-instance dual objective of the last solve
- * (debug copy-out; allocates on first use). */
+/* Parity hook: double-precision primal solution [batch][12h] and per-instance dual objective of the last solve.
+ * hmpc_enable_f64_output (before the solve) makes every later solve write them; without it hmpc_download_f64 enables
+ * the copy-out and runs the current batch once more (flagged instances get the safe pass of hmpc_download). */
+int hmpc_enable_f64_output(hmpc_handle *h);
 int hmpc_download_f64(hmpc_handle *h, double *x, double *obj);
 
 /* Developer hook (only in builds with -DHMPC_PROFILE, scripts/phase_profile.py): per-phase shader-clock cycles of
  * one more launch of the current batch, [batch][32] (phase ids: hmpc_kernel.h P_*). */
 int hmpc_debug_phase_cycles(hmpc_handle *h, long long *cycles);
+
+/* ---- device groups: one process, several GPUs of a node (csrc/hmpc_group.hip) ----
+ * Every MPC instance is an independent QP: a batch is cut into contiguous slices [lo, hi), one per member device
+ * (hmpc_shard_bounds: the first batch % n members carry one extra instance), each solved by its own handle on its own
+ * stream with no data-path collective.  The single exchange step is the gather of what the controller reads,
+ * get_solution(0..11) of every instance (ConvexMPCLocomotion.cpp:419-440): the step-0 wrench [F_L F_R M_L M_R] and the
+ * status word.  hmpc_group_post_gather packs them on each solve stream and all-gathers the packed slices on each
+ * member's communication stream (RCCL: ncclCommInitAll + grouped ncclAllGather, librccl loaded on first use; or
+ * hipMemcpyPeerAsync copies), so the exchange of solve k runs under solve k+1; afterwards EVERY member holds the
+ * gathered block in HBM (hmpc_group_device_gathered) and hmpc_group_gather_wrench also hands it to the host. */
+typedef struct hmpc_group hmpc_group;
+enum hmpc_group_transport {
+  HMPC_GROUP_AUTO = 0, /* RCCL when all listed devices are distinct, else P2P */
+  HMPC_GROUP_RCCL = 1,
+  HMPC_GROUP_P2P = 2   /* the only transport that accepts a device listed twice (one-GPU test of the multi-member path) */
+};
+int hmpc_shard_bounds(int global_batch, int n_shards, int index, int *lo, int *hi);
+/* devices == NULL: devices 0 .. n_devices-1.  max_batch is the GLOBAL batch the group can hold. */
+int hmpc_group_create(hmpc_group **out, const struct problem_setup *setup, const int *devices, int n_devices,
+                      int max_batch, int transport);
+int hmpc_group_destroy(hmpc_group *g);
+int hmpc_group_size(const hmpc_group *g);
+int hmpc_group_transport(const hmpc_group *g);
+int hmpc_group_batch(const hmpc_group *g);
+/* member's handle (for the per-handle switches), device, slice of the current batch and solve stream; any may be NULL */
+int hmpc_group_member(hmpc_group *g, int member, hmpc_handle **handle, int *device, int *lo, int *n, void **solve_stream);
+int hmpc_group_upload_records(hmpc_group *g, const void *host_records, int batch);
+/* device_records[i] = member i's first record, resident on member i's device (slice sizes from hmpc_shard_bounds) */
+int hmpc_group_set_device_records(hmpc_group *g, const void *const *device_records, int batch, int max_reduced_vars);
+int hmpc_group_solve(hmpc_group *g);       /* asynchronous on every member */
+int hmpc_group_post_gather(hmpc_group *g); /* asynchronous: the exchange step for the solves enqueued so far */
+int hmpc_group_wait_gather(hmpc_group *g);
+/* member's gathered copy in HBM: [group size][slot_rows][13] 32-bit words, slot s = member s's slice, row = 12 floats of
+ * the step-0 wrench + the status word.  Valid from hmpc_group_wait_gather until the next hmpc_group_post_gather. */
+int hmpc_group_device_gathered(hmpc_group *g, int member, const uint32_t **gathered, int *slot_rows);
+/* blocking form of the exchange step: posts it if hmpc_group_post_gather was not called since the last solve, waits,
+ * and returns host copies in instance order: wrench [batch][12], status [batch] (either may be NULL) */
+int hmpc_group_gather_wrench(hmpc_group *g, float *host_wrench, uint32_t *host_status);
+/* all 12h forces of every instance to the host (no collective; the members' safe pass included) */
+int hmpc_group_download(hmpc_group *g, float *forces, uint32_t *status);
+int hmpc_group_synchronize(hmpc_group *g);
+const char *hmpc_group_last_error(void);
 
 const char *hmpc_last_hip_error(void);
 const char *hmpc_version(void);

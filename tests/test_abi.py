@@ -89,3 +89,21 @@ def test_product_does_not_touch_the_oracle():
                 assert not re.search(r"#\s*include\s*[<\"][^>\"]*oracle", txt), (dp, fn)
                 assert "libhmpc_oracle" not in txt and "libqpoases_ref" not in txt and "orc_" not in txt, (dp, fn)
     assert "hmpc_oracle" not in os.popen(f"ldd {_lib.lib_path()}").read()
+
+
+def test_shard_bounds_in_c_matches_the_python_sharding():
+    """hmpc_shard_bounds (C ABI, pure host arithmetic) == hector_simulation_amd.sharding.shard_bounds: contiguous cover,
+    the first batch % n shards one longer."""
+    from hector_simulation_amd import interface, sharding
+
+    for batch in (0, 1, 7, 64, 100, 1000, 8192, 65536):
+        for n in (1, 2, 3, 4, 8):
+            prev = 0
+            for i in range(n):
+                lo, hi = interface.shard_bounds(batch, n, i)
+                assert (lo, hi) == sharding.shard_bounds(batch, n, i)
+                assert lo == prev
+                prev = hi
+            assert prev == batch
+    with pytest.raises(ValueError):
+        interface.shard_bounds(10, 2, 2)

@@ -27,7 +27,8 @@ def _has_gpu():
     return torch.cuda.is_available()
 
 
-@pytest.mark.parametrize("src,cc,std", [("legacy_tick.cpp", "g++", "-std=c++17"), ("batched.c", "gcc", "-std=c11")])
+@pytest.mark.parametrize("src,cc,std", [("legacy_tick.cpp", "g++", "-std=c++17"), ("batched.c", "gcc", "-std=c11"),
+                                        ("batched_multi.c", "gcc", "-std=c11")])
 def test_examples_compile_and_fail_loudly_without_gpu(tmp_path, src, cc, std):
     exe = _compile(tmp_path, src, cc, std)
     if _has_gpu():
@@ -46,3 +47,14 @@ def test_examples_run_on_gpu(tmp_path, src, cc, std):
     if src == "legacy_tick.cpp":
         u0 = [float(x) for x in r.stdout.split("u0 =")[1].split()]
         assert abs(u0[2] - 47.84) < 0.05 and abs(u0[5] - 47.84) < 0.05  # the nominal standing tick (tests/test_gpu_solve.py)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [["1"], ["3", "p2p"]])
+def test_multi_device_example_runs_on_gpu(tmp_path, args):
+    """examples/batched_multi.c: a group of one over RCCL (what a one-GPU box can run of the real transport) and a group of
+    three members on device 0 over the P2P transport (ragged 334/333/333 slices)."""
+    exe = _compile(tmp_path, "batched_multi.c", "gcc", "-std=c11")
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 of 1000 not ok, 0 gathered rows differ" in r.stdout

@@ -1,0 +1,95 @@
+"""Device groups behind the C ABI (include/hector_mpc.h ``hmpc_group_*``, csrc/hmpc_group.hip):
+contiguous slices per member, no data-path collective, one exchange step = the gather of step-0 wrench + status on every
+member and on the host.  A one-GPU box exercises (a) the RCCL transport with a group of one (ncclCommInitAll +
+ncclAllGather on hardware) and (b) the multi-member slicing / packing / stream ordering / layout with device 0 listed
+several times over the P2P transport.  No run with more than one physical GPU exists."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hector_simulation_amd import interface, records, synthetic
+
+pytestmark = pytest.mark.gpu
+H = 10
+
+
+def _single(rec):
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, rec.shape[0])
+    mpc.upload(rec)
+    mpc.solve()
+    f, s = mpc.download()
+    mpc.close()
+    return f, s
+
+
+def _device_words(ptr, nwords):
+    import torch  # plumbing only: a device -> host copy of the gathered block
+
+    out = np.zeros(nwords, dtype=np.uint32)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(out.ctypes.data, C.c_void_p(ptr), nwords * 4, 2) == 0
+    return out
+
+
+@pytest.mark.parametrize("devices,transport,nb", [([0], "rccl", 96), ([0], "auto", 1), ([0, 0, 0], "p2p", 100),
+                                                 ([0, 0], "p2p", 64), ([0, 0, 0, 0], "auto", 3)])
+def test_group_gather_equals_single_handle(devices, transport, nb):
+    f = synthetic.make_batch(nb, H, "walking", seed=31, phase="random")
+    rec = records.pack_records(f, H)
+    ref_f, ref_s = _single(rec)
+    grp = interface.DeviceGroup(synthetic.DT_MPC, H, synthetic.F_MAX, nb, devices, transport)
+    assert grp.transport == ("rccl" if len(set(devices)) == len(devices) else "p2p")
+    grp.upload(rec)
+    covered = []
+    for i in range(grp.size):
+        _, dev, lo, n, _ = grp.member(i)
+        assert (lo, lo + n) == interface.shard_bounds(nb, grp.size, i)
+        covered += list(range(lo, lo + n))
+    assert covered == list(range(nb))
+    grp.solve()
+    wrench, status = grp.gather_wrench()
+    np.testing.assert_array_equal(status, ref_s)
+    np.testing.assert_array_equal(wrench.view(np.uint32), ref_f[:, :12].view(np.uint32))
+    # every member holds the same gathered block in HBM
+    blocks = []
+    for i in range(grp.size):
+        ptr, rows = grp.device_gathered(i)
+        blk = _device_words(ptr, grp.size * rows * 13).reshape(grp.size, rows, 13)
+        blocks.append(blk)
+        for s in range(grp.size):
+            _, _, lo, n, _ = grp.member(s)
+            np.testing.assert_array_equal(blk[s, :n, :12], ref_f[lo:lo + n, :12].view(np.uint32))
+            np.testing.assert_array_equal(blk[s, :n, 12], ref_s[lo:lo + n])
+    for b in blocks[1:]:
+        np.testing.assert_array_equal(b, blocks[0])
+    full_f, full_s = grp.download()
+    np.testing.assert_array_equal(full_f.view(np.uint32), ref_f.view(np.uint32))
+    np.testing.assert_array_equal(full_s, ref_s)
+    grp.close()
+
+
+def test_group_pipelined_exchange_under_the_next_solve():
+    """solve k+1 is enqueued before the gather of solve k is waited for; each gather must still carry solve k's data."""
+    nb = 90
+    batches = [records.pack_records(synthetic.make_batch(nb, H, g, seed=40 + i, phase="random"), H)
+               for i, g in enumerate(("walking", "standing", "mixed", "walking"))]
+    refs = [_single(r) for r in batches]
+    grp = interface.DeviceGroup(synthetic.DT_MPC, H, synthetic.F_MAX, nb, [0, 0, 0], "p2p")
+    grp.upload(batches[0])
+    grp.solve()
+    for k in range(len(batches)):
+        grp.post_gather()              # exchange of solve k on the comm streams ...
+        if k + 1 < len(batches):
+            grp.upload(batches[k + 1])
+            grp.solve()                # ... under solve k+1 on the solve streams
+        wrench, status = grp.gather_wrench()
+        np.testing.assert_array_equal(status, refs[k][1])
+        np.testing.assert_array_equal(wrench.view(np.uint32), refs[k][0][:, :12].view(np.uint32))
+    grp.close()
+
+
+def test_group_rejects_repeated_devices_over_rccl():
+    with pytest.raises(interface.HmpcError):
+        interface.DeviceGroup(synthetic.DT_MPC, H, synthetic.F_MAX, 8, [0, 0], "rccl")
