@@ -30,55 +30,82 @@ BYTES_PER_SOLVE = {10: 1200, 20: 2180}   # (54+12h)*4 + 2h
 MFLOP_PER_SOLVE = {10: 3.744, 20: 29.952}  # 2*(12h)^2*(13h) dense B'SB contraction
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3
+FP64_VALU_PEAK_TF = 78.6                   # vector fp64 = half the fp32 vector rate of MI355X_MICROARCH.md (157.3 / 2)
 
 
-def cpu_worker(path: str, horizon: int, first: int, count: int) -> None:
-    """One CPU-baseline process: oracle assembly + the reference's qpOASES on records [first, first+count)."""
-    from hector_simulation_amd import synthetic
+def cpu_worker(path: str, horizon: int, first: int, count: int, kind: str = "reference") -> None:
+    """One CPU-baseline process over instances [first, first+count) of the saved field arrays.
+
+    kind "reference": the reference's OWN source end to end -- setup_problem / update_problem_data / get_solution of
+    oracle/_ref/libsolvempc_ref.so (ConvexMPC/SolverMPC.cpp + RobotState.cpp + convexMPC_interface.cpp compiled
+    unmodified against the Eigen stand-in, linked with the reference's vendored qpOASES; oracle/Makefile).  Its three
+    printed lines per solve go to /dev/null.
+    kind "port": the oracle's C restatement of the assembly + the same qpOASES (prints removed)."""
+    from hector_simulation_amd import records, synthetic
+
+    f = dict(np.load(path))
+    if kind == "reference":
+        from oracle import ref_py
+
+        ref_py.lib()
+        ref_py.silence_forever()
+        t0 = time.perf_counter()
+        q = ref_py.solve_fields(f, horizon, synthetic.DT_MPC, 0.25, synthetic.F_MAX, first=first, count=count)
+        t1 = time.perf_counter()
+        os.write(2, (json.dumps(dict(count=count, wall=t1 - t0, n_bad=int(np.isnan(q).any(axis=1).sum()))) + "\n").encode())
+        return
     from oracle import oracle_py
 
-    rec = np.load(path)
+    rec = records.pack_records(f, horizon)
     t0 = time.perf_counter()
     r = oracle_py.solve_records(rec, horizon, synthetic.DT_MPC, synthetic.F_MAX, first=first, count=count)
     t1 = time.perf_counter()
-    print(json.dumps(dict(count=count, wall=t1 - t0, t_assemble=r["t_assemble"], t_solve=r["t_solve"],
-                          n_bad=int(r["n_bad"]), nwsr_med=float(np.median(r["nwsr"])), nwsr_max=int(r["nwsr"].max()),
-                          nwsr_hist=np.bincount(np.minimum(r["nwsr"] // 10, 9), minlength=10).tolist())))
+    os.write(2, (json.dumps(dict(count=count, wall=t1 - t0, t_assemble=r["t_assemble"], t_solve=r["t_solve"],
+                                 n_bad=int(r["n_bad"]), nwsr_med=float(np.median(r["nwsr"])), nwsr_max=int(r["nwsr"].max()),
+                                 nwsr_hist=np.bincount(np.minimum(r["nwsr"] // 10, 9), minlength=10).tolist())) + "\n").encode())
 
 
-def cpu_baseline(rec: np.ndarray, horizon: int, per_core: int) -> dict:
+def _run_worker(path, horizon, first, count, kind):
+    return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(horizon), str(first),
+                             str(count), kind], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+
+
+def cpu_baseline(fields: dict, horizon: int, per_core: int) -> dict:
     """Reference CPU path timed on the host cores as PROCESSES (qpOASES has a process-global message handler)."""
+    from oracle import ref_py
+
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
-    per_core = max(1, min(per_core, rec.shape[0] // cores))
+    nb = int(np.asarray(fields["p"]).shape[0])
+    per_core = max(1, min(per_core, nb // cores))
     total = per_core * cores
+    kind = "reference" if ref_py.available() else "port"
+    last = lambda p: json.loads(p.communicate()[1].strip().splitlines()[-1])
     with tempfile.TemporaryDirectory() as td:
-        path = os.path.join(td, "records.npy")
-        np.save(path, rec[:total])
+        path = os.path.join(td, "fields.npz")
+        np.savez(path, **{k: np.asarray(v)[:total] for k, v in fields.items()})
         # P = 1: one process alone on the box (the reference's own operating point: one controller, one core)
         solo_n = min(96, total)
-        solo = json.loads(subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(horizon),
-                                          "0", str(solo_n)], stdout=subprocess.PIPE, text=True).stdout.strip().splitlines()[-1])
+        solo = last(_run_worker(path, horizon, 0, solo_n, kind))
+        solo_port = last(_run_worker(path, horizon, 0, solo_n, "port"))
         t0 = time.perf_counter()
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(horizon),
-                                   str(c * per_core), str(per_core)], stdout=subprocess.PIPE, text=True)
-                 for c in range(cores)]
-        outs = [p.communicate()[0] for p in procs]
+        procs = [_run_worker(path, horizon, c * per_core, per_core, kind) for c in range(cores)]
+        res = [last(p) for p in procs]
         wall = time.perf_counter() - t0
-    res = [json.loads(o.strip().splitlines()[-1]) for o in outs]
     inner = max(r["wall"] for r in res)  # slowest worker, excluding interpreter start-up
-    t_asm = sum(r["t_assemble"] for r in res)
-    t_sol = sum(r["t_solve"] for r in res)
-    return dict(value=total / inner, unit="QP solves/s", cores=cores, kind="port",
-                sample=f"{total} of the bench's 2-contact h={horizon} instances ({per_core}/process x {cores} processes); "
-                       f"oracle C restatement of the fp32 assembly + the reference's own vendored qpOASES 3.2.0 "
-                       f"(oracle/_ref), setToMPC, cold start; prints removed",
-                single_process_alone_value=solo_n / (solo["t_assemble"] + solo["t_solve"]),
-                single_process_alone_ms={"assemble": 1e3 * solo["t_assemble"] / solo_n, "solve": 1e3 * solo["t_solve"] / solo_n},
-                per_process_value_under_full_load=per_core / max(r["t_assemble"] + r["t_solve"] for r in res),
-                assemble_ms=1e3 * t_asm / total, solve_ms=1e3 * t_sol / total,
-                nwsr_median=float(np.median([r["nwsr_med"] for r in res])), nwsr_max=max(r["nwsr_max"] for r in res),
-                nwsr_hist_by_10=np.sum([r["nwsr_hist"] for r in res], axis=0).tolist(),  # bins [0,10) .. [90,inf)
+    what = ("the reference's own SolverMPC.cpp/RobotState.cpp/convexMPC_interface.cpp compiled unmodified against the Eigen "
+            "stand-in oracle/mini_eigen (naive k-ascending products: its assembly is slower than real Eigen's would be) + "
+            "the reference's vendored qpOASES 3.2.0, driven through setup_problem/update_problem_data/get_solution; its "
+            "three printed lines per solve go to /dev/null") if kind == "reference" else \
+           "oracle C restatement of the fp32 assembly + the reference's own vendored qpOASES 3.2.0 (oracle/_ref), prints removed"
+    return dict(value=total / inner, unit="QP solves/s", cores=cores, kind=kind,
+                sample=f"{total} of the bench's 2-contact h={horizon} instances ({per_core}/process x {cores} processes); " + what,
+                single_process_alone_value=solo_n / solo["wall"], single_process_alone_ms=1e3 * solo["wall"] / solo_n,
+                per_process_value_under_full_load=per_core / inner,
+                port_single_process_alone_value=solo_n / (solo_port["t_assemble"] + solo_port["t_solve"]),
+                port_single_process_alone_ms={"assemble": 1e3 * solo_port["t_assemble"] / solo_n,
+                                              "solve": 1e3 * solo_port["t_solve"] / solo_n},
+                nwsr_median=solo_port["nwsr_med"], nwsr_max=solo_port["nwsr_max"], nwsr_hist_by_10=solo_port["nwsr_hist"],
                 n_failed=sum(r["n_bad"] for r in res), wall_s=wall)
 
 
@@ -136,7 +163,7 @@ def bench_builder(args, torch, local_rank) -> None:
 
 def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
-        cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
+        cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6] if len(sys.argv) > 6 else "reference")
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,7 +180,7 @@ def main() -> None:
     ap.add_argument("--cpu-per-core", type=int, default=384)
     ap.add_argument("--path", default="solve", choices=["solve", "builder"],
                     help="solve = the metric (default); builder = rows f1-f3 only (record builder + wrench kernels)")
-    ap.add_argument("--check", type=int, default=32, help="instances checked against the oracle after the timed region")
+    ap.add_argument("--check", type=int, default=256, help="instances checked against the oracle after the timed region")
     args = ap.parse_args()
 
     import torch
@@ -248,17 +275,31 @@ def main() -> None:
         mfl = MFLOP_PER_SOLVE.get(h, 2 * (12 * h) ** 2 * (13 * h) / 1e6)
         ach_gbs = B * bps / (kernel_ms * 1e-3) / 1e9
         ach_tf = B * mfl * 1e6 / (kernel_ms * 1e-3) / 1e12
-        traffic = None
-        counters = None
+        # HBM traffic and issue counters come from rocprofv3 --pmc passes, which cannot run inside this process; the
+        # committed summary is used ONLY when it was taken on exactly this build of the library (source hash) and this
+        # workload -- otherwise the keys are null rather than stale
+        traffic = counters = valu_issue_frac = None
+        traffic_note = "no committed PMC profile for this build"
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):  # PMC-measured HBM bytes per solve from the committed rocprofv3 passes
+        if os.path.exists(tpath):
             try:
+                from hector_simulation_amd import build as hip_build
+
                 tj = json.load(open(tpath))
-                if tj.get("horizon") == h and tj.get("gait") == args.gait:
+                if tj.get("source_hash") != hip_build.source_hash():
+                    traffic_note = "profiles/hbm_traffic.json was taken on another build of the kernel: ignored"
+                elif tj.get("horizon") == h and tj.get("gait") == args.gait:
                     traffic = tj["bytes_per_solve"] * B
                     counters = tj.get("counters")
+                    valu_issue_frac = (counters or {}).get("valu_issue_frac")
+                    traffic_note = f"rocprofv3 --pmc passes of {tj.get('profile_dir', 'profiles/')} on this build (source hash matches)"
             except Exception:
                 traffic = None
+        # useful binary64 work of one solve: the inverse by n symmetric sweeps over the upper
+        # triangle, n^2 (n+1) flop, plus per active-set iteration the products z = M w and r = E d, ~4 n^2 flop
+        it_mean = float(iters.mean())
+        fp64_flop = n_red * n_red * (n_red + 1) + it_mean * 4.0 * n_red * n_red
+        fp64_tf = B * fp64_flop / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "MPC QP solves/sec (horizon=10, 2 contacts)" if (h == 10 and args.gait == "standing")
                       else f"MPC QP solves/sec (horizon={h}, gait={args.gait})",
@@ -266,20 +307,26 @@ def main() -> None:
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 assembly / f64 solve", "data": "synthetic",
             "config": {"workload": f"{'2-contact standing' if args.gait == 'standing' else args.gait} randomized MPC ticks, "
-                                   f"horizon {h}, reduced QP up to {n_red}x{n_red // 6 * 8}",
+                                   f"horizon {h}, reduced QP up to {n_red}x{n_red // 6 * 8}; records and forces device-resident in/out",
                        "batch_per_gpu": B, "global_batch": world * B, "horizon": h,
                        "parallelism": (f"batch shards x{world}, all_gather of "
                                        f"{'step-0 wrench + status (overlapped with the next solve)' if xch is not None else 'all forces'}")
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "counters_from_committed_pmc_passes": counters,
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                         "pmc_counters": counters,
                          "kernel": "hmpc_kernel (fused assembly + QP solve)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_solve": bps,
                          "note": "neither HBM nor MFMA binds this path (SURVEY.md 8d): the limiter is the serial "
                                  "active-set iteration inside one workgroup (LDS/VALU fp64 latency)"},
             "roofline_mfma": {"bound": "mfma", "achieved": ach_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                               "frac": ach_tf / MFMA_F32_PEAK_TF, "algorithmic_mflop_per_solve": mfl},
+            "fp64_valu_frac": fp64_tf / FP64_VALU_PEAK_TF,
+            "fp64_valu": {"achieved": fp64_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                          "useful_flop_per_solve": fp64_flop,
+                          "formula": "n^2 (n+1) [inverse by symmetric sweeps] + iterations_mean * 4 n^2 [z = M w, r = E d]"},
+            "valu_issue_frac": valu_issue_frac,
+            "iterations_per_solve": it_mean,
             "solver": {"failed": n_fail, "iters_median": float(np.median(iters)), "iters_max": int(iters.max()), "active_median": float(np.median(nact)), "active_max": int(nact.max()),
                        "kernel_solves_per_s": B / (kernel_ms * 1e-3)},
         }
@@ -405,7 +452,7 @@ def main() -> None:
             out["parity"] = {"checked": nchk, "max_rel_force_err_vs_qpoases": float(err.max()),
                              "qpoases_failed": int(ref["n_bad"])}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rec, h, args.cpu_per_core)
+            out["cpu_baseline"] = cpu_baseline(fields, h, args.cpu_per_core)
         print(json.dumps(out), flush=True)
     mpc.close()
     if world > 1:

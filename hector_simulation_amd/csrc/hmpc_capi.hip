@@ -524,7 +524,9 @@ int hmpc_time_solve(hmpc_handle *h, void *stream, int reps, float *ms_per_launch
   h->last_stream = s;
   HIP_TRY(hipEventRecord(ev.e0, s));
   for (int i = 0; i < reps; ++i) {
-    int rc = launch(h, s, false, 0, nullptr, 0, 0.0, -1, /*carry_wset=*/false);
+    // a single timed launch is a genuine solve of the current batch (it consumes and leaves the tick-to-tick working sets);
+    // repetitions of the same batch must not advance them again
+    int rc = launch(h, s, false, 0, nullptr, 0, 0.0, -1, /*carry_wset=*/reps == 1);
     if (rc != HMPC_OK) return rc;
   }
   HIP_TRY(hipEventRecord(ev.e1, s));

@@ -1,0 +1,77 @@
+"""Full-batch oracle parity at BASELINE.json's sizes: EVERY instance of configs 2 and 4 and of the metric's b1024
+2-contact case, and 2 048 / 1 024 of configs 3 / 5, against the reference's own qpOASES on the oracle's (bit-identical)
+QP data.  The oracle runs as a pool of processes over the host cores (oracle/pool.py) where one core would take more
+than a few seconds.  Bar: forces within north_star's 1e-4 relative of qpOASES, every instance reported ok."""
+import numpy as np
+import pytest
+
+from hector_simulation_amd import interface, records, synthetic
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _gpu(rec, h, contacts=2):
+    nb = rec.shape[0]
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb, contacts=contacts)
+    mpc.upload(rec)
+    mpc.solve()
+    forces, status = mpc.download()
+    mpc.close()
+    return forces, status
+
+
+def _compare(name, forces, status, ref):
+    assert ref["n_bad"] == 0
+    code = interface.status_code(status)
+    assert (code == 0).all(), (name, np.bincount(code))
+    q = ref["q_soln"]
+    err = np.abs(forces.astype(np.float64) - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+    print(f"{name}: {len(err)} instances vs qpOASES: max rel force err {err.max():.2e}, median {np.median(err):.2e}; "
+          f"qpOASES nWSR median {np.median(ref['nwsr']):.0f}, GPU iterations median "
+          f"{np.median(interface.status_iters(status)):.0f}")
+    assert err.max() < TOL, (name, err.max(), int(err.argmax()))
+
+
+def test_cfg2_all_1024_walking_fixed_phase(oracle):
+    kw = synthetic.CONFIGS["cfg2_walk_1024"]
+    rec = records.pack_records(synthetic.make_batch(**kw), kw["horizon"])
+    forces, status = _gpu(rec, kw["horizon"])
+    _compare("cfg2", forces, status, oracle.solve_records(rec, kw["horizon"], synthetic.DT_MPC, synthetic.F_MAX))
+
+
+def test_metric_case_all_1024_two_contact(oracle):
+    from oracle import pool
+
+    kw = synthetic.CONFIGS["metric_2contact_1024"]
+    rec = records.pack_records(synthetic.make_batch(**kw), kw["horizon"])
+    forces, status = _gpu(rec, kw["horizon"])
+    _compare("metric b1024", forces, status, pool.solve_records_parallel(rec, kw["horizon"], synthetic.DT_MPC, synthetic.F_MAX))
+
+
+def test_cfg4_all_4096_horizon_20_single_support(oracle):
+    from oracle import pool
+
+    kw = synthetic.CONFIGS["cfg4_h20_single_4096"]
+    rec = records.pack_records(synthetic.make_batch(**kw), kw["horizon"])
+    forces, status = _gpu(rec, kw["horizon"])
+    _compare("cfg4", forces, status, pool.solve_records_parallel(rec, kw["horizon"], synthetic.DT_MPC, synthetic.F_MAX))
+
+
+def test_cfg3_2048_of_the_random_sweep(oracle):
+    from oracle import pool
+
+    kw = dict(synthetic.CONFIGS["cfg3_walk_sweep_65536"], batch=2048)
+    rec = records.pack_records(synthetic.make_batch(**kw), kw["horizon"])
+    forces, status = _gpu(rec, kw["horizon"])
+    _compare("cfg3[:2048]", forces, status, pool.solve_records_parallel(rec, kw["horizon"], synthetic.DT_MPC, synthetic.F_MAX))
+
+
+def test_cfg5_1024_three_contact_extension(oracle):
+    from oracle import pool
+
+    kw = dict(synthetic.CONFIG5, batch=1024)
+    rec = records.pack_records(synthetic.make_batch3(**kw), 10, 3)
+    forces, status = _gpu(rec, 10, contacts=3)
+    _compare("cfg5[:1024] (oracle extension)", forces, status,
+             pool.solve_records_parallel(rec, 10, synthetic.DT_MPC, synthetic.F_MAX, nc=3))
