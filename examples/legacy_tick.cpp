@@ -21,7 +21,9 @@ int main() {
   for (int i = 0; i < horizon; ++i) traj[12 * i + 5] = 0.55;  // hold the nominal height
   std::vector<int> gait(2 * horizon, 1);                      // both feet in stance over the horizon
 
+  if (get_solution(2) != 0.0) return 4;  // convexMPC_interface.cpp:107: 0 before the first solve of the process
   setup_problem(dtMPC, horizon, 0.25, f_max);
+  if (get_solution(2) != 0.0) return 4;
   update_problem_data(p, v, q, w, r, joint_angles, 0.0, Q, traj.data(), Alpha, gait.data());
   const unsigned st = hmpc_last_status();
   std::printf("status code %u, active-set iterations %u\n", HMPC_STATUS_CODE(st), HMPC_STATUS_ITERS(st));

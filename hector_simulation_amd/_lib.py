@@ -36,7 +36,7 @@ class TickInputs(C.Structure):
                 ("leg_q", C.c_double * 10), ("pFoot", C.c_double * 6), ("v_des_robot", C.c_double * 2),
                 ("yaw_rate_des", C.c_double), ("roll_des", C.c_double), ("pitch_des", C.c_double),
                 ("world_position_desired", C.c_double * 2), ("gait_offsets", C.c_int * 2),
-                ("gait_durations", C.c_int * 2), ("gait_iteration", C.c_int), ("pad", C.c_int)]
+                ("gait_durations", C.c_int * 2), ("gait_iteration", C.c_int), ("flags", C.c_int)]
 
 
 class UpdateData(C.Structure):

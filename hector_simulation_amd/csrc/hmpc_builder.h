@@ -54,6 +54,10 @@ __global__ __launch_bounds__(256) void build_records_kernel(const hmpc_tick_inpu
       } else if (t < 29) {
         const int i = t - 19, k = i % 5;
         double a = tk.leg_q[i];
+        if (tk.flags & HMPC_TICK_LEG_Q_MOTOR) {  // LegController.cpp:111-113 mutates data[leg].q before the MPC reads it
+          if (k == 2 || k == 4) a = a + 0.3 * 3.14159;
+          if (k == 3) a = a - 0.6 * 3.14159;
+        }
         if (k == 2 || k == 4) a += 0.3 * PI;
         if (k == 3) a -= 0.6 * PI;
         v = (__builtin_fabs(a) < PI2) ? a : fmod(a, PI2);  // fmod(x,y) == x exactly when |x| < y

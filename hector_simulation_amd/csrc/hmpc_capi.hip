@@ -31,6 +31,9 @@ thread_local std::string g_hip_err;
     }                                                                                                    \
   } while (0)
 
+#ifndef HMPC_QCAP_FAST
+#define HMPC_QCAP_FAST 80  // working-set capacity of the fast 120-variable variants
+#endif
 typedef void (*kernel_fn)(hmpc::KernelArgs);
 
 struct Variant {
@@ -55,8 +58,8 @@ Variant make_variant() {
 }
 
 const Variant *variants() {
-  static const Variant v[] = {make_variant<60, 10, 128, 60>(),   make_variant<120, 10, 256, 80>(),
-                              make_variant<60, 20, 128, 60>(),   make_variant<120, 20, 256, 80>(),
+  static const Variant v[] = {make_variant<60, 10, 128, 60>(),   make_variant<120, 10, 256, HMPC_QCAP_FAST>(),
+                              make_variant<60, 20, 128, 60>(),   make_variant<120, 20, 256, HMPC_QCAP_FAST>(),
                               make_variant<120, 10, 256, 120>(), make_variant<120, 20, 256, 120>(),
                               make_variant<180, 10, 512, 100, 3>(), make_variant<180, 10, 512, 140, 3>()};
   return v;

@@ -218,11 +218,14 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #if HMPC_MFMA_SWEEP
 #include "hmpc_sweep_mfma.h"
 #endif
+#ifndef HMPC_WG_PER_CU_256
+#define HMPC_WG_PER_CU_256 2  // resident 256-thread workgroups per CU the fast 120-variable variant is compiled for
+#endif
 namespace hmpc {
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC = 2>
-__global__ __launch_bounds__(NT, (NT >= 512) ? 1 : 2) void hmpc_kernel(KernelArgs args) {
+__global__ __launch_bounds__(NT, (NT >= 512) ? 1 : ((NT == 256 && QCAP <= 64) ? HMPC_WG_PER_CU_256 : 2)) void hmpc_kernel(KernelArgs args) {
   using SM = Smem<NMAX, HMAX, NT, QCAP, NC>;
   using RL = RecLayout<NC>;
   constexpr int NG = SM::NG, NW = SM::NW, U = SM::U, PS = SM::PS, C8 = 8 * NC;

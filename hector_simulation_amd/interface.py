@@ -16,7 +16,7 @@ TICK_DTYPE = np.dtype([("position", "f8", 3), ("vWorld", "f8", 3), ("omegaWorld"
                        ("rpy", "f8", 3), ("rBody", "f8", 9), ("leg_q", "f8", 10), ("pFoot", "f8", 6),
                        ("v_des_robot", "f8", 2), ("yaw_rate_des", "f8"), ("roll_des", "f8"), ("pitch_des", "f8"),
                        ("world_position_desired", "f8", 2), ("gait_offsets", "i4", 2), ("gait_durations", "i4", 2),
-                       ("gait_iteration", "i4"), ("pad", "i4")], align=True)
+                       ("gait_iteration", "i4"), ("flags", "i4")], align=True)
 
 STATUS_NAMES = {0: "ok", 1: "max_iter", 2: "infeasible", 3: "too_large", 4: "kkt", 5: "working_set_full", 6: "ok_relaxed"}
 

@@ -181,14 +181,25 @@ int hmpc_time_solve(hmpc_handle *h, void *stream, int reps, float *ms_per_launch
 struct hmpc_tick_inputs {
   double position[3], vWorld[3], omegaWorld[3], orientation[4], rpy[3];
   double rBody[9];        /* row-major, world -> body (orientation_tools.h:182-200) */
-  double leg_q[10];       /* raw joint angles, left 0-4, right 5-9 */
+  /* Joint angles, left 0-4, right 5-9, AS updateMPCIfNeeded READS THEM: data[leg].q of the LegController
+   * (ConvexMPCLocomotion.cpp:288-296).  On the reference's live path that is NOT the motor angle: updateData() hands
+   * data[leg].q BY REFERENCE to computeLegJacobianAndPosition, which adds (+0.3, -0.6, +0.3) * 3.14159 to joints 2-4 in place
+   * (common/LegController.cpp:48-52, 108-113) before the MPC runs; the MPC then adds its own offsets (:302-308) and the
+   * solver a third time (SolverMPC.cpp:382-388) -- SURVEY A.9 "triple offset", reproduced, not fixed.  So pass either
+   *   - data[leg].q after the LegController update (flags = 0), or
+   *   - the raw motor angles state->motorState[].q with HMPC_TICK_LEG_Q_MOTOR set in `flags`: the builder then applies the
+   *     LegController's first offset itself (same constant 3.14159, same operation order).
+   * hmpc_leg_torques takes the Jacobian's argument, i.e. the MOTOR angle before that offset (LegController.cpp:108-113). */
+  double leg_q[10];
   double pFoot[6];        /* world foot positions, [leg][axis] */
   double v_des_robot[2];  /* stateDes[6], stateDes[7] */
   double yaw_rate_des;    /* stateDes[11] */
   double roll_des, pitch_des; /* stateDes[3], stateDes[4] */
   double world_position_desired[2];
-  int gait_offsets[2], gait_durations[2], gait_iteration, pad;
+  int gait_offsets[2], gait_durations[2], gait_iteration;
+  int flags;              /* HMPC_TICK_* bits (was padding: 0 keeps the previous meaning) */
 };
+#define HMPC_TICK_LEG_Q_MOTOR 1 /* leg_q holds raw motor angles: apply LegController.cpp:111-113's offset first */
 /* f1+f2: builds the packed records of `batch` ticks on the device into the handle's own record buffer (which becomes
  * the current batch) and returns the clamped world_position_desired (ConvexMPCLocomotion.cpp:336-346) per instance.
  * host_ticks / wpd_out are host pointers (wpd_out may be NULL); the _device form takes device pointers and a stream. */
@@ -199,7 +210,9 @@ int hmpc_build_records_device(hmpc_handle *h, const void *device_ticks, int batc
 int hmpc_body_wrench(hmpc_handle *h, const double *host_rBody, double *host_f_ff);
 int hmpc_body_wrench_device(hmpc_handle *h, const double *device_rBody, double *device_f_ff, void *stream);
 /* f3, with the joint torques: f_ff as above, then tau[batch][2][5] = J_fm' f_ff with the force-moment Jacobian of
- * common/LegController.cpp:108-167 evaluated at leg_q[batch][10] (LegController.cpp:57-61).  f_ff may be NULL. */
+ * common/LegController.cpp:108-167 evaluated at leg_q[batch][10] (LegController.cpp:57-61).  f_ff may be NULL.
+ * leg_q here is what computeLegJacobianAndPosition RECEIVES: the raw motor angles (it adds its 3.14159-based offset
+ * itself) -- not the hmpc_tick_inputs.leg_q of a flags = 0 tick, which already carries that offset. */
 int hmpc_leg_torques(hmpc_handle *h, const double *host_rBody, const double *host_leg_q, double *host_f_ff, double *host_tau);
 int hmpc_leg_torques_device(hmpc_handle *h, const double *device_rBody, const double *device_leg_q, double *device_f_ff,
                             double *device_tau, void *stream);

@@ -684,6 +684,13 @@ void orc_mpc_gait(int n, const int offsets[2], const int durations[2], int itera
 void orc_build_record(const orc_tick_t *t, int h, double dtMPC, unsigned char *record, double wpd_out[2]) {
   double q[10];
   for (int i = 0; i < 10; ++i) q[i] = t->leg_q[i];
+  if (t->flags & 1) { /* raw motor angles: common/LegController.cpp:111-113 mutates data[leg].q before the MPC reads it */
+    for (int l = 0; l < 2; ++l) {
+      q[5 * l + 2] = q[5 * l + 2] + 0.3 * 3.14159;
+      q[5 * l + 3] = q[5 * l + 3] - 0.6 * 3.14159;
+      q[5 * l + 4] = q[5 * l + 4] + 0.3 * 3.14159;
+    }
+  }
   const double PI = 3.14159265359;
   q[2] += 0.3 * PI, q[3] -= 0.6 * PI, q[4] += 0.3 * PI;
   q[7] += 0.3 * PI, q[8] -= 0.6 * PI, q[9] += 0.3 * PI;

@@ -125,13 +125,13 @@ int orc_solve_records(const unsigned char *records, int stride, int first, int c
 typedef struct {
   double position[3], vWorld[3], omegaWorld[3], orientation[4], rpy[3];
   double rBody[9];        /* row-major, world -> body */
-  double leg_q[10];       /* raw joint angles, left 0-4, right 5-9 */
+  double leg_q[10];       /* data[leg].q as updateMPCIfNeeded reads it (flags = 0) or raw motor angles (flags & 1) */
   double pFoot[6];        /* world foot positions, [leg][axis] */
   double v_des_robot[2];  /* stateDes[6], stateDes[7] */
   double yaw_rate_des;    /* stateDes[11] */
   double roll_des, pitch_des; /* stateDes[3], stateDes[4] */
   double world_position_desired[2];
-  int gait_offsets[2], gait_durations[2], gait_iteration, pad;
+  int gait_offsets[2], gait_durations[2], gait_iteration, flags;
 } orc_tick_t;
 
 void orc_mpc_gait(int n_segments, const int offsets[2], const int durations[2], int iteration, int *table /*[2n]*/);

@@ -118,6 +118,62 @@ def test_oracle_jacobian_structure(oracle):
             np.testing.assert_allclose(tau[k, leg], J.T @ f[k, 6 * leg:6 * leg + 6], rtol=1e-13, atol=1e-13)
 
 
+def _legcontroller_mutation(q_motor):
+    """common/LegController.cpp:48-52, 108-113: updateData() passes data[leg].q BY REFERENCE to
+    computeLegJacobianAndPosition, which adds its offsets (pi ~ 3.14159) in place -- what the MPC reads afterwards."""
+    q = np.array(q_motor, dtype=np.float64, copy=True)
+    for leg in (0, 1):
+        q[..., 5 * leg + 2] = q[..., 5 * leg + 2] + 0.3 * 3.14159
+        q[..., 5 * leg + 3] = q[..., 5 * leg + 3] - 0.6 * 3.14159
+        q[..., 5 * leg + 4] = q[..., 5 * leg + 4] + 0.3 * 3.14159
+    return q
+
+
+def test_motor_angle_flag_models_the_legcontroller_mutation(oracle):
+    """The live reference feeds the MPC data[leg].q AFTER the LegController's in-place offset (SURVEY A.9 "triple
+    offset").  A tick carrying raw motor angles with HMPC_TICK_LEG_Q_MOTOR builds the same record, bit for bit, as a tick
+    carrying the mutated angles with flags = 0; the record's joint field is motor + 0.3*3.14159 + 0.3*PI (fmod 2 PI)."""
+    h = 10
+    t = synthetic.make_ticks(24, h, "walking", seed=5)
+    q_motor = np.array(t["leg_q"], copy=True)          # treat the synthetic angles as what the motors report
+    t_mut = t.copy()
+    t_mut["leg_q"] = _legcontroller_mutation(q_motor)  # what updateMPCIfNeeded reads on the live path
+    t_mot = t.copy()
+    t_mot["flags"] = 1
+    rec_mut, _ = oracle.build_records(t_mut, h, synthetic.DT_MPC)
+    rec_mot, _ = oracle.build_records(t_mot, h, synthetic.DT_MPC)
+    np.testing.assert_array_equal(rec_mot, rec_mut)
+    rec_plain, _ = oracle.build_records(t, h, synthetic.DT_MPC)  # same angles WITHOUT the flag: a different record
+    ja = lambda r: records.unpack_records(r, h)["joint_angles"].astype(np.float64)
+    PI = 3.14159265359
+    want = q_motor.copy()
+    for leg in (0, 1):
+        for j, c in ((2, 0.3), (3, -0.6), (4, 0.3)):
+            want[:, 5 * leg + j] = np.fmod((want[:, 5 * leg + j] + c * 3.14159) + c * PI, 2 * PI)
+    np.testing.assert_array_equal(ja(rec_mot), want.astype(np.float32).astype(np.float64))
+    assert np.abs(ja(rec_plain)[:, 2] - ja(rec_mot)[:, 2]).min() > 0.9  # ~0.3*pi: the mistake the flag exists to prevent
+    # the Jacobian side (hmpc_leg_torques) takes the MOTOR angle: it applies LegController.cpp:111-113 itself
+    J = oracle.leg_jacobian(q_motor[0, :5], 0)
+    assert np.isfinite(J).all()
+
+
+@pytest.mark.gpu
+def test_device_builder_motor_angle_flag_bitwise(oracle):
+    h, nb = 10, 40
+    t = synthetic.make_ticks(nb, h, "walking", seed=9)
+    t["flags"] = 1
+    want, _ = oracle.build_records(t, h, synthetic.DT_MPC)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb)
+    mpc.build_records(t, synthetic.DT_MPC)
+    np.testing.assert_array_equal(mpc.download_records(), want)
+    t2 = t.copy()
+    t2["flags"] = 0
+    t2["leg_q"] = _legcontroller_mutation(t["leg_q"])
+    mpc.build_records(t2, synthetic.DT_MPC)
+    np.testing.assert_array_equal(mpc.download_records(), want)
+    mpc.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("gait,h,nb", [("walking", 10, 64), ("standing", 10, 33), ("walking", 20, 16)])
 def test_device_builder_bitwise(oracle, gait, h, nb):
