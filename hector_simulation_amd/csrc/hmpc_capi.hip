@@ -32,7 +32,7 @@ thread_local std::string g_hip_err;
   } while (0)
 
 #ifndef HMPC_QCAP_FAST
-#define HMPC_QCAP_FAST 80  // working-set capacity of the fast 120-variable variants
+#define HMPC_QCAP_FAST 64  // working-set capacity of the fast 120-variable h <= 10 variant (49 KB LDS: three per CU)
 #endif
 typedef void (*kernel_fn)(hmpc::KernelArgs);
 
@@ -45,7 +45,8 @@ struct Variant {
 
 // NMAX = reduced variables held on chip (6 per stance leg-step); 120 -> 256-thread workgroups (210 register blocks),
 // 60 (single support over h <= 10) -> 128-thread workgroups (55 blocks).  QCAP = working-set capacity: the fast variants
-// hold 80 rows (two workgroups per CU); the "safe" variants hold NMAX rows (can never overflow, one workgroup per CU)
+// hold 64 rows at h <= 10 (49 KB LDS, 168 VGPRs: three workgroups per CU) and 80 at h = 20 (two per CU); the "safe"
+// variants hold NMAX rows (can never overflow)
 // and re-solve the few instances the fast pass flags (hmpc_resolve_failed).
 // The extension with a third (hand) contact -- BASELINE config 5, 180 variables x 240 rows at h = 10 -- runs 512-thread
 // workgroups (465 register blocks, one workgroup per CU).
@@ -59,7 +60,7 @@ Variant make_variant() {
 
 const Variant *variants() {
   static const Variant v[] = {make_variant<60, 10, 128, 60>(),   make_variant<120, 10, 256, HMPC_QCAP_FAST>(),
-                              make_variant<60, 20, 128, 60>(),   make_variant<120, 20, 256, HMPC_QCAP_FAST>(),
+                              make_variant<60, 20, 128, 60>(),   make_variant<120, 20, 256, 80>(),
                               make_variant<120, 10, 256, 120>(), make_variant<120, 20, 256, 120>(),
                               make_variant<180, 10, 512, 100, 3>(), make_variant<180, 10, 512, 140, 3>()};
   return v;

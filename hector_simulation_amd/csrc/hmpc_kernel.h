@@ -218,14 +218,26 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #if HMPC_MFMA_SWEEP
 #include "hmpc_sweep_mfma.h"
 #endif
-#ifndef HMPC_WG_PER_CU_256
-#define HMPC_WG_PER_CU_256 2  // resident 256-thread workgroups per CU the fast 120-variable variant is compiled for
+// Waves per SIMD ("execution unit") each variant is compiled for -- the second argument of HIP's __launch_bounds__ --
+// which fixes the register budget (512 / waves):
+//   fast variants with h <= 10 (256 threads / 120 variables / working set <= 64 rows: 49 KB LDS; 128 threads / 60
+//   variables: 26 KB LDS): THREE waves per SIMD = 168 VGPRs = three resp. six resident workgroups per CU.  The kernel is
+//   bound by dependent-instruction latency and barrier phases, not by issue: the third wave is worth +30 % (profiles/r02).
+//   Everything else (h = 20 scratch, safe variants, 512 threads): two.
+#ifndef HMPC_WAVES_PER_EU_256
+#define HMPC_WAVES_PER_EU_256 3
+#endif
+#ifndef HMPC_WAVES_PER_EU_128
+#define HMPC_WAVES_PER_EU_128 3
+#endif
+#ifndef HMPC_PIN_SWEEP
+#define HMPC_PIN_SWEEP 1
 #endif
 namespace hmpc {
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC = 2>
-__global__ __launch_bounds__(NT, (NT >= 512) ? 1 : ((NT == 256 && QCAP <= 64) ? HMPC_WG_PER_CU_256 : 2)) void hmpc_kernel(KernelArgs args) {
+__global__ __launch_bounds__(NT, (NT < 512 && QCAP <= 64 && HMAX <= 10) ? (NT == 128 ? HMPC_WAVES_PER_EU_128 : HMPC_WAVES_PER_EU_256) : 2) void hmpc_kernel(KernelArgs args) {
   using SM = Smem<NMAX, HMAX, NT, QCAP, NC>;
   using RL = RecLayout<NC>;
   constexpr int NG = SM::NG, NW = SM::NW, U = SM::U, PS = SM::PS, C8 = 8 * NC;
@@ -804,6 +816,15 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : ((NT == 256 && QCAP <= 64) ? 
           for (int ii = 0; ii < GS; ++ii) pn[i0 + ii] = a[ii][0];
         }
       }
+      // every update of this sweep is complete before the barrier: the pivot-row temporaries die here instead of
+      // overlapping the next sweep's reads (the compiler would otherwise sink 30 of the 36 FMAs past the barrier and keep
+      // two sets of pivot-row registers alive: +30 VGPRs, the difference between two and three workgroups per CU)
+#if HMPC_PIN_SWEEP
+#pragma unroll
+      for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < GS; ++jj) asm volatile("" : "+v"(a[ii][jj]));
+#endif
       __syncthreads();
     }
   }
@@ -878,9 +899,11 @@ __global__ __launch_bounds__(NT, (NT >= 512) ? 1 : ((NT == 256 && QCAP <= 64) ? 
       constexpr int HB = NG / 2;
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
+        // rows >= ng of ST are never written: they are read all the same (one base address, immediate offsets -- a
+        // clamped row index costs one address register per row) and masked out by the selects below
         double sv[HB];
 #pragma unroll
-        for (int s = 0; s < HB; ++s) sv[s] = Q.ST[(hb * HB + s < ng) ? hb * HB + s : 0][tid];
+        for (int s = 0; s < HB; ++s) sv[s] = Q.ST[hb * HB + s][tid];
 #pragma unroll
         for (int s = 0; s < HB; s += 2) {
           s0 += (hb * HB + s < ng) ? sv[s] : 0.0;

@@ -97,7 +97,7 @@ enum hmpc_status_code {
   HMPC_S_INFEASIBLE = 2,  /* constraints inconsistent */
   HMPC_S_TOO_LARGE = 3,   /* more than HMPC_MAX_VARS reduced variables (e.g. double support over h > 10) */
   HMPC_S_KKT = 4,         /* final KKT check outside tolerance */
-  HMPC_S_WORKSET = 5,     /* more simultaneously active constraints than the on-chip working set holds (80) */
+  HMPC_S_WORKSET = 5,     /* more simultaneously active constraints than the fast variant's on-chip working set holds (64 rows at h <= 10, 80 at h = 20; the safe pass holds as many as there are variables) */
   HMPC_S_OK_RELAXED = 6   /* solved, but only after every bound was moved outward by <= 2e-6 (relative for the Fz cap):
                              the last-resort pass of hmpc_resolve_failed for instances cycling at a degenerate vertex */
 };

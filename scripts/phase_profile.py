@@ -21,7 +21,7 @@ def main():
     nb = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
     prof_lib = os.path.join(ROOT, "gpurun_out", "libhector_mpc_hip_prof.so")
     os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
-    subprocess.check_call(["hipcc"] + build.FLAGS + ["-DHMPC_PROFILE", os.path.join(build.CSRC, "hmpc_capi.hip"), "-o", prof_lib])
+    subprocess.check_call(["hipcc"] + build.FLAGS + ["-DHMPC_PROFILE"] + [os.path.join(build.CSRC, s) for s in build.SOURCES] + ["-o", prof_lib])
     build.LIB = prof_lib
     build.needs_build = lambda: False
     f = synthetic.make_batch(nb, h, gait, seed=6, phase="random")
