@@ -15,10 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhector_mpc_hip.so")
 SOURCES = ["hmpc_capi.hip", "hmpc_group.hip"]
-DEPS = ["hmpc_capi.hip", "hmpc_group.hip", "hmpc_kernel.h", "hmpc_sweep_mfma.h", "hmpc_math.h", "hmpc_builder.h", os.path.join("..", "..", "include", "hector_mpc.h")]
+DEPS = ["hmpc_capi.hip", "hmpc_group.hip", "hmpc_kernel.h", "hmpc_math.h", "hmpc_builder.h", os.path.join("..", "..", "include", "hector_mpc.h")]
 # -ffp-contract=off is part of the numerical contract (HMPC-A1): every fused multiply-add in the source is explicit
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value",
-         "-Wno-pass-failed", "-ldl"] + os.environ.get("HMPC_EXTRA_FLAGS", "").split()  # developer switches, e.g. -DHMPC_MFMA_SWEEP=1
+         "-Wno-pass-failed", "-ldl"] + os.environ.get("HMPC_EXTRA_FLAGS", "").split()  # developer switches, e.g. -DHMPC_WAVES_PER_EU_256=2
 
 
 def source_hash() -> str:

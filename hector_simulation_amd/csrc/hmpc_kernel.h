@@ -24,9 +24,6 @@
 #ifndef HMPC_REFINE
 #define HMPC_REFINE 1  // corrections u += E (b_W - N_W x(u)) applied to the multipliers of the final working set
 #endif
-#ifndef HMPC_MFMA_SWEEP
-#define HMPC_MFMA_SWEEP 0  // 1: experimental panel-blocked inversion on the fp64 matrix cores (hmpc_sweep_mfma.h)
-#endif
 
 #include "hmpc_math.h"
 
@@ -215,9 +212,6 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 }
 
 }  // namespace hmpc
-#if HMPC_MFMA_SWEEP
-#include "hmpc_sweep_mfma.h"
-#endif
 // Waves per SIMD ("execution unit") each variant is compiled for -- the second argument of HIP's __launch_bounds__ --
 // which fixes the register budget (512 / waves):
 //   fast variants with h <= 10 (256 threads / 120 variables / working set <= 64 rows: 49 KB LDS; 128 threads / 60
@@ -733,9 +727,6 @@ __global__ __launch_bounds__(NT, (NT < 512 && QCAP <= 64 && HMAX <= 10) ? (NT ==
   const bool diag = (e0 == e1);
   const int i0 = GS * e0, j0 = GS * e1;
   double a[GS][GS];
-#if HMPC_MFMA_SWEEP
-  sweep_mfma<NMAX, NT>(S, a, n, ng, tid, wv, ln, owner, e1, i0, j0, diag);
-#else
 #pragma unroll
   for (int ii = 0; ii < GS; ++ii)
 #pragma unroll
@@ -838,7 +829,6 @@ __global__ __launch_bounds__(NT, (NT < 512 && QCAP <= 64 && HMAX <= 10) ? (NT ==
   for (int ii = 1; ii < GS; ++ii)
 #pragma unroll
     for (int jj = 0; jj < ii; ++jj) a[ii][jj] = diag ? a[jj][ii] : a[ii][jj];
-#endif
   PROF_MARK(P_SWEEP);
 
   // ---- products with the register blocks --------------------------------------------------------------------------

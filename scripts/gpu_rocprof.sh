@@ -11,6 +11,10 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/rocp
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/rocprof/pmc_write -o pmc -- $CMD > gpurun_out/rocprof/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/rocprof/pmc_sq -o pmc -- $CMD > gpurun_out/rocprof/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_FMA_F SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/rocprof/pmc_sq2 -o pmc -- $CMD > gpurun_out/rocprof/pmc_sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 --output-format csv -d gpurun_out/rocprof/pmc_f64 -o pmc -- $CMD > gpurun_out/rocprof/pmc_f64.log 2>&1
+python scripts/phase_profile.py standing 10 6144 > gpurun_out/rocprof/phase_cycles.txt 2>/dev/null
+python scripts/phase_profile.py walking 10 6144 >> gpurun_out/rocprof/phase_cycles.txt 2>/dev/null
+python scripts/soak.py > gpurun_out/rocprof/soak.txt 2>&1
 find gpurun_out/rocprof -name '*.db' -delete
 cat gpurun_out/rocprof/bench_standing.json
 head -3 gpurun_out/rocprof/kt/kt_kernel_stats.csv
