@@ -856,8 +856,6 @@ __global__ __launch_bounds__(NT, (NT < 512 && QCAP <= 64 && HMAX <= 10) ? (NT ==
       ca[jj] = s0 + s1;
     }
   };
-  // a diagonal block is stored as the full symmetric 6x6
-  auto blk_sym = [&](const double (&w)[GS], double (&out)[GS]) { blk_rows(w, out); };
   // z = M w for a dense w in LDS (entries >= n exactly 0).  Every block writes its row partial to ST[e1][vars of e0]
   // and its mirrored partial to ST[e0][vars of e1]; variable i then sums ST[0..ng-1][i] in index order (deterministic).
   auto rmatvec = [&](const double *w) {
@@ -869,18 +867,14 @@ __global__ __launch_bounds__(NT, (NT < 512 && QCAP <= 64 && HMAX <= 10) ? (NT ==
         const double2 u2 = *reinterpret_cast<const double2 *>(w + j0 + k);
         wi[k] = t2.x, wi[k + 1] = t2.y, wj[k] = u2.x, wj[k + 1] = u2.y;
       }
-      if (diag) {
-        blk_sym(wj, ra);
+      // one code path for every block: a diagonal block is stored as the full, exactly symmetric 6x6 and has wi == wj, so
+      // its two products are the same bits and its two stores hit the same words with the same values
+      blk_rows(wj, ra);
+      blk_cols(wi, ca);
 #pragma unroll
-        for (int k = 0; k < GS; k += 2) *reinterpret_cast<double2 *>(&Q.ST[e0][i0 + k]) = make_double2(ra[k], ra[k + 1]);
-      } else {
-        blk_rows(wj, ra);
-        blk_cols(wi, ca);
-#pragma unroll
-        for (int k = 0; k < GS; k += 2) {
-          *reinterpret_cast<double2 *>(&Q.ST[e1][i0 + k]) = make_double2(ra[k], ra[k + 1]);
-          *reinterpret_cast<double2 *>(&Q.ST[e0][j0 + k]) = make_double2(ca[k], ca[k + 1]);
-        }
+      for (int k = 0; k < GS; k += 2) {
+        *reinterpret_cast<double2 *>(&Q.ST[e1][i0 + k]) = make_double2(ra[k], ra[k + 1]);
+        *reinterpret_cast<double2 *>(&Q.ST[e0][j0 + k]) = make_double2(ca[k], ca[k + 1]);
       }
     }
     __syncthreads();
@@ -1135,8 +1129,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && QCAP <= 64 && HMAX <= 10) ? (NT ==
             double cn1[GS], t6[GS];
 #pragma unroll
             for (int k = 0; k < GS; ++k) cn1[k] = (double)ac1 * S.Cn[leg1][r1][k];
-            if (diag) blk_sym(cn1, t6);
-            else blk_rows(cn1, t6);
+            blk_rows(cn1, t6);  // (a diagonal block is stored as the full symmetric 6x6)
             const int s1 = Q.slot[8 * e1 + r1];
             for (int r0 = rlo; r0 <= (diag ? r1 : rhi); ++r0) {
               const int ac0 = (int)(signed char)((am0 >> (8 * r0)) & 0xff);
@@ -1355,10 +1348,14 @@ __global__ __launch_bounds__(NT, (NT < 512 && QCAP <= 64 && HMAX <= 10) ? (NT ==
         //     (min(eo,ep), max(eo,ep)), whose owner forms t = M(eo,ep) n+ once and dots it with each active row;
         //     the diagonal block also gives gamma = n+' M n+
         if (owner && e1 < ng && (e0 == ep || e1 == ep)) {
-          double t6[GS];
-          if (diag) blk_sym(np, t6);
-          else if (e1 == ep) blk_rows(np, t6);
-          else blk_cols(np, t6);
+          // t = M(eo, ep) n+: the row product when ep is this block's column leg-step (and on the diagonal), the column
+          // product otherwise; both are formed (no divergence inside the wave) and one is kept
+          double t6[GS], tc[GS];
+          blk_rows(np, t6);
+          blk_cols(np, tc);
+          const bool use_rows = (e1 == ep);
+#pragma unroll
+          for (int k = 0; k < GS; ++k) t6[k] = use_rows ? t6[k] : tc[k];
           const int eo = (e0 == ep) ? e1 : e0;
           const int lego = S.ls_leg[eo];
           const unsigned long long am = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * eo]);
