@@ -60,7 +60,7 @@ Variant make_variant() {
 
 const Variant *variants() {
   static const Variant v[] = {make_variant<60, 10, 128, 60>(),   make_variant<120, 10, 256, HMPC_QCAP_FAST>(),
-                              make_variant<60, 20, 128, 60>(),   make_variant<120, 20, 256, 80>(),
+                              make_variant<60, 20, 128, 60>(),   make_variant<120, 20, 256, HMPC_QCAP_FAST>(),
                               make_variant<120, 10, 256, 120>(), make_variant<120, 20, 256, 120>(),
                               make_variant<180, 10, 512, 100, 3>(), make_variant<180, 10, 512, 140, 3>()};
   return v;

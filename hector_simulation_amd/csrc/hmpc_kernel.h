@@ -115,7 +115,7 @@ struct Smem {
     float ypsc[4];  // cy, sy, cp, sp
     float Acd[169], Bcd[PS], x0[13], W[13], Fc[8 * NC * U];
     float Apow[2 * 169];
-    float Phi[HMAX * PS], SPhi[HMAX * PS];
+    float Phi[HMAX * PS];  // Phi_k = Acd^k Bcd; S Phi_k = fl(w_s Phi_k) is formed where it is consumed (one multiply)
     float e[13 * HMAX];
     unsigned char pre_nl[HMAX], pre_nv[HMAX], pre_st[HMAX];  // per step: leg-steps / variables before it, stance bits
     float Hs[(NMAX / 2) * (NMAX + 1)];  // H, upper triangle, binary32 (exact), rows i and NMAX-1-i folded into one
@@ -229,9 +229,15 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #endif
 namespace hmpc {
 
+// three waves per SIMD = 3 (256 threads) or 6 (128 threads) workgroups per CU: their LDS must fit the CU's 160 KB
+template <int NMAX, int HMAX, int NT, int QCAP, int NC>
+constexpr bool fits_three_waves() {
+  return sizeof(Smem<NMAX, HMAX, NT, QCAP, NC>) * (size_t)(3 * 256 / NT) <= (size_t)160 * 1024;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC = 2>
-__global__ __launch_bounds__(NT, (NT < 512 && QCAP <= 64 && HMAX <= 10) ? (NT == 128 ? HMPC_WAVES_PER_EU_128 : HMPC_WAVES_PER_EU_256) : 2) void hmpc_kernel(KernelArgs args) {
+__global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, QCAP, NC>()) ? (NT == 128 ? HMPC_WAVES_PER_EU_128 : HMPC_WAVES_PER_EU_256) : 2) void hmpc_kernel(KernelArgs args) {
   using SM = Smem<NMAX, HMAX, NT, QCAP, NC>;
   using RL = RecLayout<NC>;
   constexpr int NG = SM::NG, NW = SM::NW, U = SM::U, PS = SM::PS, C8 = 8 * NC;
@@ -572,7 +578,6 @@ __global__ __launch_bounds__(NT, (NT < 512 && QCAP <= 64 && HMAX <= 10) ? (NT ==
       } else if (kind == 1) {
         if (k < h) {
           A.Phi[k * PS + out] = acc;
-          A.SPhi[k * PS + out] = A.W[out / U] * acc;
         }
       } else if (kind == 2 && k >= 1) {
         const float xd = (out < 12) ? in_traj[12 * (k - 1) + out] : 0.0f;
@@ -588,10 +593,10 @@ __global__ __launch_bounds__(NT, (NT < 512 && QCAP <= 64 && HMAX <= 10) ? (NT ==
     const int a = S.vstep[tid], c = S.vcomp[tid];
     float acc = 0.0f;
     for (int i = a; i < h; ++i) {
-      const float *sp = A.SPhi + (i - a) * PS + c;
+      const float *sp = A.Phi + (i - a) * PS + c;
       const float *ep = A.e + 13 * i;
 #pragma unroll
-      for (int s = 0; s < 13; ++s) acc = ffma(sp[s * U], ep[s], acc);
+      for (int s = 0; s < 13; ++s) acc = ffma(A.W[s] * sp[s * U], ep[s], acc);  // (B'S) first: fl(w_s Phi), then the chain
     }
     S.g[S.o2s[tid]] = (double)(2.0f * acc);
   }
@@ -605,6 +610,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && QCAP <= 64 && HMAX <= 10) ? (NT ==
     const int nti = (n + 15) >> 4;
     const int ntiles = nti * (nti + 1) / 2;
     const int l15 = ln & 15, kq = ln >> 4;
+    const float wq0 = A.W[kq], wq1 = A.W[kq + 4], wq2 = A.W[kq + 8];
     // Two tiles per pass (independent accumulators hide the MFMA dependency latency) and the operands of step i+1 are
     // fetched while the matrix instructions of step i run.  A tile's steps before its first live one only add exact zeros.
     struct Tile {
@@ -623,9 +629,10 @@ __global__ __launch_bounds__(NT, (NT < 512 && QCAP <= 64 && HMAX <= 10) ? (NT ==
     };
     auto fetch = [&](const Tile &T, int i, float (&o)[6]) {
       const bool la = T.rav && i >= T.sa, lb = T.cbv && i >= T.sb;
-      const float *pa = A.SPhi + (la ? (i - T.sa) * PS + T.ca : 0) + kq * U;
+      const float *pa = A.Phi + (la ? (i - T.sa) * PS + T.ca : 0) + kq * U;
       const float *pb = A.Phi + (lb ? (i - T.sb) * PS + T.cc : 0) + kq * U;
-      const float a0 = pa[0], a1 = pa[4 * U], a2 = pa[8 * U], b0 = pb[0], b1 = pb[4 * U], b2 = pb[8 * U];
+      const float a0 = wq0 * pa[0], a1 = wq1 * pa[4 * U], a2 = wq2 * pa[8 * U];  // S Phi = fl(w_s Phi), rows kq, kq+4, kq+8
+      const float b0 = pb[0], b1 = pb[4 * U], b2 = pb[8 * U];
       o[0] = la ? a0 : 0.0f, o[1] = la ? a1 : 0.0f, o[2] = la ? a2 : 0.0f;
       o[3] = lb ? b0 : 0.0f, o[4] = lb ? b1 : 0.0f, o[5] = lb ? b2 : 0.0f;
     };
