@@ -763,6 +763,17 @@ static int g_q_len = 0;
 static int g_has_solved = 0;
 static uint32_t g_last_status = 0;
 static int g_setup_error = 0;
+// one tick = one pinned staging buffer [record | 12h forces | status word] and one contiguous device output block, so that
+// a blocking tick costs one asynchronous H2D copy, one launch, one asynchronous D2H copy and a single synchronisation
+static unsigned char *g_pin = nullptr;
+static float *g_dev_out = nullptr;
+static size_t g_pin_rec_bytes = 0;
+
+static void free_tick_buffers(void) {
+  if (g_pin) hipHostFree(g_pin);
+  if (g_dev_out) hipFree(g_dev_out);
+  g_pin = nullptr, g_dev_out = nullptr, g_pin_rec_bytes = 0;
+}
 
 void setup_problem(double dt, int horizon, double mu, double f_max) {
   g_setup.horizon = horizon;
@@ -782,6 +793,7 @@ void setup_problem(double dt, int horizon, double mu, double f_max) {
                    g_handle->setup.f_max != g_setup.f_max)) {
     hmpc_destroy(g_handle);
     g_handle = nullptr;
+    free_tick_buffers();
   }
   if (!g_handle) {
     // the reference has no notion of a device: HMPC_DEVICE (default 0) picks the GPU of the process-global solver
@@ -792,6 +804,18 @@ void setup_problem(double dt, int horizon, double mu, double f_max) {
       fprintf(stderr, "[hector_mpc_hip] setup_problem failed (%d): %s\n", rc, hmpc_last_hip_error());
       g_handle = nullptr;
       g_setup_error = rc;
+      return;
+    }
+    g_pin_rec_bytes = (record_stride(horizon) + 63) & ~(size_t)63;
+    const size_t out_bytes = sizeof(float) * 12 * horizon + sizeof(uint32_t);
+    if (hipHostMalloc((void **)&g_pin, g_pin_rec_bytes + out_bytes, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&g_dev_out, out_bytes) != hipSuccess ||
+        hmpc_set_device_outputs(g_handle, g_dev_out, (uint32_t *)(g_dev_out + 12 * horizon)) != HMPC_OK) {
+      fprintf(stderr, "[hector_mpc_hip] setup_problem: could not allocate the tick buffers\n");
+      free_tick_buffers();
+      hmpc_destroy(g_handle);
+      g_handle = nullptr;
+      g_setup_error = HMPC_E_HIP;
       return;
     }
   }
@@ -808,19 +832,35 @@ static void solve_global(void) {
     return;
   }
   const int hz = g_setup.horizon;
-  std::vector<unsigned char> rec(record_stride(hz), 0);
-  float *f = (float *)rec.data();
+  unsigned char *rec = g_pin;
+  memset(rec, 0, record_stride(hz));
+  float *f = (float *)rec;
   memcpy(f + 0, g_update.p, 12), memcpy(f + 3, g_update.v, 12), memcpy(f + 6, g_update.q, 16);
   memcpy(f + 10, g_update.w, 12), memcpy(f + 13, g_update.r, 24), memcpy(f + 19, g_update.joint_angles, 40);
   f[29] = g_update.yaw;
   memcpy(f + 30, g_update.weights, 48), memcpy(f + 42, g_update.Alpha_K, 48);
   memcpy(f + 54, g_update.traj, sizeof(float) * 12 * hz);
-  memcpy(rec.data() + 4 * (54 + 12 * hz), g_update.gait, 2 * hz);
-  std::vector<float> forces(12 * hz);
+  memcpy(rec + 4 * (54 + 12 * hz), g_update.gait, 2 * hz);
+  const float *forces = (const float *)(g_pin + g_pin_rec_bytes);
+  const uint32_t *pst = (const uint32_t *)(forces + 12 * hz);
+  const size_t out_bytes = sizeof(float) * 12 * hz + sizeof(uint32_t);
   uint32_t st = 0;
-  int rc = hmpc_upload_records(g_handle, rec.data(), 1);
+  int rc = hmpc_upload_records_async(g_handle, rec, 1, nullptr);  // pinned source: a true asynchronous copy
   if (rc == HMPC_OK) rc = hmpc_solve(g_handle, nullptr);
-  if (rc == HMPC_OK) rc = hmpc_download(g_handle, forces.data(), &st);
+  if (rc == HMPC_OK && (hipMemcpyAsync(g_pin + g_pin_rec_bytes, g_dev_out, out_bytes, hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
+                        hipStreamSynchronize(nullptr) != hipSuccess))
+    rc = HMPC_E_HIP;
+  if (rc == HMPC_OK) {
+    st = *pst;
+    const uint32_t c0 = HMPC_STATUS_CODE(st);
+    if (c0 == HMPC_S_WORKSET || c0 == HMPC_S_MAXITER || c0 == HMPC_S_INFEASIBLE || c0 == HMPC_S_KKT) {
+      // flagged by the fast variant: the safe pass (full-size working set, then relaxed bounds), as hmpc_download gives it
+      rc = hmpc_resolve_failed(g_handle, nullptr);
+      if (rc == HMPC_OK && hipMemcpy(g_pin + g_pin_rec_bytes, g_dev_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = HMPC_E_HIP;
+      st = *pst;
+    }
+  }
   if (rc != HMPC_OK) {
     fprintf(stderr, "[hector_mpc_hip] solve failed (%d): %s\n", rc, hmpc_last_hip_error());
     return;
