@@ -1,0 +1,32 @@
+#!/bin/bash
+# the host side of libhector_mpc_hip.so under AddressSanitizer + UndefinedBehaviorSanitizer.
+# Builds a host-instrumented copy of the library (device code not instrumented: -fno-gpu-sanitize), then runs the C/C++
+# programs that drive the C ABI -- tests/src/host_api_sweep.c (every batched entry point incl. error paths, scratch reuse,
+# safe pass, device group), examples/legacy_tick.cpp, examples/batched.c, examples/batched_multi.c -- against it.
+# Leak checking is off (the HIP runtime keeps process-lifetime allocations); every other ASan/UBSan report is fatal.
+# Run on a GPU box:  gpurun -- 'bash scripts/sanitize_host.sh > gpurun_out/sanitize.txt 2>&1'
+set -u
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+OUT=gpurun_out/sanitize; mkdir -p $OUT
+RT=$(find /opt/rocm/lib/llvm -name 'libclang_rt.asan-x86_64.so' | head -1)
+SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g"
+hipcc --offload-arch=gfx950 -O1 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -Wno-pass-failed $SAN -fno-gpu-sanitize \
+  -shared-libsan hector_simulation_amd/csrc/hmpc_capi.hip hector_simulation_amd/csrc/hmpc_group.hip -ldl -o $OUT/libhector_mpc_hip.so || exit 2
+CLANG=$(dirname $(dirname "$RT"))/../../../bin/clang
+[ -x "$CLANG" ] || CLANG=/opt/rocm/lib/llvm/bin/clang
+fail=0
+run() {  # name, compiler driver mode, source, args...
+  local name=$1 lang=$2 src=$3; shift 3
+  $CLANG $lang -O1 $SAN -shared-libsan -Iinclude $src -L$OUT -lhector_mpc_hip -lm -lstdc++ -Wl,-rpath,$PWD/$OUT -Wl,-rpath,$(dirname $RT) -o $OUT/$name || { echo "COMPILE FAILED $name"; fail=1; return; }
+  ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 $OUT/$name "$@"
+  local rc=$?
+  echo "== $name $* -> exit $rc"
+  [ $rc -eq 0 ] || fail=1
+}
+run host_api_sweep "-x c -std=c11" tests/src/host_api_sweep.c
+run legacy_tick "-x c++ -std=c++17" examples/legacy_tick.cpp
+run batched "-x c -std=c11" examples/batched.c
+run batched_multi "-x c -std=c11" examples/batched_multi.c 3 p2p
+run batched_multi_rccl "-x c -std=c11" examples/batched_multi.c 1
+echo "sanitize_host: $([ $fail -eq 0 ] && echo 'CLEAN (no AddressSanitizer / UBSan report, every program exited 0)' || echo 'FAILED')"
+exit $fail

@@ -11,11 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "hector_simulation_amd")
 
 
-def _compile(tmp_path, src, cc, std):
+def _compile(tmp_path, src, cc, std, folder="examples"):
     build.build()
     exe = str(tmp_path / os.path.splitext(src)[0])
-    cmd = [cc, std, "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", src), "-L" + PKG,
-           "-lhector_mpc_hip", "-Wl,-rpath," + PKG, "-o", exe]
+    cmd = [cc, std, "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, folder, src), "-L" + PKG,
+           "-lhector_mpc_hip", "-lm", "-Wl,-rpath," + PKG, "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
@@ -58,3 +58,21 @@ def test_multi_device_example_runs_on_gpu(tmp_path, args):
     r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 of 1000 not ok, 0 gathered rows differ" in r.stdout
+
+
+def test_host_api_sweep_compiles_and_fails_loudly_without_gpu(tmp_path):
+    exe = _compile(tmp_path, "host_api_sweep.c", "gcc", "-std=c11", folder=os.path.join("tests", "src"))
+    if _has_gpu():
+        pytest.skip("GPU present: covered by the gpu-marked test")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 3 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_host_api_sweep_on_gpu(tmp_path):
+    """tests/src/host_api_sweep.c: every batched entry point from plain C, error paths, scratch reuse, safe pass, f64
+    copy-out before/after, tick warm start, device group (also the program scripts/sanitize_host.sh runs under ASan/UBSan)."""
+    exe = _compile(tmp_path, "host_api_sweep.c", "gcc", "-std=c11", folder=os.path.join("tests", "src"))
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host API sweep ok" in r.stdout
