@@ -1,8 +1,8 @@
 /*
  * hmpc_oracle.c -- CPU ORACLE (plain C restatement of the reference's convex-MPC QP path).
  * TEST INFRASTRUCTURE ONLY: imported/linked only by tests/, __graft_entry__.smoke() and bench.py's
- * cpu_baseline leg.  See oracle/hmpc_oracle.h for scope, provenance and the parity status
- * ("assembly half parity unpinned; solver half = the reference's own qpOASES").
+ * cpu_baseline leg.  See oracle/hmpc_oracle.h for scope, provenance and the parity status (assembly half pinned
+ * against the reference's own source compiled with oracle/mini_eigen; solver half = the reference's own qpOASES).
  *
  * Reference files restated (paths under Hector_ROS_Simulation/hector_control/ConvexMPC/):
  *   SolverMPC.cpp:65-89    euler_to_rotation      -> orc_euler_rate_inverse

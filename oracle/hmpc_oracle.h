@@ -7,10 +7,15 @@
  * used ONLY by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker.
  * The product (hector_simulation_amd/) never includes, links or calls anything in oracle/.
  *
- * PARITY STATUS: the reference ships no tests, golden vectors or fixtures for this path,
- * and its fp32 assembly runs inside Eigen3, which is not vendored and not installed here -> the ASSEMBLY half
- * is "parity unpinned" against the reference's own tests.  The SOLVER half is pinned: the QP is solved by the
- * reference's own vendored qpOASES 3.2.0 compiled unmodified into oracle/_ref/ (see oracle/Makefile).
+ * PARITY STATUS: the reference ships no tests, golden vectors or fixtures for this path.
+ * The SOLVER half is the reference itself: its vendored qpOASES 3.2.0 compiled unmodified into oracle/_ref/.
+ * The ASSEMBLY half (this file's restatement) is pinned against an EXECUTION OF THE REFERENCE'S OWN SOURCE:
+ * oracle/_ref/libsolvempc_ref.so = SolverMPC.cpp + RobotState.cpp + convexMPC_interface.cpp compiled unmodified
+ * against the Eigen stand-in oracle/mini_eigen (Eigen3 is an un-vendored, un-pinned dependency that is not installed
+ * here).  tests/test_reference_source.py: reduced structure, elimination pattern and bounds identical; with the two
+ * study switches orc_set_unfused_chain / orc_set_libm_trig on, x_0, A_ct, A_qp, B_qp, F_control, g and the upper triangle
+ * of H equal the reference's source bit for bit; under the default contract the data stay within binary32 round-off.
+ * Not pinned: the association inside Eigen's own kernels (see the header of oracle/mini_eigen/eigen3/Eigen/Dense).
  *
  * Pinned arithmetic ("HMPC-A1"): IEEE binary32, round-to-nearest-even, no implicit
  * contraction; every matrix contraction is a k-ascending fmaf chain started at +0; trigonometry is evaluated
