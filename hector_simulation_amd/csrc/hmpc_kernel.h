@@ -97,6 +97,7 @@ struct Smem {
   static constexpr int NW = NT / 64;
   static constexpr int QMAX = QCAP;      // working-set capacity (packed Schur inverse); QCAP = NMAX can never overflow
   static constexpr int RECW = ((RecLayout<NC>::NF + 12 * HMAX) * 4 + NC * HMAX + 15) / 16 * 4;  // record words
+  static constexpr bool FULLBLK = (HMAX <= 10 && NMAX >= 120);  // staging layout of H (struct Asm)
 
   double g[NMAX];        // gradient, sweep order
   double Cn[NC][8][6];   // per-contact constraint normals (columns: F then M of that contact)
@@ -118,7 +119,12 @@ struct Smem {
     float Phi[HMAX * PS];  // Phi_k = Acd^k Bcd; S Phi_k = fl(w_s Phi_k) is formed where it is consumed (one multiply)
     float e[13 * HMAX];
     unsigned char pre_nl[HMAX], pre_nv[HMAX], pre_st[HMAX];  // per step: leg-steps / variables before it, stance bits
-    float Hs[(NMAX / 2) * (NMAX + 1)];  // H, upper triangle, binary32 (exact), rows i and NMAX-1-i folded into one
+    // H in binary32 (exact), staged between the matrix-core phase and the register blocks of the sweeps.
+    //   FULLBLK (120/180 variables at h <= 10): every U x U block (a <= b) of the UNREDUCED matrix, row-major, block
+    //     a*h - a(a-1)/2 + (b-a) -- written by the Toeplitz chains with no index arithmetic (entries of swing leg-steps are
+    //     simply never read); + one spare word per lane for the padding lanes of the tiles;
+    //   otherwise: upper triangle over the reduced variables in reference order, rows i and NMAX-1-i folded into one.
+    float Hs[FULLBLK ? HMAX * (HMAX + 1) / 2 * U * U + 64 : (NMAX / 2) * (NMAX + 1)];
   };
   struct Rec {
     double val, raw, cn[6];
@@ -601,7 +607,93 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     S.g[S.o2s[tid]] = (double)(2.0f * acc);
   }
   PROF_MARK(P_G);
-  {
+  if constexpr (SM::FULLBLK) {
+    // H on the matrix cores, through the block-Toeplitz structure of B_qp.  With Phi_k = Acd^k Bcd,
+    //     H(a,b) = 2 [ sum_{i >= b} Phi_{i-a}' S Phi_{i-b} + alpha delta_ab ]          (U x U block, steps a <= b)
+    // and with j = i - b, d = b - a:  H(a, a+d) = 2 [ T_d(h-1-b) + ... ],  T_d(m) = sum_{j = 0..m} Phi_{j+d}' S Phi_j.
+    // So every block of one block-diagonal d is a PREFIX of one and the same chain T_d: h chains of h-d steps (55 block
+    // steps at h = 10) instead of one chain per block (220), and the bits are those of the contract's chain for every
+    // block -- terms in ascending step order, state rows ascending inside a step, started at +0 (the rows of B_qp above the
+    // block diagonal, which the dense chain also visits, are exact zeros and bitwise neutral; HMPC-A1).
+    // One chain = one 16x16 accumulator tile per (d, ti, tj) (ti, tj: 16-wide tiles of the U x U block: one for two
+    // contacts, four for three); K = 12 live state rows = 3 x k4 per step (the weight of row 12 is 0, SolverMPC.cpp:453);
+    // after each step the accumulator is the finished block H(h-1-m-d, h-1-m) and goes to the staging area as
+    // 2 (acc + alpha delta): four stores per lane at lane-constant offsets from a per-step base, no index arithmetic.
+    // (On the diagonal chain the lower triangle of a block is the unmirrored product; the loader reads the upper one.)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int l15 = ln & 15, kq = ln >> 4;
+    const float wq0 = A.W[kq], wq1 = A.W[kq + 4], wq2 = A.W[kq + 8];
+    constexpr int TB = (U + 15) / 16, UU = U * U;
+    constexpr int HB_SPARE = HMAX * (HMAX + 1) / 2 * UU;
+    const int nchain = h * TB * TB;
+    struct Chain {
+      bool live, av, bv;
+      int d, len, ra, cb;
+      int off[4], vm[4];  // staging offset of the four rows this lane holds inside a block (or its spare word), 1/0
+      float al[4];        // alpha on the diagonal entries of the diagonal chain, else 0
+    };
+    auto setup = [&](int idx, Chain &C) {
+      C.live = idx < nchain;
+      const int ci = C.live ? idx : 0;
+      C.d = ci / (TB * TB);
+      const int ti = (ci / TB) % TB, tj = ci % TB;
+      C.len = C.live ? h - C.d : 0;
+      C.ra = 16 * ti + l15, C.cb = 16 * tj + l15;
+      C.av = C.live && C.ra < U, C.bv = C.live && C.cb < U;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = 16 * ti + 4 * kq + rg;
+        const bool ok = C.bv && r < U;
+        C.vm[rg] = ok ? 1 : 0;
+        C.off[rg] = ok ? r * U + C.cb : HB_SPARE + ln;
+        C.al[rg] = (ok && C.d == 0 && r == C.cb) ? in_al[r] : 0.0f;
+      }
+    };
+    auto fetch = [&](const Chain &C, int j, float (&o)[6]) {
+      const bool la = C.av && j < C.len, lb = C.bv && j < C.len;
+      const float *pa = A.Phi + (la ? (j + C.d) * PS + C.ra : 0) + kq * U;
+      const float *pb = A.Phi + (lb ? j * PS + C.cb : 0) + kq * U;
+      const float a0 = wq0 * pa[0], a1 = wq1 * pa[4 * U], a2 = wq2 * pa[8 * U];  // S Phi = fl(w_s Phi), rows kq, kq+4, kq+8
+      const float b0 = pb[0], b1 = pb[4 * U], b2 = pb[8 * U];
+      o[0] = la ? a0 : 0.0f, o[1] = la ? a1 : 0.0f, o[2] = la ? a2 : 0.0f;
+      o[3] = lb ? b0 : 0.0f, o[4] = lb ? b1 : 0.0f, o[5] = lb ? b2 : 0.0f;
+    };
+    auto store = [&](const Chain &C, int m, const f4 &acc) {
+      if (!(C.live && m < C.len)) return;              // uniform
+      const int sb = h - 1 - m, sa = sb - C.d;          // the block this prefix of the chain is
+      const int base = (sa * h - sa * (sa - 1) / 2 + C.d) * UU;  // uniform
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) A.Hs[base * C.vm[rg] + C.off[rg]] = 2.0f * (acc[rg] + C.al[rg]);
+    };
+    // two chains per pass (independent accumulators hide the MFMA dependency latency); the operands of step j+1 are
+    // fetched while the matrix instructions of step j run
+    for (int idx = wv; idx < nchain; idx += 2 * NW) {
+      Chain C0, C1;
+      setup(idx, C0);
+      setup(idx + NW, C1);
+      const int steps = C0.len;  // the second chain of the pass lies on a later block-diagonal: it is not longer
+      f4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+      float c0[6], c1[6], n0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, n1[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      fetch(C0, 0, c0);
+      fetch(C1, 0, c1);
+      for (int j = 0; j < steps; ++j) {
+        if (j + 1 < steps) {
+          fetch(C0, j + 1, n0);
+          fetch(C1, j + 1, n1);
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[0], c0[3], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[0], c1[3], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[1], c0[4], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[1], c1[4], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[2], c0[5], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[2], c1[5], acc1, 0, 0, 0);
+        store(C0, j, acc0);
+        store(C1, j, acc1);
+#pragma unroll
+        for (int q2 = 0; q2 < 6; ++q2) c0[q2] = n0[q2], c1[q2] = n1[q2];
+      }
+    }
+  } else {
     // matrix cores: 16x16 output tiles over the reduced variables, K runs over (step i ascending, state row s ascending).
     // Rows of B_qp above the block diagonal are exact zeros, which are bitwise neutral in an fmaf chain started at +0,
     // so operands before a variable's own step are fed as 0 and the chain starts at the tile's first live step.
@@ -695,8 +787,13 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       o[DL::G + t] = (float)S.g[S.o2s[t]];
     }
     for (int t = tid; t < n * n; t += NT) {
-      const int i = t / n, j = t % n;
-      o[DL::H + t] = A.Hs[hs_index<NMAX>(i < j ? i : j, i < j ? j : i)];
+      const int i = t / n, j = t % n, lo = i < j ? i : j, hi = i < j ? j : i;  // reference order, upper triangle
+      if constexpr (SM::FULLBLK) {
+        const int sa = S.vstep[lo], sb = S.vstep[hi];
+        o[DL::H + t] = A.Hs[(sa * h - sa * (sa - 1) / 2 + (sb - sa)) * U * U + S.vcomp[lo] * U + S.vcomp[hi]];
+      } else {
+        o[DL::H + t] = A.Hs[hs_index<NMAX>(lo, hi)];
+      }
     }
     for (int t = tid; t < C8 * U; t += NT) o[DL::FC + t] = A.Fc[t];
     const float big = 5e10f;
@@ -734,18 +831,43 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   const bool diag = (e0 == e1);
   const int i0 = GS * e0, j0 = GS * e1;
   double a[GS][GS];
+  if constexpr (SM::FULLBLK) {
+    // Block (e0, e1) of the sweep order = leg-steps (sa, la) <= (sb, lb) (step-major); its entry (ii, jj) is the entry
+    // (r, c) = (comp(la, ii), comp(lb, jj)) of the staged U x U block (sa, sb), comp(l, k) = 3 l + k for the force and
+    // 3 NC + 3 l + k - 3 for the moment components -- read from the upper triangle in the reference order: when both
+    // leg-steps lie in the same horizon step, (r, c) with r > c is read at (c, r) (moment-of-la x force-of-lb entries, and
+    // the lower triangle of a diagonal block, which therefore comes out exactly symmetric).
+    const bool have = owner && e1 < ng;
+    const int sa = have ? (int)S.ls_step[e0] : 0, la = have ? (int)S.ls_leg[e0] : 0;
+    const int sb = have ? (int)S.ls_step[e1] : 0, lb = have ? (int)S.ls_leg[e1] : 0;
+    const int base = (sa * h - sa * (sa - 1) / 2 + (sb - sa)) * (U * U);
+    const float *bN = A.Hs + base + 3 * la * U + 3 * lb;  // + compR(ii) * U + compC(jj)
+    const float *bT = A.Hs + base + 3 * lb * U + 3 * la;  // transposed position: + compC(jj) * U + compR(ii)
+    const bool same = (sa == sb);
 #pragma unroll
-  for (int ii = 0; ii < GS; ++ii)
+    for (int ii = 0; ii < GS; ++ii)
 #pragma unroll
-    for (int jj = 0; jj < GS; ++jj) {
-      const int i = i0 + ii, j = j0 + jj;
-      double v = 0.0;
-      if (i < n && j < n) {
-        const int oi = S.s2o[i], oj = S.s2o[j];
-        v = (double)A.Hs[hs_index<NMAX>(oi < oj ? oi : oj, oi < oj ? oj : oi)];
+      for (int jj = 0; jj < GS; ++jj) {
+        constexpr int F = 3 * NC - 3;  // comp(l, k) - 3 l - k for a moment component
+        const int cr = (ii < 3) ? ii : F + ii, cc = (jj < 3) ? jj : F + jj;
+        const bool sw = (ii >= 3 && jj < 3) ? same : ((ii > jj) ? diag : false);
+        const float v = sw ? bT[cc * U + cr] : bN[cr * U + cc];
+        a[ii][jj] = have ? (double)v : 0.0;
       }
-      a[ii][jj] = v;
-    }
+  } else {
+#pragma unroll
+    for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < GS; ++jj) {
+        const int i = i0 + ii, j = j0 + jj;
+        double v = 0.0;
+        if (i < n && j < n) {
+          const int oi = S.s2o[i], oj = S.s2o[j];
+          v = (double)A.Hs[hs_index<NMAX>(oi < oj ? oi : oj, oi < oj ? oj : oi)];
+        }
+        a[ii][jj] = v;
+      }
+  }
   __syncthreads();  // every block is loaded before the solver state (which aliases the staging area) is written
   if (tid < NMAX) Q.piv[0][tid] = 0.0, Q.piv[1][tid] = 0.0;
   __syncthreads();
