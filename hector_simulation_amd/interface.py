@@ -275,6 +275,14 @@ class DeviceGroup:
         assert recs.ndim == 2 and recs.shape[1] == self.stride
         self._check(self.L.hmpc_group_upload_records(self.g, recs.ctypes.data, recs.shape[0]), "hmpc_group_upload_records")
 
+    def set_device_records(self, member_ptrs, batch: int, max_reduced_vars: int = -1, keepalive=None) -> None:
+        """Records already resident on each member's device: member_ptrs[i] = device pointer of member i's first record
+        (slice sizes follow ``shard_bounds``)."""
+        self._keep = keepalive
+        arr = (C.c_void_p * self.size)(*[C.c_void_p(int(p)) for p in member_ptrs])
+        self._check(self.L.hmpc_group_set_device_records(self.g, arr, int(batch), int(max_reduced_vars)),
+                    "hmpc_group_set_device_records")
+
     def solve(self) -> None:
         self._check(self.L.hmpc_group_solve(self.g), "hmpc_group_solve")
 

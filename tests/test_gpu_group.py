@@ -93,3 +93,26 @@ def test_group_pipelined_exchange_under_the_next_solve():
 def test_group_rejects_repeated_devices_over_rccl():
     with pytest.raises(interface.HmpcError):
         interface.DeviceGroup(synthetic.DT_MPC, H, synthetic.F_MAX, 8, [0, 0], "rccl")
+
+
+def test_group_device_resident_records():
+    """hmpc_group_set_device_records: every member solves its slice straight from records that already live in HBM."""
+    import torch
+
+    nb = 77
+    f = synthetic.make_batch(nb, H, "standing", seed=12)
+    rec = records.pack_records(f, H)
+    ref_f, ref_s = _single(rec)
+    d_rec = torch.from_numpy(rec).cuda()
+    grp = interface.DeviceGroup(synthetic.DT_MPC, H, synthetic.F_MAX, nb, [0, 0, 0], "p2p")
+    ptrs = []
+    for i in range(grp.size):
+        lo, hi = interface.shard_bounds(nb, grp.size, i)
+        ptrs.append(d_rec.data_ptr() + lo * rec.shape[1])
+    torch.cuda.synchronize()
+    grp.set_device_records(ptrs, nb, max_reduced_vars=120, keepalive=d_rec)
+    grp.solve()
+    wrench, status = grp.gather_wrench()
+    np.testing.assert_array_equal(status, ref_s)
+    np.testing.assert_array_equal(wrench.view(np.uint32), ref_f[:, :12].view(np.uint32))
+    grp.close()
