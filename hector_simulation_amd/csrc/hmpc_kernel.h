@@ -137,6 +137,7 @@ struct Smem {
     // would put them on two bank groups only)
     alignas(16) double ST[NG][NMAX + 2];
     alignas(16) double piv[2][NMAX];
+    double pd[2];  // the pivot of the published row (its own slot in the row carries d - 1, see the sweeps)
     double u[NMAX], d[NMAX], r[NMAX], col[NMAX];
     double redv[NW], redw[NW];
     double gamma;
@@ -821,7 +822,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // Thread t < NG(NG+1)/2 owns the 6x6 block (e, e'), e <= e', of the symmetric matrix in sweep order (block-row-major).
   // Sweep k:  d = a_kk, p = row k;  a_ij -= (p_i/d) p_j  (i,j != k);  a_kj = p_j/d;  a_kk = -1/d.  After n sweeps a = -H^-1.
   // Row k / column k entries take the same fused update with a substituted multiplier (1 - 1/d for row k, d - 1 for
-  // column k: p_j - (1-1/d) p_j = p_j/d), so the 6x6 update has no special cases; only a_kk is patched.
+  // column k: p_j - (1-1/d) p_j = p_j/d), so the 6x6 update has no special cases; only a_kk is patched.  The substitution
+  // costs nothing: the published pivot row carries d - 1 in the pivot's own slot (d itself travels in Q.pd).
   // The pivot row for sweep k+1 is published to LDS right after sweep k (double buffered) -> one barrier per sweep; the six
   // sweeps of a leg-step are statically unrolled (static register indices).
   constexpr int NTILE = NG * (NG + 1) / 2;
@@ -879,6 +881,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
 #pragma unroll
     for (int jj = 0; jj < GS; ++jj)
       if (j0 + jj < n) Q.piv[0][j0 + jj] = a[0][jj];
+    if (diag) Q.piv[0][0] = a[0][0] - 1.0, Q.pd[0] = a[0][0];
   }
   __syncthreads();
   for (int kb = 0; kb < ng; ++kb) {
@@ -891,7 +894,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       const int k = kb * GS + kk;
       const double *pv = Q.piv[k & 1];
       double *pn = Q.piv[(k + 1) & 1];
-      const double d = pv[k];
+      const double d = Q.pd[k & 1];
       double pi[GS], pj[GS];
 #pragma unroll
       for (int ii = 0; ii < GS; ii += 2) {
@@ -911,8 +914,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       double qi[GS];
 #pragma unroll
       for (int ii = 0; ii < GS; ++ii) qi[ii] = pi[ii] * invd;
-      qi[kk] = rowb ? (1.0 - invd) : qi[kk];
-      pj[kk] = colb ? (d - 1.0) : pj[kk];
+      // (the published row carries d - 1 in the pivot's own slot: the threads that hold row k then find q_k = (d-1)/d = 1 - 1/d
+      //  and those that hold column k find p_k = d - 1 by themselves -- the substituted multipliers, without any select)
 #pragma unroll
       for (int ii = 0; ii < GS; ++ii)
 #pragma unroll
@@ -924,6 +927,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
 #pragma unroll
           for (int jj = 0; jj < GS; ++jj)
             if (!diag || jj >= kk + 1) pn[j0 + jj] = a[(kk + 1) % GS][jj];
+          if (diag) pn[j0 + (kk + 1) % GS] = a[(kk + 1) % GS][(kk + 1) % GS] - 1.0, Q.pd[(k + 1) & 1] = a[(kk + 1) % GS][(kk + 1) % GS];
         }
         if (colb) {
 #pragma unroll
@@ -934,6 +938,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         if (rown) {
 #pragma unroll
           for (int jj = 0; jj < GS; ++jj) pn[j0 + jj] = a[0][jj];
+          if (diag) pn[j0] = a[0][0] - 1.0, Q.pd[(k + 1) & 1] = a[0][0];
         }
         if (coln && !diag) {
 #pragma unroll
