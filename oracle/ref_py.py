@@ -43,13 +43,22 @@ def build() -> None:
 
 _lib = None
 _libc = C.CDLL(None)
+ASSOC_LIB_PATH = os.path.join(HERE, "_ref", "libsolvempc_ref_assoc.so")
+
+
+def use_variant(name: str | None) -> None:
+    """Switches this module to another build of the same reference sources: ``"assoc"`` = the sensitivity build whose
+    stand-in associates three-term sums as d0 + (d1 + d2) (oracle/Makefile); ``None`` = the default build."""
+    global _lib, LIB_PATH
+    LIB_PATH = ASSOC_LIB_PATH if name == "assoc" else os.path.join(HERE, "_ref", "libsolvempc_ref.so")
+    _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not available():
-            build()
+        if not os.path.exists(LIB_PATH):
+            subprocess.check_call(["make", "-C", HERE, "-s", LIB_PATH])
         L = C.CDLL(LIB_PATH)
         L.setup_problem.argtypes = [C.c_double, C.c_int, C.c_double, C.c_double]
         L.update_problem_data.argtypes = [C.c_void_p] * 6 + [C.c_double] + [C.c_void_p] * 4

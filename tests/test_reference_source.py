@@ -165,6 +165,38 @@ def test_forces_end_to_end_against_the_reference_source(ref, oracle):
         assert np.median(err) < bound / 5
 
 
+def test_association_sensitivity_of_the_unpinned_part(ref, oracle):
+    """What a build against the Eigen stand-in does not pin is the association inside Eigen's own small-product kernels.
+    The same reference sources compiled with the stand-in's three-term sums associated the other way
+    (d0 + (d1 + d2): every 3x3 / 1x3 product -- I_world, I_world^-1 [r]x, the foot-frame rows of F_control) bound that:
+    measured |dH| = 4.6e-7 max|H|, |dg| = 3.5e-7 max|g|, |dA| = 6e-8, same structure; forces move by up to 6.1e-4 relative on
+    the 2-contact set -- the same cond(H) sensitivity as every other last-bit change of the QP data."""
+    if not os.path.exists(ref.ASSOC_LIB_PATH) and not os.path.isdir("/root/reference"):
+        pytest.skip("sensitivity build absent")
+    nb = 48
+    f = synthetic.make_batch(nb, H, "standing", seed=6)
+    base = [ref.tick(row, H, DT, MU, FMAX, setup=(k == 0)) for k, row in _rows(f, nb)]
+    ref.use_variant("assoc")
+    try:
+        alt = [ref.tick(row, H, DT, MU, FMAX, setup=(k == 0)) for k, row in _rows(f, nb)]
+    finally:
+        ref.use_variant(None)
+    dH = dg = dA = dq = 0.0
+    changed = 0
+    for a, b in zip(base, alt):
+        np.testing.assert_array_equal(a["var_ind"], b["var_ind"])
+        np.testing.assert_array_equal(a["con_ind"], b["con_ind"])
+        assert np.array_equal(a["lb_red"], b["lb_red"]) and np.array_equal(a["ub_red"], b["ub_red"])
+        changed += int(not np.array_equal(a["H_red"], b["H_red"]))
+        dH = max(dH, np.abs(a["H_red"] - b["H_red"]).max() / np.abs(a["H_red"]).max())
+        dg = max(dg, np.abs(a["g_red"] - b["g_red"]).max() / max(1.0, np.abs(a["g_red"]).max()))
+        dA = max(dA, np.abs(a["A_red"] - b["A_red"]).max())
+        dq = max(dq, np.abs(a["q_soln"] - b["q_soln"]).max() / max(1.0, np.abs(a["q_soln"]).max()))
+    print(f"association sensitivity: H changed in {changed}/{nb}; |dH| {dH:.2e} |dg| {dg:.2e} |dA| {dA:.2e} forces {dq:.2e}")
+    assert changed > 0          # the switch does reach the arithmetic
+    assert dH < 1e-6 and dg < 1e-6 and dA < 2.4e-7 and dq < 2e-3
+
+
 def test_reference_interface_semantics_in_a_fresh_process(ref):
     """convexMPC_interface.cpp:105-110: get_solution returns 0 before the first solve; afterwards q_soln[index]."""
     code = textwrap.dedent(f"""
