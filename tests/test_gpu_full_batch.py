@@ -1,5 +1,5 @@
 """Full-batch oracle parity at BASELINE.json's sizes: EVERY instance of configs 2 and 4 and of the metric's b1024
-2-contact case, and 2 048 / 1 024 of configs 3 / 5, against the reference's own qpOASES on the oracle's (bit-identical)
+2-contact case, and one GPU's shard of configs 3 / 5 (8 192 / 2 048), against the reference's own qpOASES on the oracle's (bit-identical)
 QP data.  The oracle runs as a pool of processes over the host cores (oracle/pool.py) where one core would take more
 than a few seconds.  Bar: forces within north_star's 1e-4 relative of qpOASES, every instance reported ok."""
 import numpy as np
@@ -58,20 +58,22 @@ def test_cfg4_all_4096_horizon_20_single_support(oracle):
     _compare("cfg4", forces, status, pool.solve_records_parallel(rec, kw["horizon"], synthetic.DT_MPC, synthetic.F_MAX))
 
 
-def test_cfg3_2048_of_the_random_sweep(oracle):
+def test_cfg3_one_gpu_shard_8192_of_the_random_sweep(oracle):
+    """BASELINE config 3 is 65 536 instances over 8 GPUs: one GPU's shard, every instance."""
     from oracle import pool
 
-    kw = dict(synthetic.CONFIGS["cfg3_walk_sweep_65536"], batch=2048)
+    kw = dict(synthetic.CONFIGS["cfg3_walk_sweep_65536"], batch=8192)
     rec = records.pack_records(synthetic.make_batch(**kw), kw["horizon"])
     forces, status = _gpu(rec, kw["horizon"])
-    _compare("cfg3[:2048]", forces, status, pool.solve_records_parallel(rec, kw["horizon"], synthetic.DT_MPC, synthetic.F_MAX))
+    _compare("cfg3[:8192]", forces, status, pool.solve_records_parallel(rec, kw["horizon"], synthetic.DT_MPC, synthetic.F_MAX))
 
 
-def test_cfg5_1024_three_contact_extension(oracle):
+def test_cfg5_one_gpu_shard_2048_three_contact_extension(oracle):
+    """BASELINE config 5 is 8 192 instances over 4 GPUs: one GPU's shard, every instance."""
     from oracle import pool
 
-    kw = dict(synthetic.CONFIG5, batch=1024)
+    kw = dict(synthetic.CONFIG5, batch=2048)
     rec = records.pack_records(synthetic.make_batch3(**kw), 10, 3)
     forces, status = _gpu(rec, 10, contacts=3)
-    _compare("cfg5[:1024] (oracle extension)", forces, status,
+    _compare("cfg5[:2048] (oracle extension)", forces, status,
              pool.solve_records_parallel(rec, 10, synthetic.DT_MPC, synthetic.F_MAX, nc=3))
