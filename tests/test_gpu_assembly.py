@@ -9,7 +9,9 @@ from hector_simulation_amd import interface, records, synthetic
 pytestmark = pytest.mark.gpu
 
 CASES = [("standing", 10, 6), ("walking", 10, 2), ("mixed", 10, 11), ("single", 20, 4), ("walking", 7, 13),
-         ("standing", 3, 14)]
+         ("standing", 3, 14),
+         # the 120-variable variant (Toeplitz chains + full-block staging) at horizons below its scratch size
+         ("standing", 7, 15), ("standing", 9, 16), ("mixed", 8, 17), ("standing", 6, 18)]
 
 
 @pytest.mark.parametrize("gait,h,seed", CASES)
