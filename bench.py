@@ -6,7 +6,8 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (assembly + QP solve, one kernel launch) over one batch of synthetic MPC
-instances whose packed records already live in HBM; for N > 1 every rank owns a contiguous shard of the global batch
+instances whose packed records already live in HBM (consecutive steps alternate between two launch streams / two output
+blocks, --streams 1 for strictly serial launches); for N > 1 every rank owns a contiguous shard of the global batch
 (weak scaling, per-GPU batch fixed) and the step ends with the all_gather (RCCL) of the solved forces.
 Rank 0 prints ONE JSON line.  Workload = the case BASELINE.json's metric string names: randomized 2-contact
 (standing gait) instances, horizon 10 -> 120 x 160 QPs (SURVEY.md section 8d "metric_2contact").
@@ -175,6 +176,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip the other_configs side measurements (profiling runs: only the headline kernel launches)")
+    ap.add_argument("--streams", type=int, default=2, help="launch streams used alternately by consecutive steps (1 or 2)")
     ap.add_argument("--exchange", default="wrench", choices=["wrench", "full"],
                     help="N>1: what the ranks all_gather per solve (wrench = step-0 wrench + status, SURVEY 8e)")
     ap.add_argument("--cpu-per-core", type=int, default=384)
@@ -212,12 +214,22 @@ def main() -> None:
 
     dev = torch.device("cuda", local_rank)
     d_rec = torch.from_numpy(rec).to(dev)                      # inputs resident in HBM before the timed region
-    d_forces = torch.zeros((B, 12 * h), dtype=torch.float32, device=dev)
-    d_status = torch.zeros((B,), dtype=torch.int32, device=dev)
-    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, B, device=local_rank)
-    mpc.set_device_records(d_rec.data_ptr(), B, max_reduced_vars=n_red, keepalive=d_rec)
-    mpc.set_device_outputs(d_forces.data_ptr(), d_status.data_ptr(), keepalive=(d_forces, d_status))
-    stream = torch.cuda.current_stream().cuda_stream
+    # Two handles on two streams, each with its own output block, used alternately: the tail of one step's launch (the last,
+    # partly filled round of workgroups) and the launch gap overlap the head of the next step's.  Every step still is one
+    # complete pass of the hot path over the whole batch; --streams 1 times strictly back-to-back launches on one stream.
+    nstream = max(1, min(2, args.streams))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
+    d_forces_l = [torch.zeros((B, 12 * h), dtype=torch.float32, device=dev) for _ in range(nstream)]
+    d_status_l = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(nstream)]
+    mpcs = []
+    for k in range(nstream):
+        m = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, B, device=local_rank)
+        m.set_device_records(d_rec.data_ptr(), B, max_reduced_vars=n_red, keepalive=d_rec)
+        m.set_device_outputs(d_forces_l[k].data_ptr(), d_status_l[k].data_ptr(), keepalive=(d_forces_l[k], d_status_l[k]))
+        mpcs.append(m)
+    mpc, d_forces, d_status = mpcs[0], d_forces_l[0], d_status_l[0]
+    stream = streams[0].cuda_stream
+    torch.cuda.synchronize()
 
     # the path's only exchange: all_gather of the step-0 wrenches + status words, posted after every
     # solve on the communicator's stream so that it overlaps the next solve; --exchange full gathers all 12h forces
@@ -226,11 +238,13 @@ def main() -> None:
     nstep = [0]
 
     def step():
-        mpc.solve(stream)
-        if xch is not None:
-            xch.post(nstep[0] & 1, d_forces, d_status)
-        elif world > 1:
-            sharding.gather_forces(d_forces, world * B)
+        k = nstep[0] % nstream
+        with torch.cuda.stream(streams[k]):
+            mpcs[k].solve(streams[k].cuda_stream)
+            if xch is not None:
+                xch.post(nstep[0] & 1, d_forces_l[k], d_status_l[k])
+            elif world > 1:
+                sharding.gather_forces(d_forces_l[k], world * B)
         nstep[0] += 1
 
     for _ in range(args.warmup):
@@ -241,14 +255,11 @@ def main() -> None:
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
     for _ in range(args.steps):
         step()
     if xch is not None:
         xch.wait_all()   # every posted exchange is complete inside the timed region
-    ev1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -259,6 +270,15 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
+
+    # the same K passes strictly back to back on ONE stream (no overlap of a launch's tail with the next launch's head),
+    # reported beside the headline value
+    torch.cuda.synchronize()
+    ts0 = time.perf_counter()
+    for _ in range(args.steps):
+        mpcs[0].solve(stream)
+    torch.cuda.synchronize()
+    single_stream_s = time.perf_counter() - ts0
 
     # dominant kernel's own duration: HIP events on the launch stream, kernel launches only (no collective)
     kernel_ms = mpc.time_solve(max(5, args.steps), stream)
@@ -309,6 +329,7 @@ def main() -> None:
             "config": {"workload": f"{'2-contact standing' if args.gait == 'standing' else args.gait} randomized MPC ticks, "
                                    f"horizon {h}, reduced QP up to {n_red}x{n_red // 6 * 8}; records and forces device-resident in/out",
                        "batch_per_gpu": B, "global_batch": world * B, "horizon": h,
+                       "launch_streams": nstream,
                        "parallelism": (f"batch shards x{world}, all_gather of "
                                        f"{'step-0 wrench + status (overlapped with the next solve)' if xch is not None else 'all forces'}")
                        if world > 1 else "single GPU"},
@@ -321,6 +342,10 @@ def main() -> None:
                                  "active-set iteration inside one workgroup (LDS/VALU fp64 latency)"},
             "roofline_mfma": {"bound": "mfma", "achieved": ach_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                               "frac": ach_tf / MFMA_F32_PEAK_TF, "algorithmic_mflop_per_solve": mfl},
+            "single_stream": {"value": B * args.steps / single_stream_s, "ms_per_step": 1e3 * single_stream_s / args.steps,
+                              "note": "this rank's K passes launched back to back on one stream, no exchange; the headline value "
+                                      "alternates two streams (config.launch_streams) so that the partly filled last round of "
+                                      "workgroups of one launch overlaps the next launch"},
             "fp64_valu_frac": fp64_tf / FP64_VALU_PEAK_TF,
             "fp64_valu": {"achieved": fp64_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                           "useful_flop_per_solve": fp64_flop,
@@ -454,7 +479,8 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fields, h, args.cpu_per_core)
         print(json.dumps(out), flush=True)
-    mpc.close()
+    for m in mpcs:
+        m.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
