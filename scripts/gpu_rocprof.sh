@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/rocprof; export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 3 > gpurun_out/rocprof/bench_standing.json 2> gpurun_out/rocprof/bench.err
 python bench.py --steps 20 --warmup 3 --gait walking --no-cpu-baseline > gpurun_out/rocprof/bench_walking.json 2>> gpurun_out/rocprof/bench.err
 python bench.py --steps 10 --warmup 2 --horizon 20 --gait single --batch 4096 --no-cpu-baseline > gpurun_out/rocprof/bench_h20_single.json 2>> gpurun_out/rocprof/bench.err
-CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side-configs --check 0"
+CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side-configs --check 0 --streams 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rocprof/kt -o kt -- $CMD > gpurun_out/rocprof/kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/rocprof/pmc_fetch -o pmc -- $CMD > gpurun_out/rocprof/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/rocprof/pmc_write -o pmc -- $CMD > gpurun_out/rocprof/pmc_write.log 2>&1
