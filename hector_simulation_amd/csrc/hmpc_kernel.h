@@ -4,17 +4,21 @@
 //   update_problem_data -> solve_mpc -> qpOASES::QProblem::init
 //   (ConvexMPC/convexMPC_interface.cpp:83-103, ConvexMPC/SolverMPC.cpp:371-738, third_party/qpOASES/src/QProblem.cpp:316).
 //
+// Compiled for three waves per SIMD where the LDS footprint allows it (168 VGPRs; see HMPC_WAVES_PER_EU_* below).
 // Phases (all state lives in LDS / registers; HBM sees only the ~716 B record in and 12h floats + 1 word out):
 //   A  assembly in binary32 under the HMPC-A1 arithmetic contract (bit-identical to the CPU oracle):
 //      trig -> scalar algebra -> Acd^k, Phi_k = Acd^k Bcd -> tracking error -> swing elimination tables
 //      -> H = 2(B'SB + alpha) on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 = k-ordered fmaf chain), g.
+//      B_qp is block lower-triangular Toeplitz, so all blocks of one block-diagonal of H are prefixes of ONE chain: the
+//      120/180-variable h <= 10 variants run h chains and read a finished block off after every step (bit-identical).
 //   S  M = H^-1 in binary64 by n symmetric sweeps.  The matrix lives in REGISTERS for the rest of the kernel: the
 //      reduced variables are ordered leg-step by leg-step ([F(3), M(3)] per stance leg-step), and thread t owns the
 //      6x6 block M(e,e') between two leg-steps (e <= e'): 210 blocks for 20 leg-steps.
 //   W  block warm start: every moment / line-contact row (rows 4-6 of a leg-step's 8) violated at the unconstrained
 //      minimiser enters the working set at once.  Their Schur matrix N M N' is formed block-locally (a row touches one
-//      leg-step, so n_i' M n_j needs only the 6x6 block its owner already holds), inverted in LDS, and rows whose
-//      multiplier comes out negative are removed again -> a valid Goldfarb-Idnani state, ~20 iterations saved.
+//      leg-step, so n_i' M n_j needs only the 6x6 block its owner already holds), inverted in registers, rows of the
+//      foot-x moment window whose multiplier comes out negative are switched to their other bound, other rows with a
+//      negative multiplier are removed again -> a valid Goldfarb-Idnani state, ~20 iterations saved.
 //   Q  dual active set (Goldfarb-Idnani, range-space form) from that state: Schur inverse E = (N M N')^-1 kept
 //      explicitly (bordering / Schur-complement downdates: no triangular solves), M applied in place from the register
 //      blocks with a fixed-order staged reduction (deterministic).  One refinement step of the multipliers at the end (HMPC_REFINE).
