@@ -176,7 +176,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip the other_configs side measurements (profiling runs: only the headline kernel launches)")
-    ap.add_argument("--streams", type=int, default=2, help="launch streams used alternately by consecutive steps (1 or 2)")
+    ap.add_argument("--streams", type=int, default=2, help="launch streams used alternately by consecutive steps (1..4; 2 measured best but for +0.8 %% at 3)")
     ap.add_argument("--exchange", default="wrench", choices=["wrench", "full"],
                     help="N>1: what the ranks all_gather per solve (wrench = step-0 wrench + status, SURVEY 8e)")
     ap.add_argument("--cpu-per-core", type=int, default=384)
@@ -217,7 +217,7 @@ def main() -> None:
     # Two handles on two streams, each with its own output block, used alternately: the tail of one step's launch (the last,
     # partly filled round of workgroups) and the launch gap overlap the head of the next step's.  Every step still is one
     # complete pass of the hot path over the whole batch; --streams 1 times strictly back-to-back launches on one stream.
-    nstream = max(1, min(2, args.streams))
+    nstream = max(1, min(4, args.streams))
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
     d_forces_l = [torch.zeros((B, 12 * h), dtype=torch.float32, device=dev) for _ in range(nstream)]
     d_status_l = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(nstream)]
