@@ -33,9 +33,11 @@ def ref_solve(args):
 
 def main():
     nb, worst, nbad_gpu, total = 512, 0.0, 0, 0
-    workers = max(1, min(32, (os.cpu_count() or 2) - 1))
+    workers = max(1, min(60, (os.cpu_count() or 2) - 1))
     with ProcessPoolExecutor(workers) as pool:
-        for seed in range(100, 106):
+        s0 = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+        ns = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+        for seed in range(s0, s0 + ns):
             for gait, h in (("standing", 10), ("walking", 10), ("mixed", 10), ("single", 20)):
                 for scale in (1, 2):
                     rec = records.pack_records(hard_batch(nb, h, gait, seed, scale), h)
