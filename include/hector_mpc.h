@@ -270,7 +270,10 @@ int hmpc_group_wait_gather(hmpc_group *g);
  * the step-0 wrench + the status word.  Valid from hmpc_group_wait_gather until the next hmpc_group_post_gather. */
 int hmpc_group_device_gathered(hmpc_group *g, int member, const uint32_t **gathered, int *slot_rows);
 /* blocking form of the exchange step: posts it if hmpc_group_post_gather was not called since the last solve, waits,
- * and returns host copies in instance order: wrench [batch][12], status [batch] (either may be NULL) */
+ * and returns host copies in instance order: wrench [batch][12], status [batch] (either may be NULL).
+ * The exchange carries the fast pass's results as they are: an instance the fast variant flagged (working set full /
+ * max-iter / KKT) shows in its status word and its wrench is not valid; hmpc_group_download runs the members' safe
+ * pass (as hmpc_download does) and returns the repaired forces. */
 int hmpc_group_gather_wrench(hmpc_group *g, float *host_wrench, uint32_t *host_status);
 /* all 12h forces of every instance to the host (no collective; the members' safe pass included) */
 int hmpc_group_download(hmpc_group *g, float *forces, uint32_t *status);
