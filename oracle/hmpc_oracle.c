@@ -771,11 +771,20 @@ void orc_leg_jacobian(const double q_in[5], int leg, double J[30] /* row-major 6
   const double q2 = q_in[2] + 0.3 * 3.14159, q3 = q_in[3] - 0.6 * 3.14159, q4 = q_in[4] + 0.3 * 3.14159;
   const double side = (leg == 0) ? 1.0 : -1.0;
   double s0, c0, s1, c1, s2, c2, s23, c23, s234, c234;
-  orc_sincos(q0, &s0, &c0);
-  orc_sincos(q1, &s1, &c1);
-  orc_sincos(q2, &s2, &c2);
-  orc_sincos(q2 + q3, &s23, &c23);
-  orc_sincos(q2 + q3 + q4, &s234, &c234);
+  if (g_libm_trig) { /* study switch: libm's double sin/cos, what the reference's build calls (LegController.cpp:130-165) */
+    /* g++ -O3 turns SOME of the reference's sin(x)/cos(x) pairs into sincos(x) calls (its binary here mixes sin, cos and
+     * sincos), and glibc's sincos differs from its sin/cos in the last bit on ~0.2 % of arguments: which entry gets which is
+     * a compiler decision the reference does not pin.  Plain sin/cos is the closest single choice (measured: 7 of 60 000
+     * Jacobian entries differ from the reference build by one ulp; tests/test_caller_reference.py). */
+    s0 = sin(q0), c0 = cos(q0), s1 = sin(q1), c1 = cos(q1), s2 = sin(q2), c2 = cos(q2);
+    s23 = sin(q2 + q3), c23 = cos(q2 + q3), s234 = sin(q2 + q3 + q4), c234 = cos(q2 + q3 + q4);
+  } else {
+    orc_sincos(q0, &s0, &c0);
+    orc_sincos(q1, &s1, &c1);
+    orc_sincos(q2, &s2, &c2);
+    orc_sincos(q2 + q3, &s23, &c23);
+    orc_sincos(q2 + q3 + q4, &s234, &c234);
+  }
   const double Ls = 0.04 * s234 + 0.22 * s23 + 0.22 * s2, Lc = 0.04 * c234 + 0.22 * c23 + 0.22 * c2;
   const double Ls3 = 0.04 * s234 + 0.22 * s23, Lc3 = 0.04 * c234 + 0.22 * c23;
   const double k1 = 0.018 * side + 0.0025, k0 = 0.015 * side;

@@ -1,0 +1,7 @@
+// TEST INFRASTRUCTURE ONLY -- see ../README.md.
+#pragma once
+#include <memory>
+namespace boost {
+template <class T>
+using shared_ptr = std::shared_ptr<T>;
+}

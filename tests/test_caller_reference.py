@@ -1,0 +1,315 @@
+"""SURVEY.md section 8(f) rows f1-f3 pinned against an EXECUTION OF THE REFERENCE'S OWN CALLER-SIDE SOURCE.
+
+``oracle/_ref/libcaller_ref.so`` is ``ConvexMPC/GaitGenerator.cpp`` + ``ConvexMPC/ConvexMPCLocomotion.cpp`` +
+``src/common/LegController.cpp`` (+ ``FootSwingTrajectory.cpp``, ``DesiredCommand.cpp``) compiled unmodified from
+/root/reference against the Eigen stand-in (recipe ``oracle/Makefile``; what the shim supplies and why:
+``oracle/caller_ref_shim.cpp``).  What is asserted:
+
+f2  gait tables: ``orc_mpc_gait`` (the checker of the device builder) and ``synthetic.mpc_gait`` are IDENTICAL to
+    ``Gait::setIterations`` + ``Gait::mpc_gait`` for every offsets/durations/iteration ``synthetic.make_ticks`` uses and for
+    random ones;
+f1  the arguments the reference's ``updateMPCIfNeeded`` hands to ``update_problem_data`` -- after the reference's own
+    double->float narrowing -- are BIT FOR BIT the packed record ``orc_build_record`` produces from the same tick (up to the
+    sign of a zero commanded velocity, see ``_assert_records_equal``), and the
+    clamped ``world_position_desired`` is the same double; also through the public ``run()`` over a 50-tick sequence fed by
+    the reference's ``LegController::updateData``;
+f3  ``f_ff = -rBody [GRF; GRM]`` is the same double bit for bit; the force-moment Jacobian agrees to one unit in the last
+    place of 1.0 (measured 2.2e-16 absolute with the contract's deterministic sincos; under the libm study switch all but
+    0.03 % of the entries are bit-identical, the rest is glibc's sincos-vs-sin last bit, a compiler choice the reference
+    does not pin) and tau = J' f to 1.1e-13 absolute at |f| <= 200 N: the LowlevelCmd float the reference sends is the same
+    float in every one of 15 000 entries measured (asserted: >= 99.9 %).
+
+The golden file ``tests/golden/caller_ref_golden.npz`` (``tests/golden/make_caller_golden.py``) carries these reference
+results to boxes without /root/reference; the GPU leg checks the device kernels against it.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from hector_simulation_amd import interface, records, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "caller_ref_golden.npz")
+H = 10
+LEG_OFFSET = np.tile([0, 0, 0.3 * 3.14159, -0.6 * 3.14159, 0.3 * 3.14159], 2)  # LegController.cpp:111-113
+
+
+@pytest.fixture(scope="module")
+def caller_py():
+    from oracle import caller_py as m
+
+    if not m.available() and not os.path.isdir("/root/reference"):
+        pytest.skip("oracle/_ref/libcaller_ref.so not built and /root/reference absent")
+    m.lib()
+    return m
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def _assert_records_equal(got, want, msg=""):
+    """Packed records equal in every bit -- except that -0.0 and +0.0 compare equal in the float part: for a commanded
+    velocity of -0.0 the reference's rBody' * v_des_robot is +0.0 under the stand-in (its products start from +0) and -0.0
+    as a bare three-term sum (what the builder and real Eigen's unrolled 3-vector reduction evaluate); nothing downstream
+    can tell the two apart (the value only ever enters sums with non-zero terms)."""
+    got, want = np.atleast_2d(got), np.atleast_2d(want)
+    assert got.shape == want.shape, msg
+    nfl = 4 * (54 + 12 * H)
+    a, b = got[:, :nfl].copy().view(np.float32), want[:, :nfl].copy().view(np.float32)
+    assert not np.isnan(a).any() and np.array_equal(a, b), msg
+    diff = a.view(np.uint32) != b.view(np.uint32)
+    cols = np.nonzero(diff.any(axis=0))[0]
+    assert (a[diff] == 0).all() and all(c >= 54 and (c - 54) % 12 in (9, 10) for c in cols), msg  # only traj's v_des_world x, y
+    np.testing.assert_array_equal(got[:, nfl:], want[:, nfl:], err_msg=msg)
+
+
+def _gold_ticks(gold, name):
+    raw = gold[f"ticks/{name}/ticks"]
+    return np.ascontiguousarray(raw).view(interface.TICK_DTYPE).reshape(-1)
+
+
+# ------------------------------------------------------------------------------------------------------ f2
+def test_gait_tables_identical_to_reference_gaitgenerator(caller_py, oracle):
+    rng = np.random.default_rng(0)
+    cases = []
+    for h in (10, 20):  # what synthetic.make_ticks uses
+        cases += [(h, (0, h // 2), (h // 2, h - h // 2)), (h, (0, 0), (h, h))]
+    for _ in range(12):
+        n = int(rng.integers(4, 21))
+        cases.append((n, tuple(rng.integers(0, n, 2)), tuple(rng.integers(1, n + 1, 2))))
+    checked = 0
+    for n, off, dur in cases:
+        for ipm in (40, 5, 1):
+            for it in list(range(0, 2 * ipm * n + 3, max(1, ipm // 3))):
+                g = caller_py.gait(n, off, dur, ipm, it)
+                iteration = (it // ipm) % n  # Gait::setIterations, GaitGenerator.cpp:111
+                np.testing.assert_array_equal(oracle.mpc_gait(n, off, dur, iteration), g["table"])
+                np.testing.assert_array_equal(synthetic.mpc_gait(n, off, dur, iteration), g["table"])
+                checked += 1
+    assert checked > 3000
+    g = caller_py.gait(10, (0, 5), (5, 5), 40, 0)
+    assert (g["stance"], g["swing_segments"]) == (5, 5)
+
+
+def test_gait_golden_is_current(caller_py, gold):
+    for row, tab in zip(gold["gait/cases"], gold["gait/tables"]):
+        n, o0, o1, d0, d1, ipm, it = [int(x) for x in row]
+        np.testing.assert_array_equal(caller_py.gait(n, (o0, o1), (d0, d1), ipm, it)["table"], tab[:2 * n])
+
+
+def test_gait_golden_vs_oracle(oracle, gold):
+    """runs without /root/reference: the committed reference tables against the builder's checker"""
+    for row, tab in zip(gold["gait/cases"], gold["gait/tables"]):
+        n, o0, o1, d0, d1, ipm, it = [int(x) for x in row]
+        np.testing.assert_array_equal(oracle.mpc_gait(n, (o0, o1), (d0, d1), (it // ipm) % n), tab[:2 * n])
+
+
+# ------------------------------------------------------------------------------------------------------ f1
+def _record_from_capture(cap):
+    """update_problem_data's double->float / int->u8 narrowing (convexMPC_interface.cpp:83-103) on the captured arguments"""
+    f = {k: np.asarray(cap[k], dtype=np.float64)[None, :] for k in ("p", "v", "q", "w", "r", "joint_angles", "weights", "Alpha_K", "traj")}
+    f["yaw"] = np.array([cap["yaw"]])
+    f["gait"] = np.asarray(cap["gait"])[None, :]
+    return records.pack_records(f, H)[0]
+
+
+@pytest.mark.parametrize("gait,gait_number,flags", [("walking", 2, 0), ("standing", 1, 0), ("walking", 2, 1)])
+def test_record_builder_bitwise_vs_reference_updateMPCIfNeeded(caller_py, oracle, gait, gait_number, flags):
+    nb = 48
+    t = synthetic.make_ticks(nb, H, gait, seed=100 + gait_number + 7 * flags)
+    t["flags"] = flags
+    if flags:
+        t["leg_q"] -= LEG_OFFSET
+    want, wpd = oracle.build_records(t, H, synthetic.DT_MPC)
+    c = caller_py.Caller()
+    clamped = 0
+    for k in range(nb):
+        cap = caller_py.tick_through_reference(c, t[k], gait_number)
+        assert (cap["horizon"], cap["dt"], cap["mu"], cap["f_max"]) == (H, 0.04, 0.25, 500.0)  # ConvexMPCLocomotion.cpp:409-410
+        _assert_records_equal(_record_from_capture(cap), want[k], f"tick {k}")
+        np.testing.assert_array_equal(cap["world_position_desired"][:2].view(np.uint64), wpd[k].view(np.uint64))
+        clamped += int(np.any(cap["world_position_desired"][:2] != t["world_position_desired"][k]))
+    assert clamped > nb // 4  # the 5 cm clamp was exercised
+    assert cap["n_update"] >= nb
+    c.close()
+
+
+def test_record_golden_is_current_and_matches_oracle(caller_py, oracle, gold):
+    """the reference's OWN narrowing (update_data_t read back from libsolvempc_ref.so) == golden == orc_build_record"""
+    from tests.golden import make_caller_golden as mk
+
+    c = caller_py.Caller(backend="reference")
+    for name, kw in mk.TICK_SETS.items():
+        t = _gold_ticks(gold, name)
+        want, wpd = oracle.build_records(t, H, synthetic.DT_MPC)
+        _assert_records_equal(gold[f"ticks/{name}/records"], want)
+        np.testing.assert_array_equal(gold[f"ticks/{name}/wpd"].view(np.uint64), wpd.view(np.uint64))
+        for k in range(0, len(t), 5):
+            caller_py.tick_through_reference(c, t[k], kw["gait_number"])
+            np.testing.assert_array_equal(mk.record_from_reference_update(H), gold[f"ticks/{name}/records"][k])
+    c.close()
+
+
+def test_records_golden_vs_oracle(oracle, gold):
+    """runs without /root/reference"""
+    for name in ("walking", "standing", "walking_motor_q"):
+        t = _gold_ticks(gold, name)
+        want, wpd = oracle.build_records(t, H, synthetic.DT_MPC)
+        _assert_records_equal(gold[f"ticks/{name}/records"], want)
+        np.testing.assert_array_equal(gold[f"ticks/{name}/wpd"].view(np.uint64), wpd.view(np.uint64))
+
+
+def test_public_run_sequence_vs_builder(caller_py, oracle):
+    """FSMState_Walking::run's sequence on the reference's objects (updateData -> run -> updateCommand), 50 control ticks:
+    every MPC tick's captured arguments equal the record built from a HMPC_TICK_LEG_Q_MOTOR tick bit for bit; the torques
+    sent equal orc_leg_torques on the reference's f_ff."""
+    c = caller_py.Caller(backend="reference")
+    t0 = synthetic.make_ticks(1, H, "walking", seed=5)[0]
+    rng = np.random.default_rng(9)
+    q_motor = (t0["leg_q"] - LEG_OFFSET).astype(np.float32)  # MotorState::q is float
+    c.set_state(t0["position"], t0["vWorld"], t0["omegaWorld"], t0["orientation"], t0["rpy"], t0["rBody"])
+    c.set_command(t0["roll_des"], t0["pitch_des"], 0.3, -0.1, 0.2)
+    n_mpc = 0
+    for tick in range(50):
+        pos = t0["position"] + 1e-3 * tick * np.array([0.3, -0.1, 0.0])
+        c.set_state(pos, t0["vWorld"], t0["omegaWorld"], t0["orientation"], t0["rpy"], t0["rBody"])
+        q_motor = (q_motor + rng.uniform(-1e-3, 1e-3, 10)).astype(np.float32)
+        c.update_leg_data_from_motors(q_motor)
+        before = c.members()
+        n_before = c.capture()["n_update"]
+        c.run(2)
+        cap, m = c.capture(), c.members()
+        if cap["n_update"] == n_before:
+            assert before["iterationCounter"] % 5 != 0  # ConvexMPCLocomotion.cpp:277
+            continue
+        n_mpc += 1
+        # the tick our builder would be handed at this instant
+        tk = np.zeros(1, dtype=interface.TICK_DTYPE)
+        tk["position"], tk["vWorld"], tk["omegaWorld"] = pos, t0["vWorld"], t0["omegaWorld"]
+        tk["orientation"], tk["rpy"], tk["rBody"] = t0["orientation"], t0["rpy"], t0["rBody"]
+        tk["leg_q"], tk["flags"] = q_motor.astype(np.float64), 1
+        tk["pFoot"] = m["pFoot"].reshape(6)
+        tk["v_des_robot"], tk["yaw_rate_des"] = (0.3, -0.1), 0.2
+        tk["roll_des"], tk["pitch_des"] = t0["roll_des"], t0["pitch_des"]
+        if tick == 0:  # firstRun: world_position_desired = position (ConvexMPCLocomotion.cpp:66-68)
+            tk["world_position_desired"] = pos[:2]
+        else:          # run() integrates the set point before the MPC (:50-51): += dt * (rBody' v_des_robot)
+            rb = t0["rBody"].reshape(3, 3)
+            vdw = [(rb[0, i] * 0.3 + rb[1, i] * -0.1) + rb[2, i] * 0.0 for i in range(2)]
+            tk["world_position_desired"] = [before["world_position_desired"][i] + 0.001 * vdw[i] for i in range(2)]
+        tk["gait_offsets"], tk["gait_durations"] = (0, 5), (5, 5)
+        tk["gait_iteration"] = (before["iterationCounter"] // 40) % 10
+        want, wpd = oracle.build_records(tk, H, synthetic.DT_MPC)
+        _assert_records_equal(_record_from_capture(cap), want[0], f"control tick {tick}")
+        np.testing.assert_array_equal(m["world_position_desired"][:2].view(np.uint64), wpd[0].view(np.uint64))
+        # f3 on the reference's own solution
+        sol = np.array([caller_py.ref_py.lib().get_solution(i) for i in range(12)])
+        f = oracle.body_wrench(np.concatenate([sol, np.zeros(108)])[None, :], t0["rBody"][None, :])[0]
+        np.testing.assert_array_equal(f.view(np.uint64), m["f_ff"].view(np.uint64))
+        tau = c.update_command(m["f_ff"])
+        want_tau = oracle.leg_torques(m["f_ff"].reshape(1, 12), q_motor.astype(np.float64)[None, :])[0].reshape(-1)
+        np.testing.assert_allclose(tau, want_tau, rtol=0, atol=1e-5 * max(1.0, np.abs(want_tau).max()))
+    assert n_mpc == 10
+    c.close()
+
+
+# ------------------------------------------------------------------------------------------------------ f3
+def test_body_wrench_bitwise_vs_reference(caller_py, oracle, gold):
+    c = caller_py.Caller()
+    t = synthetic.make_ticks(32, H, "standing", seed=41)
+    rng = np.random.default_rng(2)
+    for k in range(32):
+        sol = rng.normal(size=120) * 50
+        c.set_solution(sol)
+        cap = caller_py.tick_through_reference(c, t[k], 1)
+        want = oracle.body_wrench(sol[None, :], t["rBody"][k:k + 1])[0]
+        np.testing.assert_array_equal(cap["f_ff"].view(np.uint64), want.view(np.uint64))
+    c.close()
+    want = oracle.body_wrench(gold["wrench/forces"].astype(np.float64), gold["wrench/rBody"])
+    np.testing.assert_array_equal(gold["wrench/f_ff"].view(np.uint64), want.view(np.uint64))
+
+
+def _jacobian_stats(caller_py, oracle, n, seed):
+    c = caller_py.Caller()
+    rng = np.random.default_rng(seed)
+    dJ, nz, tot, dtau, n32, tot32 = 0.0, 0, 0, 0.0, 0, 0
+    for _ in range(n):
+        qm = rng.uniform(-0.8, 0.8, 10)
+        f = rng.uniform(-200, 200, 12)
+        c.set_leg_q(qm)
+        for leg in (0, 1):
+            L = c.leg(leg)
+            np.testing.assert_array_equal(L["q"], (qm + LEG_OFFSET)[5 * leg:5 * leg + 5])  # the in-place offset, SURVEY A.9(1)
+            d = np.abs(L["J_force_moment"] - oracle.leg_jacobian(qm[5 * leg:5 * leg + 5], leg))
+            dJ, nz, tot = max(dJ, d.max()), nz + int((d > 0).sum()), tot + d.size
+        want = oracle.leg_torques(f.reshape(1, 12), qm[None, :])[0].reshape(-1)
+        dtau = max(dtau, np.abs(c.leg_tau_f64(f) - want).max())
+        t32 = c.update_command(f)
+        n32, tot32 = n32 + int((t32 != want.astype(np.float32)).sum()), tot32 + 10
+    c.close()
+    return dJ, nz / tot, dtau, n32 / tot32
+
+
+def test_leg_jacobian_and_torques_vs_reference(caller_py, oracle):
+    dJ, frac, dtau, frac32 = _jacobian_stats(caller_py, oracle, 1500, 3)
+    # default contract (deterministic binary64 sincos, csrc/hmpc_math.h == oracle); measured: |dJ| 2.2e-16 (one ulp of 1.0),
+    # 8.9 % of the entries differ at all, |dtau| 1.1e-13 at |f| <= 200 N, the float sent to the motors identical everywhere
+    assert dJ <= 4.5e-16 and frac < 0.15, (dJ, frac)
+    assert dtau <= 2.5e-13 and frac32 <= 1e-3, (dtau, frac32)
+    oracle.lib().orc_set_libm_trig(1)
+    try:
+        dJ, frac, dtau, frac32 = _jacobian_stats(caller_py, oracle, 1500, 3)
+    finally:
+        oracle.lib().orc_set_libm_trig(0)
+    # libm sin/cos as the reference's text calls them: bit-identical but for the sincos-vs-sin last bit
+    # (measured: 2.9e-4 of the entries, 1.1e-16; |dtau| 1.4e-14)
+    assert dJ <= 2.3e-16 and frac < 1e-3, (dJ, frac)
+    assert dtau <= 3e-14 and frac32 <= 1e-3, (dtau, frac32)
+
+
+def test_leg_golden_vs_oracle(oracle, gold):
+    """runs without /root/reference: the reference's Jacobians and torques against the device kernels' checker"""
+    qm, J = gold["legs/q_motor"], gold["legs/J_force_moment"]
+    for k in range(len(qm)):
+        for leg in (0, 1):
+            assert np.abs(J[k, leg] - oracle.leg_jacobian(qm[k, 5 * leg:5 * leg + 5], leg)).max() <= 4.5e-16
+    want = oracle.leg_torques(gold["wrench/f_ff"].reshape(-1, 12), qm).reshape(-1, 10)
+    assert np.abs(want - gold["legs/tau_f64"]).max() <= 2.5e-13
+    assert (want.astype(np.float32) != gold["legs/tau_f32"]).mean() <= 1e-2
+
+
+# ------------------------------------------------------------------------------------------------------ GPU leg
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["walking", "standing", "walking_motor_q"])
+def test_device_builder_bitwise_vs_reference_golden(gold, name):
+    t = _gold_ticks(gold, name)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, len(t))
+    wpd = mpc.build_records(t, synthetic.DT_MPC)
+    _assert_records_equal(mpc.download_records(), gold[f"ticks/{name}/records"])
+    np.testing.assert_array_equal(wpd.view(np.uint64), gold[f"ticks/{name}/wpd"].view(np.uint64))
+    mpc.close()
+
+
+@pytest.mark.gpu
+def test_device_wrench_and_torques_vs_reference_golden(gold):
+    import torch
+
+    forces = gold["wrench/forces"]
+    nb = forces.shape[0]
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb)
+    mpc.upload(records.pack_records(synthetic.make_batch(nb, H, "standing", seed=1), H))  # makes nb the current batch
+    d_forces = torch.from_numpy(forces.copy()).cuda()          # "the last solve's forces" := the golden get_solution answers
+    d_status = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    mpc.set_device_outputs(d_forces.data_ptr(), d_status.data_ptr(), keepalive=(d_forces, d_status))
+    f = mpc.body_wrench(gold["wrench/rBody"])
+    np.testing.assert_array_equal(f.view(np.uint64), gold["wrench/f_ff"].view(np.uint64))
+    f2, tau = mpc.leg_torques(gold["wrench/rBody"], gold["legs/q_motor"])
+    np.testing.assert_array_equal(f2.view(np.uint64), gold["wrench/f_ff"].view(np.uint64))
+    tau = tau.reshape(nb, 10)
+    assert np.abs(tau - gold["legs/tau_f64"]).max() <= 2.5e-13
+    assert (tau.astype(np.float32) != gold["legs/tau_f32"]).mean() <= 1e-2
+    mpc.close()
