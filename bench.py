@@ -49,11 +49,18 @@ def cpu_worker(path: str, horizon: int, first: int, count: int, kind: str = "ref
         from oracle import ref_py
 
         ref_py.lib()
-        ref_py.silence_forever()
+        # the reference reports a failed solve only by printing "failed to solve!" (SolverMPC.cpp:714-715): its stdout goes
+        # to a scratch file whose matching lines are counted afterwards (the prints stay part of the timed work)
+        log = path + f".stdout.{first}"
+        ref_py.silence_forever(log)
         t0 = time.perf_counter()
         q = ref_py.solve_fields(f, horizon, synthetic.DT_MPC, 0.25, synthetic.F_MAX, first=first, count=count)
         t1 = time.perf_counter()
-        os.write(2, (json.dumps(dict(count=count, wall=t1 - t0, n_bad=int(np.isnan(q).any(axis=1).sum()))) + "\n").encode())
+        ref_py.flush_stdio()
+        with open(log, "rb") as fh:
+            n_failed_lines = fh.read().count(b"failed to solve!")
+        os.write(2, (json.dumps(dict(count=count, wall=t1 - t0,
+                                     n_bad=int(n_failed_lines + np.isnan(q).any(axis=1).sum()))) + "\n").encode())
         return
     from oracle import oracle_py
 
@@ -179,6 +186,9 @@ def main() -> None:
     ap.add_argument("--streams", type=int, default=2, help="launch streams used alternately by consecutive steps (1..4; 2 measured best but for +0.8 %% at 3)")
     ap.add_argument("--exchange", default="wrench", choices=["wrench", "full"],
                     help="N>1: what the ranks all_gather per solve (wrench = step-0 wrench + status, SURVEY 8e)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the N>1 code path (process group, posted all_gather per solve, stream ordering) with whatever "
+                         "WORLD_SIZE is -- also 1: what the one-GPU test of the torchrun path uses")
     ap.add_argument("--cpu-per-core", type=int, default=384)
     ap.add_argument("--path", default="solve", choices=["solve", "builder"],
                     help="solve = the metric (default); builder = rows f1-f3 only (record builder + wrench kernels)")
@@ -196,8 +206,11 @@ def main() -> None:
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the solve path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world
     if args.gpus != world and rank == 0 and world > 1:
@@ -218,6 +231,8 @@ def main() -> None:
     # partly filled round of workgroups) and the launch gap overlap the head of the next step's.  Every step still is one
     # complete pass of the hot path over the whole batch; --streams 1 times strictly back-to-back launches on one stream.
     nstream = max(1, min(4, args.streams))
+    if world > 1 or args.force_exchange:
+        nstream = min(nstream, 2)  # the posted exchange is double buffered: one slot per launch stream
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
     d_forces_l = [torch.zeros((B, 12 * h), dtype=torch.float32, device=dev) for _ in range(nstream)]
     d_status_l = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(nstream)]
@@ -234,7 +249,8 @@ def main() -> None:
     # the path's only exchange: all_gather of the step-0 wrenches + status words, posted after every
     # solve on the communicator's stream so that it overlaps the next solve; --exchange full gathers all 12h forces
     # synchronously instead
-    xch = sharding.WrenchExchange(B, 12, dev) if (world > 1 and args.exchange == "wrench") else None
+    xch = sharding.WrenchExchange(B, 12, dev, always_collective=args.force_exchange) \
+        if ((world > 1 or args.force_exchange) and args.exchange == "wrench") else None
     nstep = [0]
 
     def step():
@@ -242,7 +258,7 @@ def main() -> None:
         with torch.cuda.stream(streams[k]):
             mpcs[k].solve(streams[k].cuda_stream)
             if xch is not None:
-                xch.post(nstep[0] & 1, d_forces_l[k], d_status_l[k])
+                xch.post(k, d_forces_l[k], d_status_l[k])  # slot = launch stream: never reused while that stream's step owns it
             elif world > 1:
                 sharding.gather_forces(d_forces_l[k], world * B)
         nstep[0] += 1
@@ -271,6 +287,12 @@ def main() -> None:
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
 
+    exchange_check = None
+    if xch is not None:  # what the last posted exchange delivered == this rank's own slice of the last step's outputs
+        klast = (nstep[0] - 1) % nstream
+        gw, gs = xch.result(klast)
+        mine = slice(rank * B, (rank + 1) * B)
+        exchange_check = bool(torch.equal(gw[mine], d_forces_l[klast][:, :12]) and torch.equal(gs[mine], d_status_l[klast].view(torch.int32)))
     # the same K passes strictly back to back on ONE stream (no overlap of a launch's tail with the next launch's head),
     # reported beside the headline value
     torch.cuda.synchronize()
@@ -332,7 +354,8 @@ def main() -> None:
                        "launch_streams": nstream,
                        "parallelism": (f"batch shards x{world}, all_gather of "
                                        f"{'step-0 wrench + status (overlapped with the next solve)' if xch is not None else 'all forces'}")
-                       if world > 1 else "single GPU"},
+                       if world > 1 else ("single GPU" + (", exchange code path forced on (group of one)" if xch is not None else "")),
+                       **({"exchange_selfcheck_ok": exchange_check} if exchange_check is not None else {})},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "pmc_counters": counters,
@@ -474,14 +497,43 @@ def main() -> None:
             f = d_forces[:nchk].cpu().numpy().astype(np.float64)
             q = ref["q_soln"]
             err = np.abs(f - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+            # objective and KKT quantities (SolverMPC.cpp:699-712 -> qpOASES getObjVal): the kernel's own
+            # binary64 solution and objective against qpOASES on the oracle's (bit-identical) reduced QP
+            x64, obj64 = mpc.download_f64()
+            gap = np.abs(obj64[:nchk] - ref["obj"]) / np.maximum(1.0, np.abs(ref["obj"]))
+            nk = min(nchk, 32)
+            sub = viol = stat = 0.0
+            for k in range(nk):
+                o = oracle_py.assemble_record(rec[k], h, synthetic.DT_MPC, synthetic.F_MAX)
+                x = x64[k][o["var_ind"]]
+                Hk, gk, Ak = o["H_red"], o["g_red"], o["A_red"]
+                den = max(1.0, abs(ref["obj"][k]))
+                sub = max(sub, (0.5 * x @ Hk @ x + gk @ x - ref["obj"][k]) / den)
+                ax = Ak @ x
+                scale = max(1.0, np.abs(x).max())
+                viol = max(viol, max(0.0, (o["lb_red"] - ax).max(), (ax - o["ub_red"]).max()) / scale)
+                act = (np.abs(ax - o["lb_red"]) <= 1e-7 * scale) | (np.abs(ax - o["ub_red"]) <= 1e-7 * scale)
+                grad = Hk @ x + gk  # stationarity: grad in the span of the active rows (least-squares multipliers)
+                if act.any():
+                    lam = np.linalg.lstsq(Ak[act].T, grad, rcond=None)[0]
+                    grad = grad - Ak[act].T @ lam
+                stat = max(stat, np.abs(grad).max() / max(1.0, np.abs(gk).max()))
             out["parity"] = {"checked": nchk, "max_rel_force_err_vs_qpoases": float(err.max()),
-                             "qpoases_failed": int(ref["n_bad"])}
+                             "max_rel_objective_gap": float(gap.max()),
+                             "kkt": {"checked": nk, "max_rel_suboptimality": float(sub), "max_rel_row_violation": float(viol),
+                                     "max_rel_stationarity_residual": float(stat),
+                                     "note": "binary64 solution of the kernel on the oracle's reduced QP (bit-identical QP data); "
+                                             "stationarity = |Hx + g - A_act' lambda|_inf / max(1, |g|_inf), least-squares lambda"},
+                             "qpoases_failed": int(ref["n_bad"]),
+                             "vs_reference_source": "end to end against the reference's own source the forces differ by the "
+                                                    "cond(H) sensitivity to binary32 round-off of the QP data (<= 5.5e-4, median "
+                                                    "8e-5; objective <= 2.4e-6): tests/test_reference_source.py"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fields, h, args.cpu_per_core)
         print(json.dumps(out), flush=True)
     for m in mpcs:
         m.close()
-    if world > 1:
+    if world > 1 or args.force_exchange:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -48,7 +48,7 @@ class WrenchExchange:
     stream (nccl) / the host (gloo) after it.  Equal shards only (the bench's weak-scaling layout); ragged batches use
     ``gather_forces``."""
 
-    def __init__(self, shard: int, width: int, device, depth: int = 2, group=None):
+    def __init__(self, shard: int, width: int, device, depth: int = 2, group=None, always_collective: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -58,6 +58,9 @@ class WrenchExchange:
         self.local = [torch.zeros((shard, width + 1), dtype=torch.float32, device=device) for _ in range(depth)]
         self.out = [torch.zeros((self.world * shard, width + 1), dtype=torch.float32, device=device) for _ in range(depth)]
         self.work = [None] * depth
+        # a group of one normally short-cuts to a copy; always_collective issues the all_gather anyway (bench.py
+        # --force-exchange: the torchrun code path -- communicator stream, async work handles -- on a one-GPU box)
+        self.always_collective = bool(always_collective) and dist.is_available() and dist.is_initialized()
 
     def post(self, slot: int, forces, status):
         """forces [shard, >= width] float32 and status [shard] int32 of this rank, both on ``device``."""
@@ -67,7 +70,7 @@ class WrenchExchange:
         loc = self.local[slot]
         loc[:, : self.width].copy_(forces[:, : self.width])
         loc.view(torch.int32)[:, self.width].copy_(status.view(torch.int32))
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             self.out[slot].copy_(loc)
             return
         self.work[slot] = self.dist.all_gather_into_tensor(self.out[slot], loc, group=self.group, async_op=True)

@@ -91,12 +91,17 @@ def quiet():
         os.close(saved)
 
 
-def silence_forever() -> None:
-    """For worker processes that only ever time the reference: stdout of this process goes to /dev/null."""
+def silence_forever(path: str | None = None) -> None:
+    """For worker processes that only ever time the reference: stdout of this process goes to /dev/null (or to `path`,
+    so that the reference's "failed to solve!" lines, SolverMPC.cpp:714-715, can be counted afterwards)."""
     _libc.fflush(None)
-    null = os.open(os.devnull, os.O_WRONLY)
+    null = os.open(path or os.devnull, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
     os.dup2(null, 1)
     os.close(null)
+
+
+def flush_stdio() -> None:
+    _libc.fflush(None)
 
 
 def setup_problem(dt: float, horizon: int, mu: float, f_max: float) -> None:

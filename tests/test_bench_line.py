@@ -48,5 +48,28 @@ def test_bench_line_contract():
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0
     assert abs(d["value"] - 2048 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6  # value = units / timed seconds
     assert d["parity"]["max_rel_force_err_vs_qpoases"] < 1e-4 and d["solver"]["failed"] == 0
+    assert d["parity"]["max_rel_objective_gap"] < 1e-4 and d["parity"]["kkt"]["max_rel_row_violation"] < 1e-6
+    assert abs(d["parity"]["kkt"]["max_rel_suboptimality"]) < 1e-6 and d["parity"]["kkt"]["max_rel_stationarity_residual"] < 1e-6
     for k in ("fp64_valu_frac", "iterations_per_solve", "single_stream"):
         assert k in d, k
+
+
+@pytest.mark.gpu
+def test_bench_torchrun_code_path_on_one_gpu():
+    """The N>1 code path of bench.py -- process group over RCCL, one posted all_gather of the step-0 wrench + status per
+    solve on the communicator's stream, double-buffered against the two launch streams -- launched exactly as the driver
+    launches it (torch.distributed.run), with a group of one and the collective forced on, so that it executes on hardware
+    in the GPU test run although no multi-GPU box is available to this build."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1",
+                        "--steps", "6", "--warmup", "2", "--batch", "1024", "--no-side-configs", "--check", "8",
+                        "--no-cpu-baseline", "--force-exchange"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["config"]["exchange_selfcheck_ok"] is True
+    assert "exchange code path forced on" in d["config"]["parallelism"]
+    assert d["solver"]["failed"] == 0 and d["parity"]["max_rel_force_err_vs_qpoases"] < 1e-4
+    assert d["parity"]["max_rel_objective_gap"] < 1e-4

@@ -148,21 +148,73 @@ def test_default_contract_within_binary32_roundoff_of_reference_source(ref, orac
         assert np.all(np.abs(x0r - x0o) <= np.spacing(np.abs(x0r).astype(np.float32)))
 
 
-def test_forces_end_to_end_against_the_reference_source(ref, oracle):
+def _end_to_end(ref, f, nb, x_of, obj_of=None):
+    """Per instance k of the field dict f: the reference's own tick (ref.tick -> its H_red, g_red, A_red, bounds, q_soln)
+    against a candidate full solution x_of(k) [12 h].  Returns arrays:
+      err    max |x - q_ref| / max(1, |q_ref|_inf)                            (the force error)
+      gap    |obj_own - obj_ref| / max(1, |obj_ref|) with obj_ref = 1/2 q'H q + g'q on the REFERENCE's reduced QP at the
+             REFERENCE's solution (what qpOASES' getObjVal returns, SolverMPC.cpp:699-712) and obj_own = obj_of(k), the
+             candidate's own objective on its own QP data
+      sub    (obj_ref(x) - obj_ref(q_ref)) / max(1, |obj_ref|): suboptimality of the candidate IN THE REFERENCE'S QP
+      viol   worst violation of the reference's constraint rows by the candidate / max(1, |q_ref|_inf)"""
+    err, gap, sub, viol = [], [], [], []
+    for k, row in _rows(f, nb):
+        r = ref.tick(row, H, DT, MU, FMAX, setup=(k == 0))
+        vi, q = r["var_ind"], r["q_soln"]
+        x = np.asarray(x_of(k), dtype=np.float64)
+        Hr, gr = r["H_red"], r["g_red"]
+        obj = lambda z: 0.5 * z @ Hr @ z + gr @ z
+        o_ref = obj(q[vi])
+        den = max(1.0, abs(o_ref))
+        scale = max(1.0, np.abs(q).max())
+        err.append(np.abs(x - q).max() / scale)
+        assert not np.delete(x, vi).any()  # eliminated variables are exact zeros on both sides (SolverMPC.cpp:723-726)
+        if obj_of is not None:
+            gap.append(abs(obj_of(k) - o_ref) / den)
+        sub.append((obj(x[vi]) - o_ref) / den)
+        ax = r["A_red"] @ x[vi]
+        viol.append(max(0.0, (r["lb_red"] - ax).max(), (ax - r["ub_red"]).max()) / scale)
+    return np.array(err), np.array(gap), np.array(sub), np.array(viol)
+
+
+# end-to-end bounds = ~2x the maxima measured over all 1 024 instances of the metric's 2-contact case / BASELINE config 2
+# and the 96-instance sets below (3.5e-4 .. 5.5e-4 / 4.7e-5; 29-39 % / 0 % of the instances above 1e-4)
+E2E_FORCE = {"standing": (1.1e-3, 2e-4, 0.6), "walking": (1.2e-4, 2e-5, 0.01)}  # max, median, fraction above 1e-4
+E2E_OBJ_GAP = 1e-4      # north_star's tolerance; measured <= 2.4e-6
+E2E_SUBOPT = 5e-8       # measured <= 5e-9 (and >= -1.1e-8: the reference's own q is qpOASES-accurate, not exact)
+E2E_VIOLATION = 1e-7    # measured <= 1.3e-8
+
+
+def _assert_end_to_end(gait, err, gap, sub, viol):
+    mx, med, frac = E2E_FORCE[gait]
+    assert err.max() < mx and np.median(err) < med and (err > 1e-4).mean() <= frac, (gait, err.max(), np.median(err), (err > 1e-4).mean())
+    if len(gap):
+        assert gap.max() <= E2E_OBJ_GAP, (gait, gap.max())
+    assert sub.max() <= E2E_SUBOPT and sub.min() >= -E2E_SUBOPT, (gait, sub.max(), sub.min())
+    assert viol.max() <= E2E_VIOLATION, (gait, viol.max())
+
+
+def test_forces_and_objective_end_to_end_against_the_reference_source(ref, oracle):
     """update_problem_data -> get_solution on the reference's own code vs the oracle (restated assembly + the same
-    qpOASES).  The two QPs differ by binary32 round-off (previous test) and cond(H) ~ 2.4e6 turns that into up to a few
-    1e-4 in the forces (measured: 3.3e-4 max / 8e-5 median standing, 6e-5 max walking) -- with the study switches on,
-    where only the lower triangle of H differs (by 2e-8), still 1.4e-4.  That is the sensitivity DESIGN.md section 3
-    documents; north_star's 1e-4 is therefore asserted on bit-identical QP data (tests/test_gpu_solve.py)."""
+    qpOASES), END TO END.  The two QPs differ by binary32 round-off (previous test) and cond(H) ~ 2.4e6 turns that into up to
+    a few 1e-4 in the FORCES (measured 5.5e-4 max / 9e-5 median standing, 4.7e-5 max walking -- with the study switches on,
+    where only the lower triangle of H differs (by 2e-8), still 1.4e-4): north_star's 1e-4 on forces is therefore asserted
+    on bit-identical QP data (tests/test_gpu_solve.py).  The OBJECTIVE is robust and is asserted here against the
+    reference's own: |obj - obj_ref| <= 1e-4 relative (measured 2.4e-6), and the candidate forces are a feasible,
+    5e-9-suboptimal point of the REFERENCE'S OWN QP (H_red, g_red, A_red, bounds as its source left them)."""
     nb = 96
-    for gait, bound in (("standing", 1.5e-3), ("walking", 5e-4)):
+    for gait in ("standing", "walking"):
         f = synthetic.make_batch(nb, H, gait, seed=6, phase="random")
         rec = records.pack_records(f, H)
-        qr = ref.solve_fields(f, H, DT, MU, FMAX)
-        qo = oracle.solve_records(rec, H, DT, FMAX)["q_soln"]
-        err = np.abs(qo - qr).max(axis=1) / np.maximum(1.0, np.abs(qr).max(axis=1))
-        assert err.max() < bound, (gait, err.max())
-        assert np.median(err) < bound / 5
+        sol = oracle.solve_records(rec, H, DT, FMAX)
+        qo = sol["q_soln"]
+
+        def own_objective(k):
+            o = oracle.assemble_record(rec[k], H, DT, FMAX)
+            x = qo[k][o["var_ind"]]
+            return 0.5 * x @ o["H_red"] @ x + o["g_red"] @ x
+
+        _assert_end_to_end(gait, *_end_to_end(ref, f, nb, lambda k: qo[k], own_objective))
 
 
 def test_association_sensitivity_of_the_unpinned_part(ref, oracle):
@@ -289,7 +341,7 @@ def test_hip_against_reference_source_goldens(gold):
             _biteq(d["ub"][: 16 * H][gold[p + "con_ind"]], gold[p + "ub_red"], "ub")
             q = gold[p + "q_soln"]
             err = np.abs(forces[k] - q).max() / max(1.0, np.abs(q).max())
-            assert err < 1.5e-3, (name, k, err)
+            assert err < (E2E_FORCE["standing"][0] if d["n"] > 60 else 2.5 * E2E_FORCE["walking"][0]), (name, k, err)
         mpc.close()
 
 
@@ -297,7 +349,10 @@ def test_hip_against_reference_source_goldens(gold):
 @pytest.mark.parametrize("cfg", ["cfg2_walk_1024", "metric_2contact_1024"])
 def test_hip_full_batch_against_the_reference_source(cfg):
     """ALL 1 024 instances of BASELINE config 2 and of the metric's 2-contact case: the HIP path end to end against the
-    reference's own update_problem_data/get_solution (the prebuilt oracle/_ref library travels to the GPU box)."""
+    reference's own update_problem_data/get_solution (the prebuilt oracle/_ref library travels to the GPU box): force
+    error within ~2x the measured cond(H) sensitivity, OBJECTIVE within north_star's 1e-4 of the reference's own
+    (0.5 q'H q + g'q on its H_red/g_red/q_red = qpOASES' getObjVal), and the HIP forces feasible and 5e-8-suboptimal in the
+    REFERENCE'S OWN QP."""
     from oracle import ref_py
 
     if not ref_py.available():
@@ -310,10 +365,14 @@ def test_hip_full_batch_against_the_reference_source(cfg):
     mpc.upload(rec)
     mpc.solve()
     forces, status = mpc.download()
+    x64, obj64 = mpc.download_f64()
     mpc.close()
     assert (interface.status_code(status) == 0).all()
-    qr = ref_py.solve_fields(f, H, DT, MU, FMAX)
-    err = np.abs(forces - qr).max(axis=1) / np.maximum(1.0, np.abs(qr).max(axis=1))
-    print(f"{cfg}: force error vs the reference's own source: max {err.max():.2e}, median {np.median(err):.2e}")
-    assert err.max() < (1.5e-3 if "2contact" in cfg else 5e-4)
-    assert np.median(err) < 2e-4
+    gait = "standing" if "2contact" in cfg else "walking"
+    err, gap, sub, viol = _end_to_end(ref_py, f, nb, lambda k: x64[k], lambda k: obj64[k])
+    err32 = np.array([np.abs(forces[k] - x64[k]).max() for k in range(nb)])
+    assert err32.max() <= 6e-8 * max(1.0, np.abs(x64).max()) * 2  # the float32 outputs are the rounded binary64 solution
+    print(f"{cfg}: vs the reference's own source: force err max {err.max():.2e} median {np.median(err):.2e} "
+          f">1e-4: {(err > 1e-4).mean():.3f}; objective gap max {gap.max():.2e}; suboptimality in its QP max {sub.max():.2e}; "
+          f"row violation max {viol.max():.2e}")
+    _assert_end_to_end(gait, err, gap, sub, viol)
