@@ -45,7 +45,7 @@ struct Variant {
 
 // NMAX = reduced variables held on chip (6 per stance leg-step); 120 -> 256-thread workgroups (210 register blocks),
 // 60 (single support over h <= 10) -> 128-thread workgroups (55 blocks).  QCAP = working-set capacity: the fast variants
-// hold 64 rows at h <= 10 (49 KB LDS, 168 VGPRs: three workgroups per CU) and 80 at h = 20 (two per CU); the "safe"
+// hold 64 rows (49-50 KB LDS, 168 VGPRs: three workgroups per CU, also at h = 20); the "safe"
 // variants hold NMAX rows (can never overflow)
 // and re-solve the few instances the fast pass flags (hmpc_resolve_failed).
 // The extension with a third (hand) contact -- BASELINE config 5, 180 variables x 240 rows at h = 10 -- runs 512-thread
@@ -107,7 +107,12 @@ struct hmpc_handle {
   // skips the status scan of the safe pass when nothing new was flagged
   unsigned int *d_flagged;
   unsigned int flagged_seen;
+  // device-side safe pass (hmpc_set_device_repair): list of the instances the last fast launch flagged + its counter
+  int device_repair;
+  int *d_flag_list;
+  unsigned int *d_flag_count;
 };
+constexpr int REPAIR_GRID_CAP = 2048;  // workgroups of the device-side safe launch = most instances it can repair per solve
 
 // returns a device buffer of at least `bytes` owned by the handle (contents undefined)
 static int scratch(hmpc_handle *h, size_t bytes, void **out) {
@@ -157,7 +162,8 @@ static const Variant &pick_variant(const hmpc_handle *h, int *index) {
 // warm: -1 = the handle's setting, 0/1 = override for this launch (the safe pass starts cold without touching the handle);
 // carry_wset = false keeps a repeated launch of the same batch from consuming/advancing the tick-to-tick working sets
 static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int dbg_index, const int *d_index_list = nullptr,
-                  int n_list = 0, double relax = 0.0, int warm = -1, bool carry_wset = true) {
+                  int n_list = 0, double relax = 0.0, int warm = -1, bool carry_wset = true,
+                  const unsigned int *d_list_count = nullptr, bool record_flagged = false) {
   int vi = 0;
   const Variant *pv = &pick_variant(h, &vi);
   if (d_index_list) {  // safe variant: working set as large as the variable count
@@ -192,6 +198,10 @@ static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int db
   a.flagged = h->d_flagged;
   a.wset_shift = h->tick_shift;
   a.relax = relax;
+  a.flag_list = record_flagged ? h->d_flag_list : nullptr;
+  a.flag_count = record_flagged ? h->d_flag_count : nullptr;
+  a.flag_cap = record_flagged ? (h->max_batch < REPAIR_GRID_CAP ? h->max_batch : REPAIR_GRID_CAP) : 0;
+  a.list_count = d_list_count;
   const int grid = assemble_only ? 1 : (d_index_list ? n_list : h->batch);
   if (grid < 1) return HMPC_OK;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(v.nt), v.smem, stream, a);
@@ -314,6 +324,8 @@ int hmpc_destroy(hmpc_handle *h) {
   if (h->d_wset) hipFree(h->d_wset);
   if (h->d_scratch) hipFree(h->d_scratch);
   if (h->d_flagged) hipFree(h->d_flagged);
+  if (h->d_flag_list) hipFree(h->d_flag_list);
+  if (h->d_flag_count) hipFree(h->d_flag_count);
   delete h;
   return HMPC_OK;
 }
@@ -429,7 +441,28 @@ int hmpc_solve(hmpc_handle *h, void *stream) {
   if (h->batch == 0) return HMPC_OK;
   HIP_TRY(hipSetDevice(h->device));
   h->last_stream = (hipStream_t)stream;
-  return launch(h, (hipStream_t)stream, false, 0);
+  if (!h->device_repair) return launch(h, (hipStream_t)stream, false, 0);
+  // fast launch that lists what it flags, then the safe variant over that list -- sized on the host for the worst case
+  // it accepts, trimmed on the device by the counter (workgroups beyond it leave at once): no host round trip
+  HIP_TRY(hipMemsetAsync(h->d_flag_count, 0, sizeof(unsigned int), (hipStream_t)stream));
+  int rc = launch(h, (hipStream_t)stream, false, 0, nullptr, 0, 0.0, -1, true, nullptr, /*record_flagged=*/true);
+  if (rc != HMPC_OK) return rc;
+  const int cap = h->batch < REPAIR_GRID_CAP ? h->batch : REPAIR_GRID_CAP;
+  return launch(h, (hipStream_t)stream, false, 0, h->d_flag_list, cap, 0.0, /*warm=*/0, true, h->d_flag_count);
+}
+
+int hmpc_set_device_repair(hmpc_handle *h, int on) {
+  if (!h) return HMPC_E_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  if (on && !h->d_flag_list) {
+    const int cap = h->max_batch < REPAIR_GRID_CAP ? h->max_batch : REPAIR_GRID_CAP;
+    HIP_TRY(hipMalloc(&h->d_flag_list, (size_t)cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->d_flag_count, sizeof(unsigned int)));
+    HIP_TRY(hipMemset(h->d_flag_list, 0, (size_t)cap * sizeof(int)));
+    HIP_TRY(hipMemset(h->d_flag_count, 0, sizeof(unsigned int)));
+  }
+  h->device_repair = on ? 1 : 0;
+  return HMPC_OK;
 }
 
 int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {

@@ -42,6 +42,8 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int *) = nullptr;
+  int version = 0;
   std::string err;
   bool load() {
     if (dl) return true;
@@ -66,7 +68,17 @@ struct Rccl {
     SYM(GroupStart, "ncclGroupStart")
     SYM(GroupEnd, "ncclGroupEnd")
     SYM(GetErrorString, "ncclGetErrorString")
+    SYM(GetVersion, "ncclGetVersion")
 #undef SYM
+    // The entry points above are declared by hand against rccl.h of ROCm 7.2 (RCCL 2.2x: NCCL_VERSION_CODE =
+    // major * 10000 + minor * 100 + patch since 2.9).  Their signatures and ncclInt32 == 2 have been stable across the
+    // whole 2.x line; any other major is refused rather than called through a guessed ABI.
+    if (GetVersion(&version) != 0 || version < 20000 || version >= 30000) {
+      err = "librccl reports version code " + std::to_string(version) + ": only RCCL/NCCL 2.x is supported by this binding";
+      dlclose(dl);
+      dl = nullptr;
+      return false;
+    }
     return true;
   }
 };
@@ -109,6 +121,7 @@ struct Member {
   uint32_t *d_pack = nullptr;      // [cap][13]
   uint32_t *d_gathered = nullptr;  // [G][cap][13]
   int lo = 0, n = 0;               // slice of the current batch
+  int posted_lo = 0, posted_n = 0; // slice of the batch whose exchange was posted last (may differ from the current one)
 };
 
 }  // namespace
@@ -120,8 +133,14 @@ struct hmpc_group {
   std::vector<Member> m;
   std::vector<ncclComm_t> comms;
   uint32_t *h_stage = nullptr;  // pinned [G][cap][13]
+  // an exchange has been posted and not yet collected (by hmpc_group_wait_gather or hmpc_group_gather_wrench): the
+  // pipelined pattern post(k) / solve(k+1) / gather_wrench() collects solve k's exchange, while a gather_wrench after a
+  // collected exchange posts a fresh one for the solves enqueued since
   bool gather_posted = false;
+  bool exchange_repair = true; // members run the device-side safe pass inside every solve: the exchange carries repaired rows
 };
+
+#define GENTER() g_group_err.clear() /* a stale group-level message must not shadow a later member-level one */
 
 extern "C" {
 
@@ -161,6 +180,7 @@ int hmpc_group_destroy(hmpc_group *g) {
 
 int hmpc_group_create(hmpc_group **out, const struct problem_setup *setup, const int *devices, int n_devices,
                       int max_batch, int transport) {
+  GENTER();
   if (!out || !setup || n_devices < 1 || max_batch < 1) return HMPC_E_ARG;
   if (transport != HMPC_GROUP_AUTO && transport != HMPC_GROUP_RCCL && transport != HMPC_GROUP_P2P) return HMPC_E_ARG;
   int ndev = 0;
@@ -168,6 +188,12 @@ int hmpc_group_create(hmpc_group **out, const struct problem_setup *setup, const
     g_group_err = "no HIP device visible (libhector_mpc_hip has no CPU fallback)";
     return HMPC_E_NO_DEVICE;
   }
+  int caller_device = 0;
+  (void)hipGetDevice(&caller_device);
+  struct RestoreDevice {  // the caller's current device is not a side effect of creating a group
+    int d;
+    ~RestoreDevice() { (void)hipSetDevice(d); }
+  } restore{caller_device};
   hmpc_group *g = new (std::nothrow) hmpc_group();
   if (!g) return HMPC_E_ARG;
   g->setup = *setup;
@@ -213,6 +239,7 @@ int hmpc_group_create(hmpc_group **out, const struct problem_setup *setup, const
   for (Member &mb : g->m) {
     GHIPD(hipSetDevice(mb.device));
     GTRY(hmpc_create(&mb.h, setup, g->cap, mb.device));
+    GTRY(hmpc_set_device_repair(mb.h, 1));
     GHIPD(hipStreamCreateWithFlags(&mb.solve_stream, hipStreamNonBlocking));
     GHIPD(hipStreamCreateWithFlags(&mb.comm_stream, hipStreamNonBlocking));
     GHIPD(hipEventCreateWithFlags(&mb.packed, hipEventDisableTiming));
@@ -276,6 +303,7 @@ int hmpc_group_member(hmpc_group *g, int member, hmpc_handle **handle, int *devi
 
 // contiguous slices of a host batch -> the members' record buffers (asynchronous on each member's solve stream)
 int hmpc_group_upload_records(hmpc_group *g, const void *host_records, int batch) {
+  GENTER();
   if (!g || (!host_records && batch > 0) || batch < 0) return HMPC_E_ARG;
   if (batch > g->max_batch) return HMPC_E_BATCH;
   const size_t stride = hmpc_record_stride(g->setup.horizon);
@@ -297,6 +325,7 @@ int hmpc_group_upload_records(hmpc_group *g, const void *host_records, int batch
 // records already resident on each member's device: slice sizes are taken from the shard arithmetic, the caller supplies
 // one device pointer per member (device_records[i] points at that member's first record, on that member's device)
 int hmpc_group_set_device_records(hmpc_group *g, const void *const *device_records, int batch, int max_reduced_vars) {
+  GENTER();
   if (!g || !device_records || batch < 0) return HMPC_E_ARG;
   if (batch > g->max_batch) return HMPC_E_BATCH;
   for (int i = 0; i < g->G; ++i) {
@@ -315,6 +344,7 @@ int hmpc_group_set_device_records(hmpc_group *g, const void *const *device_recor
 
 // enqueue the solve of every member's slice on its own stream; returns without waiting
 int hmpc_group_solve(hmpc_group *g) {
+  GENTER();
   if (!g) return HMPC_E_ARG;
   for (Member &mb : g->m) {
     GHIP(hipSetDevice(mb.device));
@@ -324,9 +354,25 @@ int hmpc_group_solve(hmpc_group *g) {
   return HMPC_OK;
 }
 
+// The exchange carries repaired rows (default on): every member's solve is followed, on the same stream and without a
+// host round trip, by the safe variant over the instances the fast variant flagged (hmpc_set_device_repair), so what
+// pack_step0_kernel reads is the repaired wrench and status.  Off = the fast pass's results as they are (a flagged
+// instance then shows in its status word and hmpc_group_download repairs it).
+int hmpc_group_set_exchange_repair(hmpc_group *g, int on) {
+  GENTER();
+  if (!g) return HMPC_E_ARG;
+  for (Member &mb : g->m) {
+    const int rc = hmpc_set_device_repair(mb.h, on);
+    if (rc != HMPC_OK) return rc;
+  }
+  g->exchange_repair = on != 0;
+  return HMPC_OK;
+}
+
 // post the exchange step for the solves enqueued so far: pack on the solve stream (so the NEXT solve may overwrite the
 // force buffer at once), all-gather on the comm stream (so it runs under that next solve).  Does not block.
 int hmpc_group_post_gather(hmpc_group *g) {
+  GENTER();
   if (!g) return HMPC_E_ARG;
   const int width = 12 * g->setup.horizon;
   for (Member &mb : g->m) {
@@ -349,6 +395,7 @@ int hmpc_group_post_gather(hmpc_group *g) {
     }
     GHIP(hipEventRecord(mb.packed, mb.solve_stream));
     GHIP(hipStreamWaitEvent(mb.comm_stream, mb.packed, 0));
+    mb.posted_lo = mb.lo, mb.posted_n = mb.n;  // hmpc_group_gather_wrench unpacks THIS batch's slices
   }
   const size_t slice_words = (size_t)g->cap * PACK_WORDS;
   if (g->transport == HMPC_GROUP_RCCL) {
@@ -398,7 +445,9 @@ int hmpc_group_device_gathered(hmpc_group *g, int member, const uint32_t **gathe
 }
 
 int hmpc_group_wait_gather(hmpc_group *g) {
+  GENTER();
   if (!g) return HMPC_E_ARG;
+  g->gather_posted = false;  // collected: the caller reads hmpc_group_device_gathered from here on
   for (Member &mb : g->m) {
     GHIP(hipSetDevice(mb.device));
     GHIP(hipStreamSynchronize(mb.comm_stream));
@@ -409,6 +458,7 @@ int hmpc_group_wait_gather(hmpc_group *g) {
 // the exchange step, blocking form: post (if not posted yet), wait, and copy the gathered block of the first member to
 // the host in instance order: wrench [batch][12] float, status [batch] (either may be NULL)
 int hmpc_group_gather_wrench(hmpc_group *g, float *host_wrench, uint32_t *host_status) {
+  GENTER();
   if (!g) return HMPC_E_ARG;
   if (!g->gather_posted) {
     const int rc = hmpc_group_post_gather(g);
@@ -423,9 +473,9 @@ int hmpc_group_gather_wrench(hmpc_group *g, float *host_wrench, uint32_t *host_s
   for (int s = 0; s < g->G; ++s) {
     const Member &mb = g->m[s];
     const uint32_t *rows = g->h_stage + (size_t)s * slice_words;
-    for (int i = 0; i < mb.n; ++i) {
-      if (host_wrench) memcpy(host_wrench + (size_t)(mb.lo + i) * 12, rows + (size_t)i * PACK_WORDS, 12 * sizeof(float));
-      if (host_status) host_status[mb.lo + i] = rows[(size_t)i * PACK_WORDS + 12];
+    for (int i = 0; i < mb.posted_n; ++i) {
+      if (host_wrench) memcpy(host_wrench + (size_t)(mb.posted_lo + i) * 12, rows + (size_t)i * PACK_WORDS, 12 * sizeof(float));
+      if (host_status) host_status[mb.posted_lo + i] = rows[(size_t)i * PACK_WORDS + 12];
     }
   }
   return HMPC_OK;
@@ -434,6 +484,7 @@ int hmpc_group_gather_wrench(hmpc_group *g, float *host_wrench, uint32_t *host_s
 // every member's full force block [n][12h] and status words to the host, in instance order (no collective: G D2H copies);
 // flagged instances get the members' safe pass exactly as hmpc_download gives it
 int hmpc_group_download(hmpc_group *g, float *forces, uint32_t *status) {
+  GENTER();
   if (!g) return HMPC_E_ARG;
   const size_t width = (size_t)12 * g->setup.horizon;
   for (Member &mb : g->m) {
@@ -444,6 +495,7 @@ int hmpc_group_download(hmpc_group *g, float *forces, uint32_t *status) {
 }
 
 int hmpc_group_synchronize(hmpc_group *g) {
+  GENTER();
   if (!g) return HMPC_E_ARG;
   for (Member &mb : g->m) {
     GHIP(hipSetDevice(mb.device));

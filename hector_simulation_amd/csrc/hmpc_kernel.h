@@ -60,6 +60,14 @@ struct KernelArgs {
   // optional device counter: +1 for every instance this launch leaves flagged for the safe pass (working set full,
   // max-iter, infeasible, KKT); lets hmpc_download skip the status scan when nothing was flagged
   unsigned int *flagged;
+  // Device-side safe pass (hmpc_set_device_repair): a fast launch appends the index of every instance it flags to
+  // flag_list[0 .. flag_cap) through the per-launch counter flag_count; the safe launch that follows on the same stream
+  // takes flag_list as its index_list and list_count = flag_count, so that workgroups beyond the count leave at once --
+  // no host round trip between the two launches.
+  int *flag_list;
+  unsigned int *flag_count;
+  int flag_cap;
+  const unsigned int *list_count;
 };
 constexpr int NPROF = 32;
 enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A, P_A0, P_A1, P_A2, P_G };
@@ -263,6 +271,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   auto &Q = S.u.s;
 
   const int tid = threadIdx.x, wv = uni(tid >> 6), ln = tid & 63;
+  if (!ASM_ONLY && args.list_count && blockIdx.x >= *args.list_count) return;  // device-side safe pass: nothing (more) flagged
   const int inst = ASM_ONLY ? args.dbg_index : (args.index_list ? args.index_list[blockIdx.x] : (int)blockIdx.x);
   const int h = args.horizon;
   if (inst >= args.batch) return;
@@ -1727,8 +1736,13 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   }
   if (tid == 0) {
     args.status[inst] = (uint32_t)code | ((uint32_t)(iters & 0xfff) << 8) | ((uint32_t)(q & 0xfff) << 20);
-    if (args.flagged && (code == S_WORKSET || code == S_MAXITER || code == S_INFEASIBLE || code == S_KKT))
-      atomicAdd(args.flagged, 1u);
+    if (code == S_WORKSET || code == S_MAXITER || code == S_INFEASIBLE || code == S_KKT) {
+      if (args.flagged) atomicAdd(args.flagged, 1u);
+      if (args.flag_count) {
+        const unsigned int k = atomicAdd(args.flag_count, 1u);
+        if ((int)k < args.flag_cap) args.flag_list[k] = inst;
+      }
+    }
     if (args.obj64) {
       // objective through the KKT identity  0.5 x'Hx + g'x = 0.5 g'x + 0.5 u'b_W  (H itself was consumed by the sweeps)
       double o = 0.0;

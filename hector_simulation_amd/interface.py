@@ -133,6 +133,10 @@ class BatchedMPC:
     def set_auto_resolve(self, on: bool) -> None:
         _check(self.L.hmpc_set_auto_resolve(self.h, 1 if on else 0), "hmpc_set_auto_resolve")
 
+    def set_device_repair(self, on: bool) -> None:
+        """Device-side safe pass inside every solve (include/hector_mpc.h hmpc_set_device_repair)."""
+        _check(self.L.hmpc_set_device_repair(self.h, 1 if on else 0), "hmpc_set_device_repair")
+
     def resolve_failed(self) -> int:
         n = C.c_int(0)
         _check(self.L.hmpc_resolve_failed(self.h, C.byref(n)), "hmpc_resolve_failed")
@@ -285,6 +289,9 @@ class DeviceGroup:
 
     def solve(self) -> None:
         self._check(self.L.hmpc_group_solve(self.g), "hmpc_group_solve")
+
+    def set_exchange_repair(self, on: bool) -> None:
+        self._check(self.L.hmpc_group_set_exchange_repair(self.g, 1 if on else 0), "hmpc_group_set_exchange_repair")
 
     def post_gather(self) -> None:
         self._check(self.L.hmpc_group_post_gather(self.g), "hmpc_group_post_gather")

@@ -97,7 +97,7 @@ enum hmpc_status_code {
   HMPC_S_INFEASIBLE = 2,  /* constraints inconsistent */
   HMPC_S_TOO_LARGE = 3,   /* more than HMPC_MAX_VARS reduced variables (e.g. double support over h > 10) */
   HMPC_S_KKT = 4,         /* final KKT check outside tolerance */
-  HMPC_S_WORKSET = 5,     /* more simultaneously active constraints than the fast variant's on-chip working set holds (64 rows at h <= 10, 80 at h = 20; the safe pass holds as many as there are variables) */
+  HMPC_S_WORKSET = 5,     /* more simultaneously active constraints than the fast variant's on-chip working set holds (64 rows; the safe pass holds as many as there are variables) */
   HMPC_S_OK_RELAXED = 6   /* solved, but only after every bound was moved outward by <= 2e-6 (relative for the Fz cap):
                              the last-resort pass of hmpc_resolve_failed for instances cycling at a degenerate vertex */
 };
@@ -160,6 +160,13 @@ int hmpc_reset_tick_warm_start(hmpc_handle *h);
  * hmpc_download does this automatically unless hmpc_set_auto_resolve(h, 0). */
 int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved);
 int hmpc_set_auto_resolve(hmpc_handle *h, int on);
+/* Device-side safe pass (default off for a plain handle): when on, hmpc_solve enqueues, behind the fast launch and on the
+ * same stream, the safe variant over the list of instances the fast launch flagged (the list and its length stay on the
+ * device; workgroups beyond the length leave at once) -- device-resident outputs, hmpc_download_async and the group
+ * exchange then see repaired forces/status without any host involvement.  Costs one 4-byte memset and one (normally
+ * empty) extra launch per solve; repairs at most min(batch, 2048) instances per solve, the rest stay flagged for
+ * hmpc_resolve_failed / hmpc_download. */
+int hmpc_set_device_repair(hmpc_handle *h, int on);
 /* Stream-ordered variants for pipelining host batches (two handles on two streams: the copies of one overlap the solve
  * of the other).  The host buffers should be pinned (hipHostMalloc / hipHostRegister) for the copies to be asynchronous
  * and must stay valid until the stream reaches them.  hmpc_download_async does not run the safe pass: check the status
@@ -269,12 +276,19 @@ int hmpc_group_wait_gather(hmpc_group *g);
 /* member's gathered copy in HBM: [group size][slot_rows][13] 32-bit words, slot s = member s's slice, row = 12 floats of
  * the step-0 wrench + the status word.  Valid from hmpc_group_wait_gather until the next hmpc_group_post_gather. */
 int hmpc_group_device_gathered(hmpc_group *g, int member, const uint32_t **gathered, int *slot_rows);
-/* blocking form of the exchange step: posts it if hmpc_group_post_gather was not called since the last solve, waits,
- * and returns host copies in instance order: wrench [batch][12], status [batch] (either may be NULL).
- * The exchange carries the fast pass's results as they are: an instance the fast variant flagged (working set full /
- * max-iter / KKT) shows in its status word and its wrench is not valid; hmpc_group_download runs the members' safe
- * pass (as hmpc_download does) and returns the repaired forces. */
+/* blocking form of the exchange step: collects the exchange hmpc_group_post_gather posted if it has not been collected
+ * yet (by hmpc_group_wait_gather or an earlier hmpc_group_gather_wrench) -- the pipelined pattern post(k), solve(k+1),
+ * gather_wrench() returns solve k's results -- and otherwise posts one now for the solves enqueued so far; waits, and
+ * returns host copies in instance order of the batch the exchange was posted for (its slices are remembered at post
+ * time): wrench [batch][12], status [batch] (either may be NULL).
+ * The exchange carries REPAIRED rows: every member's solve is followed on its stream, without a host round trip, by the
+ * safe variant over the instances the fast variant flagged (hmpc_set_device_repair, on by default for group members; up to
+ * 2048 per member per solve).  hmpc_group_set_exchange_repair(g, 0) turns that off: the exchange then carries the fast
+ * pass's results as they are (a flagged instance shows in its status word, its wrench is not valid) and only
+ * hmpc_group_download repairs.  Instances that defeat even the safe variant (degenerate vertices, < 0.1 % at 6x the
+ * nominal input ranges) stay flagged in the status word either way; hmpc_group_download's relaxed passes handle them. */
 int hmpc_group_gather_wrench(hmpc_group *g, float *host_wrench, uint32_t *host_status);
+int hmpc_group_set_exchange_repair(hmpc_group *g, int on);
 /* all 12h forces of every instance to the host (no collective; the members' safe pass included) */
 int hmpc_group_download(hmpc_group *g, float *forces, uint32_t *status);
 int hmpc_group_synchronize(hmpc_group *g);

@@ -116,3 +116,72 @@ def test_group_device_resident_records():
     np.testing.assert_array_equal(status, ref_s)
     np.testing.assert_array_equal(wrench.view(np.uint32), ref_f[:, :12].view(np.uint32))
     grp.close()
+
+
+def test_gather_after_a_collected_exchange_posts_a_fresh_one():
+    """solve, post, wait (collected through the device copy), solve again, gather_wrench: the second solve's data -- and
+    the host unpack follows the slices of the batch that was POSTED, also when the batch size changed in between."""
+    nb1, nb2 = 60, 45
+    rec1 = records.pack_records(synthetic.make_batch(nb1, H, "walking", seed=51, phase="random"), H)
+    rec2 = records.pack_records(synthetic.make_batch(nb2, H, "standing", seed=52), H)
+    ref1, ref2 = _single(rec1), _single(rec2)
+    grp = interface.DeviceGroup(synthetic.DT_MPC, H, synthetic.F_MAX, nb1, [0, 0, 0], "p2p")
+    grp.upload(rec1)
+    grp.solve()
+    grp.post_gather()
+    grp.wait_gather()                      # collected: the caller reads hmpc_group_device_gathered
+    ptr, rows = grp.device_gathered(1)
+    blk = _device_words(ptr, grp.size * rows * 13).reshape(grp.size, rows, 13)
+    lo, hi = interface.shard_bounds(nb1, 3, 2)
+    np.testing.assert_array_equal(blk[2, :hi - lo, :12], ref1[0][lo:hi, :12].view(np.uint32))
+    grp.upload(rec2)
+    grp.solve()
+    wrench, status = grp.gather_wrench()   # must post anew and return the SECOND solve
+    np.testing.assert_array_equal(status, ref2[1])
+    np.testing.assert_array_equal(wrench.view(np.uint32), ref2[0][:, :12].view(np.uint32))
+    # pipelined with a batch-size change between post and collection: rows land at the posted batch's slices
+    grp.upload(rec1)
+    grp.solve()
+    grp.post_gather()
+    grp.upload(rec2)
+    grp.solve()
+    w1 = np.zeros((nb1, 12), dtype=np.float32)
+    s1 = np.zeros(nb1, dtype=np.uint32)
+    grp._check(grp.L.hmpc_group_gather_wrench(grp.g, w1.ctypes.data, s1.ctypes.data), "gather")
+    np.testing.assert_array_equal(s1, ref1[1])
+    np.testing.assert_array_equal(w1.view(np.uint32), ref1[0][:, :12].view(np.uint32))
+    grp.close()
+
+
+def test_exchange_carries_repaired_rows():
+    """6x the nominal input ranges: the fast variant flags some instances (working set full).  With the members'
+    device-side safe pass (default) the gathered wrench/status are the REPAIRED ones -- equal to what hmpc_download returns
+    after its host-driven safe pass; with it off the exchange shows the flags."""
+    from tests.test_gpu_robustness import hard_batch
+
+    nb = 384
+    rec = records.pack_records(hard_batch(nb, H, "standing", 17, 6), H)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb)
+    mpc.set_auto_resolve(False)
+    mpc.upload(rec)
+    mpc.solve()
+    _, st_fast = mpc.download()
+    assert (interface.status_code(st_fast) == 5).any()      # the regime exercises the safe pass
+    mpc.set_auto_resolve(True)
+    ref_f, ref_s = mpc.download()                            # host-driven safe pass (+ relaxed passes)
+    mpc.close()
+    grp = interface.DeviceGroup(synthetic.DT_MPC, H, synthetic.F_MAX, nb, [0, 0, 0], "p2p")
+    grp.upload(rec)
+    grp.solve()
+    wrench, status = grp.gather_wrench()
+    code, ref_code = interface.status_code(status), interface.status_code(ref_s)
+    assert (code != 5).all()                                  # nothing is left "working set full"
+    same = ref_code == 0                                      # instances the first safe pass solves exactly
+    np.testing.assert_array_equal(code[same], ref_code[same])
+    np.testing.assert_array_equal(wrench[same].view(np.uint32), ref_f[same, :12].view(np.uint32))
+    assert (code[~same] != 0).all()                           # what needs the relaxed passes stays flagged, never silent
+    grp.set_exchange_repair(False)
+    grp.solve()
+    _, status_raw = grp.gather_wrench()
+    np.testing.assert_array_equal(status_raw, st_fast)
+    grp.close()

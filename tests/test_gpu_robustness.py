@@ -70,3 +70,46 @@ def test_repeated_solves_are_bitwise_identical(gait, h, nb):
     for forces, status in outs[1:]:
         np.testing.assert_array_equal(status, outs[0][1])
         np.testing.assert_array_equal(forces.view(np.uint32), outs[0][0].view(np.uint32))
+
+
+@pytest.mark.parametrize("gait,h", [("standing", 10), ("single", 20)])
+def test_device_side_safe_pass_equals_the_host_driven_one(gait, h):
+    """hmpc_set_device_repair: the safe variant runs behind the fast launch on the same stream over the device-resident
+    list of flagged instances -- the outputs in HBM equal those of hmpc_resolve_failed's first (exact) pass, bit for bit,
+    with no host round trip; nominal batches are unaffected."""
+    nb = 256
+    rec = records.pack_records(hard_batch(nb, h, gait, 23, 6), h)
+    a = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb)
+    a.set_auto_resolve(False)
+    a.upload(rec)
+    a.solve()
+    _, st_fast = a.download()
+    n_flagged = int(np.isin(interface.status_code(st_fast), (1, 2, 4, 5)).sum())
+    assert n_flagged > 0
+    b = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb)
+    b.set_auto_resolve(False)
+    b.set_device_repair(True)
+    b.upload(rec)
+    b.solve()
+    f_dev, st_dev = b.download()          # auto-resolve off: exactly what the two launches left in HBM
+    b.close()
+    a.set_auto_resolve(True)
+    f_host, st_host = a.download()
+    a.close()
+    exact = interface.status_code(st_host) == 0
+    np.testing.assert_array_equal(st_dev[exact], st_host[exact])
+    np.testing.assert_array_equal(f_dev[exact].view(np.uint32), f_host[exact].view(np.uint32))
+    assert (interface.status_code(st_dev) != 5).all()
+    assert (interface.status_code(st_dev)[~exact] != 0).all()
+    # a nominal batch: nothing flagged, same bits with and without the extra (empty) launch
+    rec2 = records.pack_records(synthetic.make_batch(nb, h, gait, seed=3, phase="random"), h)
+    outs = []
+    for on in (False, True):
+        m = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb)
+        m.set_device_repair(on)
+        m.upload(rec2)
+        m.solve()
+        outs.append(m.download())
+        m.close()
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
