@@ -897,6 +897,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     if (diag) Q.piv[0][0] = a[0][0] - 1.0, Q.pd[0] = a[0][0];
   }
   __syncthreads();
+  // waves that hold no register block at all (the second wave of the 128-thread variants: 55 blocks) only keep the barriers
+  constexpr int NW_OWN = (NTILE + 63) / 64;
+  const bool wave_owns = (NW_OWN >= NW) || (wv < NW_OWN);  // scalar; compile-time true where every wave holds blocks
   for (int kb = 0; kb < ng; ++kb) {
     const bool rowb = owner && (e0 == kb);      // my block holds matrix rows 6kb..6kb+5
     const bool colb = owner && (e1 == kb);      // my block holds matrix columns 6kb..6kb+5
@@ -905,6 +908,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
 #pragma unroll
     for (int kk = 0; kk < GS; ++kk) {
       const int k = kb * GS + kk;
+      if (wave_owns) {
       const double *pv = Q.piv[k & 1];
       double *pn = Q.piv[(k + 1) & 1];
       const double d = Q.pd[k & 1];
@@ -967,6 +971,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
 #pragma unroll
         for (int jj = 0; jj < GS; ++jj) asm volatile("" : "+v"(a[ii][jj]));
 #endif
+      }  // wave_owns
       __syncthreads();
     }
   }

@@ -19,14 +19,19 @@ def main():
     gait = sys.argv[1] if len(sys.argv) > 1 else "standing"
     h = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     nb = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
+    nc = int(sys.argv[4]) if len(sys.argv) > 4 else 2
     prof_lib = os.path.join(ROOT, "gpurun_out", "libhector_mpc_hip_prof.so")
     os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
     subprocess.check_call(["hipcc"] + build.FLAGS + ["-DHMPC_PROFILE"] + [os.path.join(build.CSRC, s) for s in build.SOURCES] + ["-o", prof_lib])
     build.LIB = prof_lib
     build.needs_build = lambda: False
-    f = synthetic.make_batch(nb, h, gait, seed=6, phase="random")
-    rec = records.pack_records(f, h)
-    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb)
+    if nc == 3:
+        f = synthetic.make_batch3(nb, h, gait, seed=5, hand="contact")
+        rec = records.pack_records(f, h, 3)
+    else:
+        f = synthetic.make_batch(nb, h, gait, seed=6, phase="random")
+        rec = records.pack_records(f, h)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb, contacts=nc)
     mpc.upload(rec)
     mpc.solve()
     _, status = mpc.download()
@@ -34,7 +39,7 @@ def main():
     interface._check(mpc.L.hmpc_debug_phase_cycles(mpc.h, cyc.ctypes.data), "phase_cycles")
     it = interface.status_iters(status)
     mean = cyc.mean(axis=0)
-    print(f"gait={gait} h={h} batch={nb} iters median {np.median(it)} mean {it.mean():.1f}")
+    print(f"gait={gait} h={h} batch={nb} contacts={nc} iters median {np.median(it)} mean {it.mean():.1f}")
     for i, name in enumerate(PH):
         print(f"  {name:8s} {mean[i]:12.0f} cycles  {100 * mean[i] / mean[13]:5.1f}%   per-iter {mean[i] / max(it.mean(), 1):9.0f}")
 
