@@ -250,6 +250,21 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #ifndef HMPC_PIN_SWEEP
 #define HMPC_PIN_SWEEP 1
 #endif
+#ifndef HMPC_BLOCK_ROUNDS
+#define HMPC_BLOCK_ROUNDS 2      // block start: rounds at most (1 = a single block start), 120-variable variants
+#endif
+#ifndef HMPC_BLOCK_ROUNDS_3C
+#define HMPC_BLOCK_ROUNDS_3C 3   // ... three-contact variant
+#endif
+#ifndef HMPC_BLOCK_MIN_NEW
+#define HMPC_BLOCK_MIN_NEW 5     // a further round needs at least this many newly violated rows (256-/128-thread variants)
+#endif
+#ifndef HMPC_BLOCK_MIN_NEW_3C
+#define HMPC_BLOCK_MIN_NEW_3C 3  // ... three-contact variant (its single-row iteration is dearer)
+#endif
+#ifndef HMPC_BLOCK_FRICTION
+#define HMPC_BLOCK_FRICTION 1  // block start also takes friction rows violated at the unconstrained minimiser
+#endif
 namespace hmpc {
 
 // three waves per SIMD = 3 (256 threads) or 6 (128 threads) workgroups per CU: their LDS must fit the CU's 160 KB
@@ -1243,6 +1258,42 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       }
       k0 = uni(k0);
     };
+    // Rounds.  Round 0 is the block start proper; while enough further rows are violated at the point it reaches
+    // (>= BLOCK_MIN_NEW of them: a round costs about as much as that many single-row iterations) another round takes the
+    // current working set plus every row violated at the current x -- same independence rule -- and solves for all of them
+    // at once.  Every round ends in a valid Goldfarb-Idnani state (x minimises over the working set, multipliers >= 0), so
+    // the dual active-set iteration below finishes from wherever the rounds stop.
+    // walking: ~1.6 iterations per solve, nothing to gain; 120 variables: two rounds (a third one is worth <1 % there and its
+    // third copy of the phase tips the register allocation of the 168-VGPR variant over: 86 spilled registers, 1.43 -> 1.78 ms);
+    // three contacts: three (1.13 -> 1.18 M solves/s over two)
+    constexpr int BLOCK_ROUNDS = (NT >= 512) ? HMPC_BLOCK_ROUNDS_3C : ((NT >= 256) ? HMPC_BLOCK_ROUNDS : 1);
+    constexpr bool BLOCK_FRICTION = HMPC_BLOCK_FRICTION && NT >= 256;
+    constexpr int BLOCK_MIN_NEW = (NT >= 512) ? HMPC_BLOCK_MIN_NEW_3C : HMPC_BLOCK_MIN_NEW;
+    constexpr int EPT = 5;  // packed-triangle entries per thread during the Schur inversion
+    constexpr int KBMAX = (NT >= 512) ? 71 : ((NT >= 256) ? 45 : 34);  // KBMAX(KBMAX+1)/2 <= EPT*NT
+    static_assert(KBMAX * (KBMAX + 1) / 2 <= EPT * NT && KBMAX <= SM::QMAX, "block start capacity");
+    // (one round as a lambda instantiated once per round rather than a loop: with the loop the register allocator keeps
+    //  ~50 more VGPRs alive across the whole phase -- measured 185 -> 244 on the unconstrained variants)
+    auto block_round = [&](const int round) __attribute__((always_inline)) -> bool {  // true: another round may follow
+    if (round > 0) {
+      take = false;
+      bool fresh = false;
+      if (is_c) {
+        const int ac = Q.act[tid];
+        bool viol = false;
+        if (ac == 0 && c_rr <= 6) viol = my_slack(Q.x, side, raw) < -FEAS_TOL;
+        if (ac != 0) side = ac;
+        const unsigned long long bal = __ballot(viol || ac != 0);
+        const bool partner = (c_rr < 4) && ((bal >> (ln ^ 1)) & 1ull);
+        fresh = viol && !partner;
+        take = (ac != 0) || fresh;
+      }
+      count_candidates();
+      if (ub(k0 - q < BLOCK_MIN_NEW || k0 > KBMAX)) return false;  // not worth a round / does not fit: the iteration below goes on
+      __syncthreads();  // wcount is free again
+      ++iters;
+      tick = true;  // rows 0..7 may be in the set from here on
+    } else
     if (args.wset) {
       if (is_c) {
         int st = (int)S.ls_step[c_e] + args.wset_shift;
@@ -1257,20 +1308,29 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     }
     if (!tick) {  // uniform.  Rows 4-6 violated at the unconstrained minimiser
       take = false;
+      if constexpr (BLOCK_FRICTION) {
+      // ... and a friction row (0-3) violated there whose partner on the same axis (0<->1, 2<->3) is not: at most one row
+      // per axis, so that the rows taken from one leg-step stay linearly independent
+      if (is_c && c_rr <= 6) {
+        const bool viol = my_slack(Q.xu, side, raw) < -FEAS_TOL;
+        const unsigned long long bal = __ballot(viol);
+        const bool partner = (c_rr < 4) && ((bal >> (ln ^ 1)) & 1ull);  // rows 8e+rr: the partner sits in the neighbouring lane
+        take = viol && !partner;
+      }
+      } else {
       if (is_c && c_rr >= 4 && c_rr <= 6) take = my_slack(Q.xu, side, raw) < -FEAS_TOL;
+      }
       count_candidates();
     }
-    const int rlo = tick ? 0 : 4, rhi = tick ? 7 : 6;
+    const int rlo = (tick || BLOCK_FRICTION) ? 0 : 4, rhi = tick ? 7 : 6;
     bool bad_start = false;
-    constexpr int EPT = 5;  // packed-triangle entries per thread during the Schur inversion
-    constexpr int KBMAX = (NT >= 512) ? 71 : ((NT >= 256) ? 45 : 34);  // KBMAX(KBMAX+1)/2 <= EPT*NT
-    static_assert(KBMAX * (KBMAX + 1) / 2 <= EPT * NT && KBMAX <= SM::QMAX, "block start capacity");
     if (k0 > KBMAX) k0 = KBMAX;
-    if (take && base + below < k0) {
-      const int sl = base + below;
-      Q.act[tid] = (signed char)side;
+    if (is_c) {  // slots are dealt afresh every round (E is rebuilt from scratch)
+      const bool in = take && base + below < k0;
+      const int sl = in ? base + below : 0;
+      Q.act[tid] = in ? (signed char)side : (signed char)0;
       Q.slot[tid] = (unsigned char)sl;
-      Q.Wrow[sl] = (unsigned char)tid;
+      if (in) Q.Wrow[sl] = (unsigned char)tid;
     }
     __syncthreads();
     if (k0 > 0) {
@@ -1399,6 +1459,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         // only possible for a working set inherited from the previous tick whose rows have become (nearly) dependent
         // under this tick's data: forget it and start from the empty set
         for (int t = tid; t < SM::MMAX; t += NT) Q.act[t] = 0, Q.slot[t] = 0;
+        if (is_v) Q.x[tid] = Q.xu[tid];
         q = 0;
         __syncthreads();
       }
@@ -1485,9 +1546,22 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         rmatvec(Q.w);
         if (is_v) Q.x[tid] = Q.xu[tid] + Q.z[tid];
         __syncthreads();
+      } else {
+        if (is_v) Q.x[tid] = Q.xu[tid];  // every row was released again
+        __syncthreads();
       }
       }
     }
+    return !ub(k0 == 0 || q == 0);  // (nothing to build on otherwise)
+    };  // block_round
+    bool more = block_round(0);
+    if constexpr (BLOCK_ROUNDS > 1) {
+      if (more) more = block_round(1);
+    }
+    if constexpr (BLOCK_ROUNDS > 2) {
+      if (more) more = block_round(2);
+    }
+    static_assert(BLOCK_ROUNDS <= 3, "rounds are instantiated one by one");
   }
   PROF_MARK(P_BLOCK);
 
