@@ -34,6 +34,9 @@ thread_local std::string g_hip_err;
 #ifndef HMPC_QCAP_FAST
 #define HMPC_QCAP_FAST 64  // working-set capacity of the fast 120-variable h <= 10 variant (49 KB LDS: three per CU)
 #endif
+#ifndef HMPC_QCAP_3C
+#define HMPC_QCAP_3C 80    // ... of the fast three-contact variant (256 threads, two register blocks each, <= 80 KB LDS: two per CU)
+#endif
 typedef void (*kernel_fn)(hmpc::KernelArgs);
 
 struct Variant {
@@ -50,11 +53,12 @@ struct Variant {
 // and re-solve the few instances the fast pass flags (hmpc_resolve_failed).
 // The extension with a third (hand) contact -- BASELINE config 5, 180 variables x 240 rows at h = 10 -- runs 512-thread
 // workgroups (465 register blocks, one workgroup per CU).
-template <int NMAX, int HMAX, int NT, int QCAP, int NC = 2>
+template <int NMAX, int HMAX, int NT, int QCAP, int NC = 2, int BPT = 1>
 Variant make_variant() {
-  static_assert(sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC>) <= 160 * 1024, "LDS budget of a gfx950 CU");
-  return Variant{NMAX, HMAX, NT, QCAP, NC, hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, false, NC>,
-                 hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, true, NC>, sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC>),
+  static_assert(sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>) <= 160 * 1024, "LDS budget of a gfx950 CU");
+  static_assert(BPT == 1 || sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>) <= 80 * 1024, "two workgroups per CU");
+  return Variant{NMAX, HMAX, NT, QCAP, NC, hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, false, NC, BPT>,
+                 hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, true, NC, BPT>, sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>),
                  hmpc::DbgLayout<NMAX, NC>::TOTAL};
 }
 
@@ -62,12 +66,13 @@ const Variant *variants() {
   static const Variant v[] = {make_variant<60, 10, 128, 60>(),   make_variant<120, 10, 256, HMPC_QCAP_FAST>(),
                               make_variant<60, 20, 128, 60>(),   make_variant<120, 20, 256, HMPC_QCAP_FAST>(),
                               make_variant<120, 10, 256, 120>(), make_variant<120, 20, 256, 120>(),
-                              make_variant<180, 10, 512, 100, 3>(), make_variant<180, 10, 512, 140, 3>()};
+                              make_variant<180, 10, 256, HMPC_QCAP_3C, 3, 2>(), make_variant<180, 10, 512, 140, 3>(),
+                              make_variant<180, 10, 512, 100, 3>()};
   return v;
 }
 constexpr int N_FAST = 4;       // two-contact fast variants [0, N_FAST), their safe variants N_FAST + (h > 10)
-constexpr int V3_FAST = 6, V3_SAFE = 7;
-constexpr int N_VARIANTS = 8;
+constexpr int V3_FAST = 6, V3_SAFE = 7, V3_FAST_512 = 8;  // (V3_FAST_512: the one-workgroup-per-CU variant of round 2, HMPC_3C_512=1)
+constexpr int N_VARIANTS = 9;
 constexpr int MAX_VARS_ANY = 180;
 constexpr int DBG_FLOATS_MAX = hmpc::DbgLayout<180, 3>::TOTAL > hmpc::DbgLayout<120, 2>::TOTAL
                                    ? hmpc::DbgLayout<180, 3>::TOTAL
@@ -144,8 +149,10 @@ static const Variant &pick_variant(const hmpc_handle *h, int *index) {
   const Variant *v = variants();
   const int hz = h->setup.horizon;
   if (h->nc == 3) {
-    if (index) *index = V3_FAST;
-    return v[V3_FAST];
+    static const bool old512 = getenv("HMPC_3C_512") && getenv("HMPC_3C_512")[0] == '1';  // developer A/B switch
+    const int vi3 = old512 ? V3_FAST_512 : V3_FAST;
+    if (index) *index = vi3;
+    return v[vi3];
   }
   int best = -1;
   for (int i = 0; i < N_FAST; ++i) {

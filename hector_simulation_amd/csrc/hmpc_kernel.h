@@ -100,7 +100,10 @@ enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT =
 
 constexpr int GS = 6;  // variables per stance leg-step: force (3) then moment (3)
 
-template <int NMAX, int HMAX, int NT, int QCAP, int NC = 2>
+// BPT = register blocks per thread (1: one 6x6 block each, NT >= NG(NG+1)/2; 2: the three-contact variant on 256 threads,
+// 465 blocks, two workgroups per CU -- which also needs its LDS under 80 KB: the staging of H is filled and drained in two
+// passes over the block-diagonals and the staged mat-vec partials in two halves of the source leg-steps).
+template <int NMAX, int HMAX, int NT, int QCAP, int NC = 2, int BPT = 1>
 struct Smem {
   static constexpr int U = 6 * NC;       // variables per horizon step before elimination: F of each contact, then M
   static constexpr int PS = 13 * U;      // floats per Phi_k
@@ -110,6 +113,18 @@ struct Smem {
   static constexpr int QMAX = QCAP;      // working-set capacity (packed Schur inverse); QCAP = NMAX can never overflow
   static constexpr int RECW = ((RecLayout<NC>::NF + 12 * HMAX) * 4 + NC * HMAX + 15) / 16 * 4;  // record words
   static constexpr bool FULLBLK = (HMAX <= 10 && NMAX >= 120);  // staging layout of H (struct Asm)
+  // FULLBLK staging passes: pass p holds the blocks of the block-diagonals d in [hs_dlo(p), hs_dlo(p+1))
+  static constexpr int HSP = (NC == 3 && BPT == 2) ? 2 : 1;
+  static constexpr int HS_D0 = 3;  // h = 10: 27 blocks on d < 3, 28 on d >= 3
+  static constexpr int hs_dlo(int p) { return p <= 0 ? 0 : (p >= HSP ? HMAX : HS_D0); }
+  static constexpr int hs_off(int d, int h) { return d * h - d * (d - 1) / 2; }  // blocks on the diagonals before d
+  static constexpr int HS_BLOCKS = (HSP == 1) ? HMAX * (HMAX + 1) / 2
+                                              : (hs_off(HS_D0, HMAX) > HMAX * (HMAX + 1) / 2 - hs_off(HS_D0, HMAX)
+                                                     ? hs_off(HS_D0, HMAX) : HMAX * (HMAX + 1) / 2 - hs_off(HS_D0, HMAX));
+  // staged mat-vec: partials of STH halves of the source leg-steps at a time (ST has NG / STH rows)
+  static constexpr int STH = (NC == 3 && BPT == 2) ? 2 : 1;
+  static constexpr int STR = NG / STH;
+  static_assert(NG % 2 == 0 && (STH == 1 || STH == 2), "the staged mat-vec sums two groups of NG/2 source leg-steps");
 
   double g[NMAX];        // gradient, sweep order
   double Cn[NC][8][6];   // per-contact constraint normals (columns: F then M of that contact)
@@ -132,11 +147,12 @@ struct Smem {
     float e[13 * HMAX];
     unsigned char pre_nl[HMAX], pre_nv[HMAX], pre_st[HMAX];  // per step: leg-steps / variables before it, stance bits
     // H in binary32 (exact), staged between the matrix-core phase and the register blocks of the sweeps.
-    //   FULLBLK (120/180 variables at h <= 10): every U x U block (a <= b) of the UNREDUCED matrix, row-major, block
-    //     a*h - a(a-1)/2 + (b-a) -- written by the Toeplitz chains with no index arithmetic (entries of swing leg-steps are
-    //     simply never read); + one spare word per lane for the padding lanes of the tiles;
+    //   FULLBLK (120/180 variables at h <= 10): every U x U block (a <= b) of the UNREDUCED matrix, row-major, ordered by
+    //     block-diagonal: block (a, a+d) at hs_off(d) + a -- written by the Toeplitz chains with no index arithmetic
+    //     (entries of swing leg-steps are simply never read); + one spare word per lane for the padding lanes of the tiles;
+    //     with HSP = 2 the area holds the diagonals of one pass at a time;
     //   otherwise: upper triangle over the reduced variables in reference order, rows i and NMAX-1-i folded into one.
-    float Hs[FULLBLK ? HMAX * (HMAX + 1) / 2 * U * U + 64 : (NMAX / 2) * (NMAX + 1)];
+    float Hs[FULLBLK ? HS_BLOCKS * U * U + 64 : (NMAX / 2) * (NMAX + 1)];
   };
   struct Rec {
     double val, raw, cn[6];
@@ -147,7 +163,7 @@ struct Smem {
     // staged partials of the in-place mat-vec: ST[source leg-step][variable]; rows padded by two doubles so that the
     // 16-byte writes of blocks with consecutive e1 (same e0) land in different LDS banks (row stride 240 words = 16 mod 32
     // would put them on two bank groups only)
-    alignas(16) double ST[NG][NMAX + 2];
+    alignas(16) double ST[STR][NMAX + 2];
     alignas(16) double piv[2][NMAX];
     double pd[2];  // the pivot of the published row (its own slot in the row carries d - 1, see the sweeps)
     double u[NMAX], d[NMAX], r[NMAX], col[NMAX];
@@ -262,24 +278,28 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #ifndef HMPC_BLOCK_MIN_NEW_3C
 #define HMPC_BLOCK_MIN_NEW_3C 3  // ... three-contact variant (its single-row iteration is dearer)
 #endif
+#ifndef HMPC_EPT_3C
+#define HMPC_EPT_3C 7            // three-contact variant on 256 threads: packed-triangle entries per thread in the block start
+#endif
 #ifndef HMPC_BLOCK_FRICTION
 #define HMPC_BLOCK_FRICTION 1  // block start also takes friction rows violated at the unconstrained minimiser
 #endif
 namespace hmpc {
 
 // three waves per SIMD = 3 (256 threads) or 6 (128 threads) workgroups per CU: their LDS must fit the CU's 160 KB
-template <int NMAX, int HMAX, int NT, int QCAP, int NC>
+template <int NMAX, int HMAX, int NT, int QCAP, int NC, int BPT>
 constexpr bool fits_three_waves() {
-  return sizeof(Smem<NMAX, HMAX, NT, QCAP, NC>) * (size_t)(3 * 256 / NT) <= (size_t)160 * 1024;
+  return BPT == 1 && sizeof(Smem<NMAX, HMAX, NT, QCAP, NC, BPT>) * (size_t)(3 * 256 / NT) <= (size_t)160 * 1024;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC = 2>
-__global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, QCAP, NC>()) ? (NT == 128 ? HMPC_WAVES_PER_EU_128 : HMPC_WAVES_PER_EU_256) : 2) void hmpc_kernel(KernelArgs args) {
-  using SM = Smem<NMAX, HMAX, NT, QCAP, NC>;
+template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC = 2, int BPT = 1>
+__global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, QCAP, NC, BPT>()) ? (NT == 128 ? HMPC_WAVES_PER_EU_128 : HMPC_WAVES_PER_EU_256) : 2) void hmpc_kernel(KernelArgs args) {
+  using SM = Smem<NMAX, HMAX, NT, QCAP, NC, BPT>;
   using RL = RecLayout<NC>;
   constexpr int NG = SM::NG, NW = SM::NW, U = SM::U, PS = SM::PS, C8 = 8 * NC;
-  static_assert(NC == 2 || (NC == 3 && NT >= 512), "contacts: two feet (reference) or two feet + hand (extension)");
+  static_assert(NC == 2 || (NC == 3 && NT * BPT >= 512), "contacts: two feet (reference) or two feet + hand (extension)");
+  static_assert(BPT == 1 || BPT == 2, "register blocks per thread");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SM &S = *reinterpret_cast<SM *>(smem_raw);
   auto &A = S.u.a;
@@ -305,14 +325,14 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   const float *in_p = rf + RL::P, *in_v = rf + RL::V, *in_q = rf + RL::Q, *in_w = rf + RL::W, *in_r = rf + RL::R,
               *in_ja = rf + RL::JA, *in_wt = rf + RL::WT, *in_al = rf + RL::AL, *in_traj = rf + RL::NF;
   // Fz cap of a contact: f_max for the feet; the hand's own cap travels in the extension record
-  auto fz_cap = [&](int c) -> float { return (NC == 3 && c == 2) ? rf[RL::FMH] : args.f_max; };
+  auto fz_cap = [&](int c) __attribute__((always_inline)) -> float { return (NC == 3 && c == 2) ? rf[RL::FMH] : args.f_max; };
 
   // ---------------- A1: trigonometry, one lane per angle (SolverMPC.cpp:374-393, 333-342, 74-85); a lane of another
   // wave builds the swing-leg elimination tables meanwhile (SolverMPC.cpp:589-637)
   {
     const double PI = 3.14159265359, PI2 = 2 * PI;
     constexpr int L_ROLL = (NT >= 256) ? 65 : 65, L_PITCH = (NT >= 256) ? 128 : 66, L_YAW = (NT >= 256) ? 192 : 12;
-    auto joint = [&](int i) -> float {
+    auto joint = [&](int i) __attribute__((always_inline)) -> float {
       float a = in_ja[i];
       const int k = i % 5;
       if (k == 2 || k == 4) a = (float)((double)a + 0.3 * PI);
@@ -442,7 +462,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   {
     // foot rotation Rz(q0)Rx(q1)Ry(q2)Ry(q3)Ry(q4) and this leg's 8 rows of the 16x12 constraint block
     // (SolverMPC.cpp:426-433, 488-548)
-    const int leg_lane0 = (NT >= 256) ? 128 : 64, leg_lane1 = (NT >= 256) ? 192 : 65, leg_lane2 = (NC == 3) ? 256 : -1;
+    const int leg_lane0 = (NT >= 256) ? 128 : 64, leg_lane1 = (NT >= 256) ? 192 : 65, leg_lane2 = (NC == 3) ? (NT >= 512 ? 256 : 96) : -1;
     if (tid == leg_lane0 || tid == leg_lane1 || tid == leg_lane2) {
       const int leg = (tid == leg_lane0) ? 0 : (tid == leg_lane1 ? 1 : 2);
       float R[9], Rt[9];
@@ -640,6 +660,25 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     S.g[S.o2s[tid]] = (double)(2.0f * acc);
   }
   PROF_MARK(P_G);
+  // ---- register blocks of the sweeps (stage S): thread t owns the 6x6 blocks number t, t + NT, ... (< NG(NG+1)/2) of the
+  // symmetric matrix in sweep order, block-row-major: (e0, e1), e0 <= e1.  Declared here because the blocks are filled
+  // straight from the staging area of H, pass by pass where that area holds only part of the block-diagonals at a time.
+  constexpr int NTILE = NG * (NG + 1) / 2;
+  static_assert(NTILE <= BPT * NT && SM::MMAX <= NT && NMAX <= NT, "threads per block / constraint row / variable");
+  int e0[BPT], e1[BPT], i0[BPT], j0[BPT];
+  bool owner[BPT], diag[BPT];
+#pragma unroll
+  for (int s = 0; s < BPT; ++s) {
+    const int t = tid + s * NT;
+    int ea = 0;
+    while (ea < NG - 1 && (ea + 1) * NG - (ea + 1) * ea / 2 <= t) ++ea;
+    owner[s] = t < NTILE;
+    e1[s] = owner[s] ? ea + (t - (ea * NG - ea * (ea - 1) / 2)) : 0;
+    e0[s] = owner[s] ? ea : 0;
+    diag[s] = (e0[s] == e1[s]);
+    i0[s] = GS * e0[s], j0[s] = GS * e1[s];
+  }
+  double a[BPT][GS][GS];
   if constexpr (SM::FULLBLK) {
     // H on the matrix cores, through the block-Toeplitz structure of B_qp.  With Phi_k = Acd^k Bcd,
     //     H(a,b) = 2 [ sum_{i >= b} Phi_{i-a}' S Phi_{i-b} + alpha delta_ab ]          (U x U block, steps a <= b)
@@ -665,8 +704,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       int off[4], vm[4];  // staging offset of the four rows this lane holds inside a block (or its spare word), 1/0
       float al[4];        // alpha on the diagonal entries of the diagonal chain, else 0
     };
-    auto setup = [&](int idx, Chain &C) {
-      C.live = idx < nchain;
+    int chain_lim = nchain, chain_dlo = 0;  // the chains of the current staging pass: idx < chain_lim, diagonals from chain_dlo
+    auto setup = [&](int idx, Chain &C) __attribute__((always_inline)) {
+      C.live = idx < chain_lim;
       const int ci = C.live ? idx : 0;
       C.d = ci / (TB * TB);
       const int ti = (ci / TB) % TB, tj = ci % TB;
@@ -682,7 +722,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         C.al[rg] = (ok && C.d == 0 && r == C.cb) ? in_al[r] : 0.0f;
       }
     };
-    auto fetch = [&](const Chain &C, int j, float (&o)[6]) {
+    auto fetch = [&](const Chain &C, int j, float (&o)[6]) __attribute__((always_inline)) {
       const bool la = C.av && j < C.len, lb = C.bv && j < C.len;
       const float *pa = A.Phi + (la ? (j + C.d) * PS + C.ra : 0) + kq * U;
       const float *pb = A.Phi + (lb ? j * PS + C.cb : 0) + kq * U;
@@ -691,16 +731,17 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       o[0] = la ? a0 : 0.0f, o[1] = la ? a1 : 0.0f, o[2] = la ? a2 : 0.0f;
       o[3] = lb ? b0 : 0.0f, o[4] = lb ? b1 : 0.0f, o[5] = lb ? b2 : 0.0f;
     };
-    auto store = [&](const Chain &C, int m, const f4 &acc) {
+    auto store = [&](const Chain &C, int m, const f4 &acc) __attribute__((always_inline)) {
       if (!(C.live && m < C.len)) return;              // uniform
       const int sb = h - 1 - m, sa = sb - C.d;          // the block this prefix of the chain is
-      const int base = (sa * h - sa * (sa - 1) / 2 + C.d) * UU;  // uniform
+      const int base = (SM::hs_off(C.d, h) - SM::hs_off(chain_dlo, h) + sa) * UU;  // uniform
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) A.Hs[base * C.vm[rg] + C.off[rg]] = 2.0f * (acc[rg] + C.al[rg]);
     };
     // two chains per pass (independent accumulators hide the MFMA dependency latency); the operands of step j+1 are
     // fetched while the matrix instructions of step j run
-    for (int idx = wv; idx < nchain; idx += 2 * NW) {
+    auto run_chains = [&](const int idx_lo, const int idx_hi) __attribute__((always_inline)) {
+    for (int idx = idx_lo + wv; idx < idx_hi; idx += 2 * NW) {
       Chain C0, C1;
       setup(idx, C0);
       setup(idx + NW, C1);
@@ -726,6 +767,59 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         for (int q2 = 0; q2 < 6; ++q2) c0[q2] = n0[q2], c1[q2] = n1[q2];
       }
     }
+    };  // run_chains
+    // Block (e0, e1) of the sweep order = leg-steps (sa, la) <= (sb, lb) (step-major); its entry (ii, jj) is the entry
+    // (r, c) = (comp(la, ii), comp(lb, jj)) of the staged U x U block (sa, sb), comp(l, k) = 3 l + k for the force and
+    // 3 NC + 3 l + k - 3 for the moment components -- read from the upper triangle in the reference order: when both
+    // leg-steps lie in the same horizon step, (r, c) with r > c is read at (c, r) (moment-of-la x force-of-lb entries, and
+    // the lower triangle of a diagonal block, which therefore comes out exactly symmetric).
+    auto load_blocks = [&](const int dlo, const int dhi) __attribute__((always_inline)) {  // blocks whose block-diagonal d = sb - sa lies in [dlo, dhi)
+#pragma unroll
+      for (int s = 0; s < BPT; ++s) {
+        const bool have = owner[s] && e1[s] < ng;
+        const int sa = have ? (int)S.ls_step[e0[s]] : 0, la = have ? (int)S.ls_leg[e0[s]] : 0;
+        const int sb = have ? (int)S.ls_step[e1[s]] : 0, lb = have ? (int)S.ls_leg[e1[s]] : 0;
+        const int dd = sb - sa;
+        // (a thread's slots that hold no live block are zero-filled in the first pass)
+        const bool in_pass = (SM::HSP == 1) ? true : (have ? (dd >= dlo && dd < dhi) : (dlo == 0));
+        if (!in_pass) continue;
+        const int base = (SM::hs_off(dd, h) - SM::hs_off(dlo, h) + sa) * (U * U);
+        const float *bN = A.Hs + (have ? base + 3 * la * U + 3 * lb : 0);  // + compR(ii) * U + compC(jj)
+        const float *bT = A.Hs + (have ? base + 3 * lb * U + 3 * la : 0);  // transposed position: + compC(jj) * U + compR(ii)
+        const bool same = (sa == sb);
+#pragma unroll
+        for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < GS; ++jj) {
+            constexpr int F = 3 * NC - 3;  // comp(l, k) - 3 l - k for a moment component
+            const int cr = (ii < 3) ? ii : F + ii, cc = (jj < 3) ? jj : F + jj;
+            const bool sw = (ii >= 3 && jj < 3) ? same : ((ii > jj) ? diag[s] : false);
+            const float v = sw ? bT[cc * U + cr] : bN[cr * U + cc];
+            a[s][ii][jj] = have ? (double)v : 0.0;
+          }
+      }
+    };
+    // staging passes: the chains of the pass's block-diagonals, then -- behind a barrier -- the register blocks (or the
+    // debug dump) that live on them
+#pragma unroll
+    for (int hp = 0; hp < SM::HSP; ++hp) {
+      const int dlo = SM::hs_dlo(hp) < h ? SM::hs_dlo(hp) : h, dhi = SM::hs_dlo(hp + 1) < h ? SM::hs_dlo(hp + 1) : h;
+      chain_dlo = dlo, chain_lim = dhi * TB * TB;
+      run_chains(dlo * TB * TB, dhi * TB * TB);
+      __syncthreads();
+      if constexpr (ASM_ONLY) {
+        using DL = DbgLayout<NMAX, NC>;
+        for (int t = tid; t < n * n; t += NT) {
+          const int i = t / n, j = t % n, lo = i < j ? i : j, hi = i < j ? j : i;  // reference order, upper triangle
+          const int sa = S.vstep[lo], sb = S.vstep[hi], dd = sb - sa;
+          if (dd >= dlo && dd < dhi)
+            args.dbg_f[DL::H + t] = A.Hs[(SM::hs_off(dd, h) - SM::hs_off(dlo, h) + sa) * U * U + S.vcomp[lo] * U + S.vcomp[hi]];
+        }
+      } else {
+        load_blocks(dlo, dhi);
+      }
+      if (hp + 1 < SM::HSP) __syncthreads();  // the next pass overwrites the staging area
+    }
   } else {
     // matrix cores: 16x16 output tiles over the reduced variables, K runs over (step i ascending, state row s ascending).
     // Rows of B_qp above the block diagonal are exact zeros, which are bitwise neutral in an fmaf chain started at +0,
@@ -742,7 +836,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       bool rav, cbv, live;
       int sa, ca, sb, cc, I, J;
     };
-    auto setup = [&](int idx, Tile &T) {
+    auto setup = [&](int idx, Tile &T) __attribute__((always_inline)) {
       T.live = idx < ntiles;
       int J = 0;
       while ((J + 1) * (J + 2) / 2 <= idx) ++J;
@@ -752,7 +846,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       T.sa = T.rav ? S.vstep[ra] : 0, T.ca = T.rav ? S.vcomp[ra] : 0;
       T.sb = T.cbv ? S.vstep[cb] : 0, T.cc = T.cbv ? S.vcomp[cb] : 0;
     };
-    auto fetch = [&](const Tile &T, int i, float (&o)[6]) {
+    auto fetch = [&](const Tile &T, int i, float (&o)[6]) __attribute__((always_inline)) {
       const bool la = T.rav && i >= T.sa, lb = T.cbv && i >= T.sb;
       const float *pa = A.Phi + (la ? (i - T.sa) * PS + T.ca : 0) + kq * U;
       const float *pb = A.Phi + (lb ? (i - T.sb) * PS + T.cc : 0) + kq * U;
@@ -761,7 +855,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       o[0] = la ? a0 : 0.0f, o[1] = la ? a1 : 0.0f, o[2] = la ? a2 : 0.0f;
       o[3] = lb ? b0 : 0.0f, o[4] = lb ? b1 : 0.0f, o[5] = lb ? b2 : 0.0f;
     };
-    auto store = [&](const Tile &T, const f4 &acc) {
+    auto store = [&](const Tile &T, const f4 &acc) __attribute__((always_inline)) {
       if (!T.live) return;
       // alpha enters on the diagonal only: looked up (two dependent LDS reads) by the diagonal lanes of diagonal tiles
       float al[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -804,8 +898,25 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       store(T0, acc0);
       store(T1, acc1);
     }
+    __syncthreads();
+    if constexpr (!ASM_ONLY) {
+    // register blocks from the folded upper triangle over the reduced variables (reference order)
+#pragma unroll
+    for (int s = 0; s < BPT; ++s)
+#pragma unroll
+      for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < GS; ++jj) {
+          const int i = i0[s] + ii, j = j0[s] + jj;
+          double v = 0.0;
+          if (i < n && j < n) {
+            const int oi = S.s2o[i], oj = S.s2o[j];
+            v = (double)A.Hs[hs_index<NMAX>(oi < oj ? oi : oj, oi < oj ? oj : oi)];
+          }
+          a[s][ii][jj] = v;
+        }
+    }
   }
-  __syncthreads();
 
   PROF_MARK(P_HG);
   if (ASM_ONLY) {
@@ -822,8 +933,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     for (int t = tid; t < n * n; t += NT) {
       const int i = t / n, j = t % n, lo = i < j ? i : j, hi = i < j ? j : i;  // reference order, upper triangle
       if constexpr (SM::FULLBLK) {
-        const int sa = S.vstep[lo], sb = S.vstep[hi];
-        o[DL::H + t] = A.Hs[(sa * h - sa * (sa - 1) / 2 + (sb - sa)) * U * U + S.vcomp[lo] * U + S.vcomp[hi]];
+        // (written pass by pass in stage A5)
       } else {
         o[DL::H + t] = A.Hs[hs_index<NMAX>(lo, hi)];
       }
@@ -854,72 +964,32 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // costs nothing: the published pivot row carries d - 1 in the pivot's own slot (d itself travels in Q.pd).
   // The pivot row for sweep k+1 is published to LDS right after sweep k (double buffered) -> one barrier per sweep; the six
   // sweeps of a leg-step are statically unrolled (static register indices).
-  constexpr int NTILE = NG * (NG + 1) / 2;
-  static_assert(NTILE <= NT && SM::MMAX <= NT && NMAX <= NT, "one thread per block / constraint row / variable");
   const bool is_v = tid < n, is_c = tid < m;
-  int e0 = 0;
-  while (e0 < NG - 1 && (e0 + 1) * NG - (e0 + 1) * e0 / 2 <= tid) ++e0;
-  const bool owner = tid < NTILE;
-  const int e1 = owner ? e0 + (tid - (e0 * NG - e0 * (e0 - 1) / 2)) : 0;
-  if (!owner) e0 = 0;
-  const bool diag = (e0 == e1);
-  const int i0 = GS * e0, j0 = GS * e1;
-  double a[GS][GS];
-  if constexpr (SM::FULLBLK) {
-    // Block (e0, e1) of the sweep order = leg-steps (sa, la) <= (sb, lb) (step-major); its entry (ii, jj) is the entry
-    // (r, c) = (comp(la, ii), comp(lb, jj)) of the staged U x U block (sa, sb), comp(l, k) = 3 l + k for the force and
-    // 3 NC + 3 l + k - 3 for the moment components -- read from the upper triangle in the reference order: when both
-    // leg-steps lie in the same horizon step, (r, c) with r > c is read at (c, r) (moment-of-la x force-of-lb entries, and
-    // the lower triangle of a diagonal block, which therefore comes out exactly symmetric).
-    const bool have = owner && e1 < ng;
-    const int sa = have ? (int)S.ls_step[e0] : 0, la = have ? (int)S.ls_leg[e0] : 0;
-    const int sb = have ? (int)S.ls_step[e1] : 0, lb = have ? (int)S.ls_leg[e1] : 0;
-    const int base = (sa * h - sa * (sa - 1) / 2 + (sb - sa)) * (U * U);
-    const float *bN = A.Hs + base + 3 * la * U + 3 * lb;  // + compR(ii) * U + compC(jj)
-    const float *bT = A.Hs + base + 3 * lb * U + 3 * la;  // transposed position: + compC(jj) * U + compR(ii)
-    const bool same = (sa == sb);
-#pragma unroll
-    for (int ii = 0; ii < GS; ++ii)
-#pragma unroll
-      for (int jj = 0; jj < GS; ++jj) {
-        constexpr int F = 3 * NC - 3;  // comp(l, k) - 3 l - k for a moment component
-        const int cr = (ii < 3) ? ii : F + ii, cc = (jj < 3) ? jj : F + jj;
-        const bool sw = (ii >= 3 && jj < 3) ? same : ((ii > jj) ? diag : false);
-        const float v = sw ? bT[cc * U + cr] : bN[cr * U + cc];
-        a[ii][jj] = have ? (double)v : 0.0;
-      }
-  } else {
-#pragma unroll
-    for (int ii = 0; ii < GS; ++ii)
-#pragma unroll
-      for (int jj = 0; jj < GS; ++jj) {
-        const int i = i0 + ii, j = j0 + jj;
-        double v = 0.0;
-        if (i < n && j < n) {
-          const int oi = S.s2o[i], oj = S.s2o[j];
-          v = (double)A.Hs[hs_index<NMAX>(oi < oj ? oi : oj, oi < oj ? oj : oi)];
-        }
-        a[ii][jj] = v;
-      }
-  }
+  // (the register blocks were loaded from the staging area of H at the end of stage A5)
   __syncthreads();  // every block is loaded before the solver state (which aliases the staging area) is written
   if (tid < NMAX) Q.piv[0][tid] = 0.0, Q.piv[1][tid] = 0.0;
   __syncthreads();
-  if (owner && e0 == 0) {
 #pragma unroll
-    for (int jj = 0; jj < GS; ++jj)
-      if (j0 + jj < n) Q.piv[0][j0 + jj] = a[0][jj];
-    if (diag) Q.piv[0][0] = a[0][0] - 1.0, Q.pd[0] = a[0][0];
-  }
+  for (int s = 0; s < BPT; ++s)
+    if (owner[s] && e0[s] == 0) {
+#pragma unroll
+      for (int jj = 0; jj < GS; ++jj)
+        if (j0[s] + jj < n) Q.piv[0][j0[s] + jj] = a[s][0][jj];
+      if (diag[s]) Q.piv[0][0] = a[s][0][0] - 1.0, Q.pd[0] = a[s][0][0];
+    }
   __syncthreads();
   // waves that hold no register block at all (the second wave of the 128-thread variants: 55 blocks) only keep the barriers
   constexpr int NW_OWN = (NTILE + 63) / 64;
   const bool wave_owns = (NW_OWN >= NW) || (wv < NW_OWN);  // scalar; compile-time true where every wave holds blocks
   for (int kb = 0; kb < ng; ++kb) {
-    const bool rowb = owner && (e0 == kb);      // my block holds matrix rows 6kb..6kb+5
-    const bool colb = owner && (e1 == kb);      // my block holds matrix columns 6kb..6kb+5
-    const bool rown = owner && (e0 == kb + 1);  // next leg-step's row / column blocks (publish at the seam)
-    const bool coln = owner && (e1 == kb + 1);
+    bool rowb[BPT], colb[BPT], rown[BPT], coln[BPT];
+#pragma unroll
+    for (int s = 0; s < BPT; ++s) {
+      rowb[s] = owner[s] && (e0[s] == kb);      // my block holds matrix rows 6kb..6kb+5
+      colb[s] = owner[s] && (e1[s] == kb);      // my block holds matrix columns 6kb..6kb+5
+      rown[s] = owner[s] && (e0[s] == kb + 1);  // next leg-step's row / column blocks (publish at the seam)
+      coln[s] = owner[s] && (e1[s] == kb + 1);
+    }
 #pragma unroll
     for (int kk = 0; kk < GS; ++kk) {
       const int k = kb * GS + kk;
@@ -927,54 +997,57 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       const double *pv = Q.piv[k & 1];
       double *pn = Q.piv[(k + 1) & 1];
       const double d = Q.pd[k & 1];
-      double pi[GS], pj[GS];
-#pragma unroll
-      for (int ii = 0; ii < GS; ii += 2) {
-        const double2 t2 = *reinterpret_cast<const double2 *>(pv + i0 + ii);
-        pi[ii] = t2.x, pi[ii + 1] = t2.y;
-      }
-#pragma unroll
-      for (int jj = 0; jj < GS; jj += 2) {
-        const double2 t2 = *reinterpret_cast<const double2 *>(pv + j0 + jj);
-        pj[jj] = t2.x, pj[jj + 1] = t2.y;
-      }
       // v_rcp_f64 is good to 2^-24 (scripts/micro/rcp64_accuracy.hip); one Newton step brings 2e-15, a second one would
       // bring the last bit -- not worth two more fp64 instructions per pivot here: the sweeps' own round-off (cond(H) eps
       // ~ 3e-10) is five orders above it and the substituted multipliers stay consistent with whatever invd is used
       double invd = __builtin_amdgcn_rcp(d);
       invd = dfma(dfma(-d, invd, 1.0), invd, invd);
-      double qi[GS];
 #pragma unroll
-      for (int ii = 0; ii < GS; ++ii) qi[ii] = pi[ii] * invd;
-      // (the published row carries d - 1 in the pivot's own slot: the threads that hold row k then find q_k = (d-1)/d = 1 - 1/d
-      //  and those that hold column k find p_k = d - 1 by themselves -- the substituted multipliers, without any select)
+      for (int s = 0; s < BPT; ++s) {
+        double pi[GS], pj[GS];
 #pragma unroll
-      for (int ii = 0; ii < GS; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < GS; ++jj) a[ii][jj] = dfma(-qi[ii], pj[jj], a[ii][jj]);
-      a[kk][kk] = (rowb && colb) ? -invd : a[kk][kk];
-      // publish row k+1 of the symmetric matrix: (k+1, j >= k+1) from its row blocks, (i < k+1, k+1) from its column blocks
-      if (kk + 1 < GS) {
-        if (rowb) {
-#pragma unroll
-          for (int jj = 0; jj < GS; ++jj)
-            if (!diag || jj >= kk + 1) pn[j0 + jj] = a[(kk + 1) % GS][jj];
-          if (diag) pn[j0 + (kk + 1) % GS] = a[(kk + 1) % GS][(kk + 1) % GS] - 1.0, Q.pd[(k + 1) & 1] = a[(kk + 1) % GS][(kk + 1) % GS];
+        for (int ii = 0; ii < GS; ii += 2) {
+          const double2 t2 = *reinterpret_cast<const double2 *>(pv + i0[s] + ii);
+          pi[ii] = t2.x, pi[ii + 1] = t2.y;
         }
-        if (colb) {
 #pragma unroll
-          for (int ii = 0; ii < GS; ++ii)
-            if (!diag || ii < kk + 1) pn[i0 + ii] = a[ii][(kk + 1) % GS];
+        for (int jj = 0; jj < GS; jj += 2) {
+          const double2 t2 = *reinterpret_cast<const double2 *>(pv + j0[s] + jj);
+          pj[jj] = t2.x, pj[jj + 1] = t2.y;
         }
-      } else if (kb + 1 < ng) {
-        if (rown) {
+        double qi[GS];
 #pragma unroll
-          for (int jj = 0; jj < GS; ++jj) pn[j0 + jj] = a[0][jj];
-          if (diag) pn[j0] = a[0][0] - 1.0, Q.pd[(k + 1) & 1] = a[0][0];
-        }
-        if (coln && !diag) {
+        for (int ii = 0; ii < GS; ++ii) qi[ii] = pi[ii] * invd;
+        // (the published row carries d - 1 in the pivot's own slot: the threads that hold row k then find q_k = (d-1)/d = 1 - 1/d
+        //  and those that hold column k find p_k = d - 1 by themselves -- the substituted multipliers, without any select)
 #pragma unroll
-          for (int ii = 0; ii < GS; ++ii) pn[i0 + ii] = a[ii][0];
+        for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < GS; ++jj) a[s][ii][jj] = dfma(-qi[ii], pj[jj], a[s][ii][jj]);
+        a[s][kk][kk] = (rowb[s] && colb[s]) ? -invd : a[s][kk][kk];
+        // publish row k+1 of the symmetric matrix: (k+1, j >= k+1) from its row blocks, (i < k+1, k+1) from its column blocks
+        if (kk + 1 < GS) {
+          if (rowb[s]) {
+#pragma unroll
+            for (int jj = 0; jj < GS; ++jj)
+              if (!diag[s] || jj >= kk + 1) pn[j0[s] + jj] = a[s][(kk + 1) % GS][jj];
+            if (diag[s]) pn[j0[s] + (kk + 1) % GS] = a[s][(kk + 1) % GS][(kk + 1) % GS] - 1.0, Q.pd[(k + 1) & 1] = a[s][(kk + 1) % GS][(kk + 1) % GS];
+          }
+          if (colb[s]) {
+#pragma unroll
+            for (int ii = 0; ii < GS; ++ii)
+              if (!diag[s] || ii < kk + 1) pn[i0[s] + ii] = a[s][ii][(kk + 1) % GS];
+          }
+        } else if (kb + 1 < ng) {
+          if (rown[s]) {
+#pragma unroll
+            for (int jj = 0; jj < GS; ++jj) pn[j0[s] + jj] = a[s][0][jj];
+            if (diag[s]) pn[j0[s]] = a[s][0][0] - 1.0, Q.pd[(k + 1) & 1] = a[s][0][0];
+          }
+          if (coln[s] && !diag[s]) {
+#pragma unroll
+            for (int ii = 0; ii < GS; ++ii) pn[i0[s] + ii] = a[s][ii][0];
+          }
         }
       }
       // every update of this sweep is complete before the barrier: the pivot-row temporaries die here instead of
@@ -982,9 +1055,11 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       // two sets of pivot-row registers alive: +30 VGPRs, the difference between two and three workgroups per CU)
 #if HMPC_PIN_SWEEP
 #pragma unroll
-      for (int ii = 0; ii < GS; ++ii)
+      for (int s = 0; s < BPT; ++s)
 #pragma unroll
-        for (int jj = 0; jj < GS; ++jj) asm volatile("" : "+v"(a[ii][jj]));
+        for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < GS; ++jj) asm volatile("" : "+v"(a[s][ii][jj]));
 #endif
       }  // wave_owns
       __syncthreads();
@@ -993,81 +1068,106 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // M = -a.  Diagonal blocks keep the full symmetric 6x6 (their lower triangle is overwritten with the mirror of the upper
   // one, so both halves are bit-identical); off-diagonal blocks hold M(e0,e1) and stand for M(e1,e0) transposed.
 #pragma unroll
-  for (int ii = 0; ii < GS; ++ii)
+  for (int s = 0; s < BPT; ++s) {
 #pragma unroll
-    for (int jj = 0; jj < GS; ++jj) a[ii][jj] = owner ? -a[ii][jj] : 0.0;
+    for (int ii = 0; ii < GS; ++ii)
 #pragma unroll
-  for (int ii = 1; ii < GS; ++ii)
+      for (int jj = 0; jj < GS; ++jj) a[s][ii][jj] = owner[s] ? -a[s][ii][jj] : 0.0;
 #pragma unroll
-    for (int jj = 0; jj < ii; ++jj) a[ii][jj] = diag ? a[jj][ii] : a[ii][jj];
+    for (int ii = 1; ii < GS; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < ii; ++jj) a[s][ii][jj] = diag[s] ? a[s][jj][ii] : a[s][ii][jj];
+  }
   PROF_MARK(P_SWEEP);
 
   // ---- products with the register blocks --------------------------------------------------------------------------
-  auto blk_rows = [&](const double (&wj)[GS], double (&ra)[GS]) {  // ra = a * wj        (result on leg-step e0)
+  auto blk_rows = [&](const int s, const double (&wj)[GS], double (&ra)[GS]) __attribute__((always_inline)) {  // ra = a[s] * wj   (result on leg-step e0)
 #pragma unroll
     for (int ii = 0; ii < GS; ++ii) {
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
       for (int jj = 0; jj < GS; jj += 2) {
-        s0 = dfma(a[ii][jj], wj[jj], s0);
-        s1 = dfma(a[ii][jj + 1], wj[jj + 1], s1);
+        s0 = dfma(a[s][ii][jj], wj[jj], s0);
+        s1 = dfma(a[s][ii][jj + 1], wj[jj + 1], s1);
       }
       ra[ii] = s0 + s1;
     }
   };
-  auto blk_cols = [&](const double (&wi)[GS], double (&ca)[GS]) {  // ca = a' * wi       (result on leg-step e1)
+  auto blk_cols = [&](const int s, const double (&wi)[GS], double (&ca)[GS]) __attribute__((always_inline)) {  // ca = a[s]' * wi  (result on leg-step e1)
 #pragma unroll
     for (int jj = 0; jj < GS; ++jj) {
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
       for (int ii = 0; ii < GS; ii += 2) {
-        s0 = dfma(a[ii][jj], wi[ii], s0);
-        s1 = dfma(a[ii + 1][jj], wi[ii + 1], s1);
+        s0 = dfma(a[s][ii][jj], wi[ii], s0);
+        s1 = dfma(a[s][ii + 1][jj], wi[ii + 1], s1);
       }
       ca[jj] = s0 + s1;
     }
   };
   // z = M w for a dense w in LDS (entries >= n exactly 0).  Every block writes its row partial to ST[e1][vars of e0]
   // and its mirrored partial to ST[e0][vars of e1]; variable i then sums ST[0..ng-1][i] in index order (deterministic).
-  auto rmatvec = [&](const double *w) {
-    if (owner && e1 < ng) {
-      double wi[GS], wj[GS], ra[GS], ca[GS];
+  auto rmatvec = [&](const double *w) __attribute__((always_inline)) {
+    // the partials are staged in STH halves of the source leg-steps (STH = 1: all at once); the running sums keep the
+    // same order either way: even sources into s0, odd ones into s1, ascending.  One block at a time, each product formed
+    // in the stage that stores it (row product: source e1, column product: source e0) -- nothing is held across a barrier.
+    double s0 = 0.0, s1 = 0.0;
+    constexpr int HB = NG / 2;
 #pragma unroll
-      for (int k = 0; k < GS; k += 2) {
-        const double2 t2 = *reinterpret_cast<const double2 *>(w + i0 + k);
-        const double2 u2 = *reinterpret_cast<const double2 *>(w + j0 + k);
-        wi[k] = t2.x, wi[k + 1] = t2.y, wj[k] = u2.x, wj[k + 1] = u2.y;
-      }
-      // one code path for every block: a diagonal block is stored as the full, exactly symmetric 6x6 and has wi == wj, so
-      // its two products are the same bits and its two stores hit the same words with the same values
-      blk_rows(wj, ra);
-      blk_cols(wi, ca);
+    for (int st = 0; st < SM::STH; ++st) {
+      const int lo = st * SM::STR;  // sources [lo, lo + STR) in this stage
 #pragma unroll
-      for (int k = 0; k < GS; k += 2) {
-        *reinterpret_cast<double2 *>(&Q.ST[e1][i0 + k]) = make_double2(ra[k], ra[k + 1]);
-        *reinterpret_cast<double2 *>(&Q.ST[e0][j0 + k]) = make_double2(ca[k], ca[k + 1]);
-      }
-    }
-    __syncthreads();
-    if (is_v) {
-      double s0 = 0.0, s1 = 0.0;
-      constexpr int HB = NG / 2;
+      for (int s = 0; s < BPT; ++s)
+        if (owner[s] && e1[s] < ng) {
+          const bool w1 = (SM::STH == 1) || (e1[s] >= lo && e1[s] < lo + SM::STR);
+          const bool w0 = (SM::STH == 1) || (e0[s] >= lo && e0[s] < lo + SM::STR);
+          // one code path for every block: a diagonal block is stored as the full, exactly symmetric 6x6 and has wi == wj, so
+          // its two products are the same bits and its two stores hit the same words with the same values
+          if (w1) {
+            double wj[GS], ra[GS];
 #pragma unroll
-      for (int hb = 0; hb < 2; ++hb) {
-        // rows >= ng of ST are never written: they are read all the same (one base address, immediate offsets -- a
-        // clamped row index costs one address register per row) and masked out by the selects below
-        double sv[HB];
+            for (int k = 0; k < GS; k += 2) {
+              const double2 u2 = *reinterpret_cast<const double2 *>(w + j0[s] + k);
+              wj[k] = u2.x, wj[k + 1] = u2.y;
+            }
+            blk_rows(s, wj, ra);
 #pragma unroll
-        for (int s = 0; s < HB; ++s) sv[s] = Q.ST[hb * HB + s][tid];
+            for (int k = 0; k < GS; k += 2)
+              *reinterpret_cast<double2 *>(&Q.ST[e1[s] - lo][i0[s] + k]) = make_double2(ra[k], ra[k + 1]);
+          }
+          if (w0) {
+            double wi[GS], ca[GS];
 #pragma unroll
-        for (int s = 0; s < HB; s += 2) {
-          s0 += (hb * HB + s < ng) ? sv[s] : 0.0;
-          if (s + 1 < HB) s1 += (hb * HB + s + 1 < ng) ? sv[s + 1] : 0.0;
+            for (int k = 0; k < GS; k += 2) {
+              const double2 t2 = *reinterpret_cast<const double2 *>(w + i0[s] + k);
+              wi[k] = t2.x, wi[k + 1] = t2.y;
+            }
+            blk_cols(s, wi, ca);
+#pragma unroll
+            for (int k = 0; k < GS; k += 2)
+              *reinterpret_cast<double2 *>(&Q.ST[e0[s] - lo][j0[s] + k]) = make_double2(ca[k], ca[k + 1]);
+          }
         }
+      __syncthreads();
+      if (is_v) {
+#pragma unroll
+        for (int hb = 0; hb < 2 / SM::STH; ++hb) {
+          // rows >= ng of ST are never written: they are read all the same (one base address, immediate offsets -- a
+          // clamped row index costs one address register per row) and masked out by the selects below
+          const int hbase = (SM::STH == 1) ? hb * HB : lo;  // first source of this group of HB rows
+          double sv[HB];
+#pragma unroll
+          for (int r = 0; r < HB; ++r) sv[r] = Q.ST[((SM::STH == 1) ? hb * HB : 0) + r][tid];
+#pragma unroll
+          for (int r = 0; r < HB; r += 2) {
+            s0 += (hbase + r < ng) ? sv[r] : 0.0;
+            if (r + 1 < HB) s1 += (hbase + r + 1 < ng) ? sv[r + 1] : 0.0;
+          }
+        }
+        if (st + 1 == SM::STH) Q.z[tid] = s0 + s1;
       }
-      Q.z[tid] = s0 + s1;
+      __syncthreads();
     }
-    __syncthreads();
   };
 
   // =============================== solver state ===============================
@@ -1117,7 +1217,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   bool c_ignored = false;  // this thread's row was found redundant at a degenerate vertex (violated by round-off only)
 
   // slack of this thread's constraint row on its tighter side at xv (unit-scaled); side = +1 lower, -1 upper
-  auto my_slack = [&](const double *xv, int &side, double &raw) -> double {
+  auto my_slack = [&](const double *xv, int &side, double &raw) __attribute__((always_inline)) -> double {
     double s0 = 0.0, s1 = 0.0;
     const double *xp = xv + GS * c_e;
 #pragma unroll
@@ -1133,7 +1233,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     return (sl <= ssu) ? sl : ssu;
   };
   // w_i = sum over the active rows of variable i's leg-step of coef(row) * a_row[i]  (+ extra)
-  auto gather_w = [&](const double *coefv, double sgn, double extra) {
+  auto gather_w = [&](const double *coefv, double sgn, double extra) __attribute__((always_inline)) {
     if (is_v) {
       const unsigned long long am = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * v_e]);
       const unsigned long long sm = *reinterpret_cast<const unsigned long long *>(&Q.slot[8 * v_e]);
@@ -1152,7 +1252,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     }
   };
   // rout[j] (+)= sum_i E(j,i) din[i] for j < q: 4 lanes per row, quad reduction; optional dual ratio test on the result
-  auto e_times = [&](const double *din, double *rout, bool accumulate, double &t1c, int &t1j, bool ratio) {
+  auto e_times = [&](const double *din, double *rout, bool accumulate, double &t1c, int &t1j, bool ratio) __attribute__((always_inline)) {
     for (int jb = 0; jb < q; jb += NT / 4) {
       const int j = jb + (tid >> 2), part = tid & 3;
       double acc = 0.0;
@@ -1184,7 +1284,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // Schur-complement downdate of E when slot l leaves (row/column l are read-only during the pass), then the last slot
   // moves into l.  Two barriers inside.
   // With follow_u the multipliers of the remaining rows follow the removal, u_R <- u_R - E(R,l) u_l / E(l,l)  (= E' d_R).
-  auto drop_slot = [&](int l, bool follow_u = false, double ul = 0.0) {
+  auto drop_slot = [&](int l, bool follow_u = false, double ul = 0.0) __attribute__((always_inline)) {
     const double iel = 1.0 / Eref(S, l, l);
     const int ti = tid >> 4, tj = tid & 15;
     if (follow_u && tid < q && tid != l) Q.u[tid] = dfma(-(Eref(S, tid, l) * iel), ul, Q.u[tid]);
@@ -1220,7 +1320,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     __syncthreads();
   };
   // d[slot] = b_j - n_j' x for the active rows (n_j = sign*a_j, b_j = sign*bound)
-  auto active_residual = [&](const double *xv) {
+  auto active_residual = [&](const double *xv) __attribute__((always_inline)) {
     if (is_c) {
       const int ac = Q.act[tid];
       if (ac != 0) {
@@ -1244,7 +1344,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     bool take = false;
     bool tick = false;  // the candidates come from the previous tick's working set (any of the 8 rows of a leg-step)
     int base = 0, k0 = 0, below = 0;
-    auto count_candidates = [&]() {
+    auto count_candidates = [&]() __attribute__((always_inline)) {
       const unsigned long long bal = __ballot(take);
       below = __popcll(bal & ((1ull << ln) - 1ull));
       if (ln == 0) Q.wcount[wv] = __popcll(bal);
@@ -1266,11 +1366,12 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     // walking: ~1.6 iterations per solve, nothing to gain; 120 variables: two rounds (a third one is worth <1 % there and its
     // third copy of the phase tips the register allocation of the 168-VGPR variant over: 86 spilled registers, 1.43 -> 1.78 ms);
     // three contacts: three (1.13 -> 1.18 M solves/s over two)
-    constexpr int BLOCK_ROUNDS = (NT >= 512) ? HMPC_BLOCK_ROUNDS_3C : ((NT >= 256) ? HMPC_BLOCK_ROUNDS : 1);
+    constexpr int BLOCK_ROUNDS = (NC == 3) ? HMPC_BLOCK_ROUNDS_3C : ((NT >= 256) ? HMPC_BLOCK_ROUNDS : 1);
     constexpr bool BLOCK_FRICTION = HMPC_BLOCK_FRICTION && NT >= 256;
-    constexpr int BLOCK_MIN_NEW = (NT >= 512) ? HMPC_BLOCK_MIN_NEW_3C : HMPC_BLOCK_MIN_NEW;
-    constexpr int EPT = 5;  // packed-triangle entries per thread during the Schur inversion
-    constexpr int KBMAX = (NT >= 512) ? 71 : ((NT >= 256) ? 45 : 34);  // KBMAX(KBMAX+1)/2 <= EPT*NT
+    constexpr int BLOCK_MIN_NEW = (NC == 3) ? HMPC_BLOCK_MIN_NEW_3C : HMPC_BLOCK_MIN_NEW;
+    constexpr int EPT = (NC == 3 && NT < 512) ? HMPC_EPT_3C : 5;  // packed-triangle entries per thread during the Schur inversion
+    constexpr int KBMAX_3C = (HMPC_EPT_3C >= 8) ? 63 : ((HMPC_EPT_3C == 7) ? 59 : 54);
+    constexpr int KBMAX = (NT >= 512) ? 71 : ((NT >= 256) ? (NC == 3 ? (KBMAX_3C < SM::QMAX ? KBMAX_3C : SM::QMAX) : 45) : 34);  // KBMAX(KBMAX+1)/2 <= EPT*NT
     static_assert(KBMAX * (KBMAX + 1) / 2 <= EPT * NT && KBMAX <= SM::QMAX, "block start capacity");
     // (one round as a lambda instantiated once per round rather than a loop: with the loop the register allocator keeps
     //  ~50 more VGPRs alive across the whole phase -- measured 185 -> 244 on the unconstrained variants)
@@ -1335,26 +1436,28 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     __syncthreads();
     if (k0 > 0) {
       // (b) S0(i,j) = n_i' M n_j: rows of leg-steps (e0, e1) meet only in my block
-      if (owner && e1 < ng) {
-        const unsigned long long am0 = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * e0]);
-        const unsigned long long am1 = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * e1]);
+#pragma unroll
+      for (int s = 0; s < BPT; ++s)
+      if (owner[s] && e1[s] < ng) {
+        const unsigned long long am0 = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * e0[s]]);
+        const unsigned long long am1 = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * e1[s]]);
         if (am0 != 0ull && am1 != 0ull) {
-          const int leg0 = S.ls_leg[e0], leg1 = S.ls_leg[e1];
+          const int leg0 = S.ls_leg[e0[s]], leg1 = S.ls_leg[e1[s]];
           for (int r1 = rlo; r1 <= rhi; ++r1) {
             const int ac1 = (int)(signed char)((am1 >> (8 * r1)) & 0xff);
             if (ac1 == 0) continue;
             double cn1[GS], t6[GS];
 #pragma unroll
             for (int k = 0; k < GS; ++k) cn1[k] = (double)ac1 * S.Cn[leg1][r1][k];
-            blk_rows(cn1, t6);  // (a diagonal block is stored as the full symmetric 6x6)
-            const int s1 = Q.slot[8 * e1 + r1];
-            for (int r0 = rlo; r0 <= (diag ? r1 : rhi); ++r0) {
+            blk_rows(s, cn1, t6);  // (a diagonal block is stored as the full symmetric 6x6)
+            const int s1 = Q.slot[8 * e1[s] + r1];
+            for (int r0 = rlo; r0 <= (diag[s] ? r1 : rhi); ++r0) {
               const int ac0 = (int)(signed char)((am0 >> (8 * r0)) & 0xff);
               if (ac0 == 0) continue;
               double v = 0.0;
 #pragma unroll
               for (int k = 0; k < GS; ++k) v = dfma((double)ac0 * S.Cn[leg0][r0][k], t6[k], v);
-              Eref(S, Q.slot[8 * e0 + r0], s1) = v;
+              Eref(S, Q.slot[8 * e0[s] + r0], s1) = v;
             }
           }
         }
@@ -1389,7 +1492,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         //     A(K,K) <- -G,   A(i,K) <- P_i G,   A(i,j) <- A(i,j) - P_i G P_j'      with P_i = [A(i,s), A(i,s+1)].
         // The two pivot columns of the next step are published right after the update (two pairs of LDS vectors,
         // alternating); an odd last pivot takes one scalar sweep.
-        auto publish = [&](double *buf, int c, int i, int j, double v) {
+        auto publish = [&](double *buf, int c, int i, int j, double v) __attribute__((always_inline)) {
           if (j == c) buf[i] = v;
           else if (i == c) buf[j] = v;
         };
@@ -1622,16 +1725,18 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         // (2) d_j = n_j' M n+ for the active rows: the rows of leg-step eo meet n+ (on leg-step ep) only in block
         //     (min(eo,ep), max(eo,ep)), whose owner forms t = M(eo,ep) n+ once and dots it with each active row;
         //     the diagonal block also gives gamma = n+' M n+
-        if (owner && e1 < ng && (e0 == ep || e1 == ep)) {
+#pragma unroll
+        for (int s = 0; s < BPT; ++s)
+        if (owner[s] && e1[s] < ng && (e0[s] == ep || e1[s] == ep)) {
           // t = M(eo, ep) n+: the row product when ep is this block's column leg-step (and on the diagonal), the column
           // product otherwise; both are formed (no divergence inside the wave) and one is kept
           double t6[GS], tc[GS];
-          blk_rows(np, t6);
-          blk_cols(np, tc);
-          const bool use_rows = (e1 == ep);
+          blk_rows(s, np, t6);
+          blk_cols(s, np, tc);
+          const bool use_rows = (e1[s] == ep);
 #pragma unroll
           for (int k = 0; k < GS; ++k) t6[k] = use_rows ? t6[k] : tc[k];
-          const int eo = (e0 == ep) ? e1 : e0;
+          const int eo = (e0[s] == ep) ? e1[s] : e0[s];
           const int lego = S.ls_leg[eo];
           const unsigned long long am = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * eo]);
           const unsigned long long sm = *reinterpret_cast<const unsigned long long *>(&Q.slot[8 * eo]);
@@ -1647,7 +1752,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
               }
             }
           }
-          if (diag) {
+          if (diag[s]) {
             double gm = 0.0;
 #pragma unroll
             for (int k = 0; k < GS; ++k) gm = dfma(np[k], t6[k], gm);
