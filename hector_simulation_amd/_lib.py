@@ -17,7 +17,7 @@ EXPORTS = [
     "hmpc_build_records", "hmpc_build_records_device", "hmpc_body_wrench", "hmpc_body_wrench_device", "hmpc_leg_torques", "hmpc_leg_torques_device",
     "hmpc_download_records", "hmpc_debug_assemble", "hmpc_debug_phase_cycles", "hmpc_download_f64", "hmpc_last_hip_error", "hmpc_version",
     "hmpc_upload_records_async", "hmpc_download_async", "hmpc_set_tick_warm_start", "hmpc_reset_tick_warm_start", "hmpc_create_ex", "hmpc_contacts", "hmpc_record_stride_ex", "hmpc_pack_record_ex",
-    "hmpc_enable_f64_output", "hmpc_set_device_repair", "hmpc_group_set_exchange_repair",
+    "hmpc_enable_f64_output", "hmpc_debug_solve_external_qp", "hmpc_set_device_repair", "hmpc_group_set_exchange_repair",
     "hmpc_shard_bounds", "hmpc_group_create", "hmpc_group_destroy", "hmpc_group_size", "hmpc_group_transport",
     "hmpc_group_batch", "hmpc_group_member", "hmpc_group_upload_records", "hmpc_group_set_device_records",
     "hmpc_group_solve", "hmpc_group_post_gather", "hmpc_group_wait_gather", "hmpc_group_device_gathered",
@@ -126,6 +126,7 @@ def load():
     L.hmpc_leg_torques.argtypes = [vp, vp, vp, vp, vp]
     L.hmpc_leg_torques_device.argtypes = [vp, vp, vp, vp, vp, vp]
     L.hmpc_enable_f64_output.argtypes = [vp]
+    L.hmpc_debug_solve_external_qp.argtypes = [vp, vp, vp, vp, ci]
     L.hmpc_shard_bounds.argtypes = [ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]
     L.hmpc_group_create.argtypes = [C.POINTER(vp), C.POINTER(ProblemSetup), vp, ci, ci, ci]
     for name in ("hmpc_group_destroy", "hmpc_group_size", "hmpc_group_transport", "hmpc_group_batch", "hmpc_group_solve",

@@ -116,6 +116,9 @@ struct hmpc_handle {
   int device_repair;
   int *d_flag_list;
   unsigned int *d_flag_count;
+  // parity hook (hmpc_debug_solve_external_qp): device copies of caller-supplied QP data, only set during that call
+  const float *d_ext_H, *d_ext_g, *d_ext_Fc;
+  int ext_ld;
 };
 constexpr int REPAIR_GRID_CAP = 2048;  // workgroups of the device-side safe launch = most instances it can repair per solve
 
@@ -209,6 +212,7 @@ static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int db
   a.flag_count = record_flagged ? h->d_flag_count : nullptr;
   a.flag_cap = record_flagged ? (h->max_batch < REPAIR_GRID_CAP ? h->max_batch : REPAIR_GRID_CAP) : 0;
   a.list_count = d_list_count;
+  a.ext_H = h->d_ext_H, a.ext_g = h->d_ext_g, a.ext_Fc = h->d_ext_Fc, a.ext_ld = h->ext_ld;
   const int grid = assemble_only ? 1 : (d_index_list ? n_list : h->batch);
   if (grid < 1) return HMPC_OK;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(v.nt), v.smem, stream, a);
@@ -615,6 +619,36 @@ int hmpc_debug_assemble(hmpc_handle *h, int index, int *n, int *m, int *var_ind,
   if (x0) memcpy(x0, hf.data() + oX0, sizeof(float) * 13);
   if (Acd) memcpy(Acd, hf.data() + oACD, sizeof(float) * 169);
   if (Bcd) memcpy(Bcd, hf.data() + oBCD, sizeof(float) * 78 * nc);
+  return HMPC_OK;
+}
+
+// Parity hook: stages S, W, Q of the kernel (inverse by sweeps, block start, dual active set, scatter) on QP data handed
+// in from outside -- e.g. the reference's own H_red / g_red / fmat as its source left them -- instead of the kernel's own
+// assembly.  The current batch's records still provide the gait tables (which leg-steps exist) and f_max.
+int hmpc_debug_solve_external_qp(hmpc_handle *h, const float *H, const float *g, const float *Fc, int ld) {
+  if (!h || !H || !g || !Fc || ld < 1) return HMPC_E_ARG;
+  if (h->batch == 0) return HMPC_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
+  const size_t nb = (size_t)h->batch, nfc = (size_t)8 * h->nc * 6 * h->nc;
+  const size_t bytes = sizeof(float) * nb * ((size_t)ld * ld + ld + nfc);
+  float *d = nullptr;
+  HIP_TRY(hipMalloc(&d, bytes));
+  struct Free {
+    float *p;
+    ~Free() { (void)hipFree(p); }
+  } guard{d};
+  float *dH = d, *dg = dH + nb * ld * ld, *dF = dg + nb * ld;
+  HIP_TRY(hipMemcpy(dH, H, sizeof(float) * nb * ld * ld, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dg, g, sizeof(float) * nb * ld, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dF, Fc, sizeof(float) * nb * nfc, hipMemcpyHostToDevice));
+  h->d_ext_H = dH, h->d_ext_g = dg, h->d_ext_Fc = dF, h->ext_ld = ld;
+  const int rc = launch(h, h->last_stream, false, 0, nullptr, 0, 0.0, -1, /*carry_wset=*/false);
+  hipError_t e = hipStreamSynchronize(h->last_stream);
+  h->d_ext_H = h->d_ext_g = h->d_ext_Fc = nullptr;
+  h->ext_ld = 0;
+  if (rc != HMPC_OK) return rc;
+  HIP_TRY(e);
   return HMPC_OK;
 }
 

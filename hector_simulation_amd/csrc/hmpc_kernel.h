@@ -68,6 +68,13 @@ struct KernelArgs {
   unsigned int *flag_count;
   int flag_cap;
   const unsigned int *list_count;
+  // Parity hook (hmpc_debug_solve_external_qp): QP data handed in instead of assembled -- per instance the reduced Hessian
+  // [ext_ld][ext_ld] and gradient [ext_ld] in the reference's reduced order (binary32 values, as the reference's own H_red /
+  // g_red are widened floats; the upper triangle is read) and the per-step constraint block [8 NC][6 NC]
+  // (SolverMPC.cpp:466-548 fmat).  The record still supplies the gait table (structure) and f_max; stages S, W, Q run
+  // unchanged.  nullptr = off (the product path).
+  const float *ext_H, *ext_g, *ext_Fc;
+  int ext_ld;
 };
 constexpr int NPROF = 32;
 enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A, P_A0, P_A1, P_A2, P_G };
@@ -531,6 +538,15 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         }
     }
   }
+  if (args.ext_Fc) {  // uniform.  Parity hook: the constraint block comes from outside (after the lanes above have written theirs)
+    __syncthreads();
+    const float *xf = args.ext_Fc + (size_t)inst * C8 * U;
+    for (int t = tid; t < C8 * U; t += NT) A.Fc[t] = xf[t];
+    for (int t = tid; t < NC * 8 * 6; t += NT) {
+      const int leg = t / 48, rr = (t / 6) % 8, k = t % 6;
+      S.Cn[leg][rr][k] = (double)xf[(8 * leg + rr) * U + ((k < 3) ? 3 * leg + k : 3 * NC + 3 * leg + k - 3)];
+    }
+  }
   {
     // index tables, one work item per (step, leg, k): two orders of the surviving variables --
     //  reference order (ascending original index, SolverMPC.cpp:644-658): used to build H, g bit-identically;
@@ -657,7 +673,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
 #pragma unroll
       for (int s = 0; s < 13; ++s) acc = ffma(A.W[s] * sp[s * U], ep[s], acc);  // (B'S) first: fl(w_s Phi), then the chain
     }
-    S.g[S.o2s[tid]] = (double)(2.0f * acc);
+    S.g[S.o2s[tid]] = args.ext_g ? (double)args.ext_g[(size_t)inst * args.ext_ld + tid] : (double)(2.0f * acc);
   }
   PROF_MARK(P_G);
   // ---- register blocks of the sweeps (stage S): thread t owns the 6x6 blocks number t, t + NT, ... (< NG(NG+1)/2) of the
@@ -807,6 +823,18 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       chain_dlo = dlo, chain_lim = dhi * TB * TB;
       run_chains(dlo * TB * TB, dhi * TB * TB);
       __syncthreads();
+      if (args.ext_H) {  // uniform.  Parity hook: the staged entries of the surviving variables are replaced by the caller's
+        const float *xh = args.ext_H + (size_t)inst * args.ext_ld * args.ext_ld;
+        for (int t = tid; t < n * n; t += NT) {
+          const int i = t / n, j = t % n;
+          if (i <= j) {
+            const int sa = S.vstep[i], sb = S.vstep[j], dd = sb - sa;
+            if (dd >= dlo && dd < dhi)
+              A.Hs[(SM::hs_off(dd, h) - SM::hs_off(dlo, h) + sa) * U * U + S.vcomp[i] * U + S.vcomp[j]] = xh[i * args.ext_ld + j];
+          }
+        }
+        __syncthreads();
+      }
       if constexpr (ASM_ONLY) {
         using DL = DbgLayout<NMAX, NC>;
         for (int t = tid; t < n * n; t += NT) {
@@ -899,6 +927,14 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       store(T1, acc1);
     }
     __syncthreads();
+    if (args.ext_H) {  // uniform.  Parity hook, folded layout
+      const float *xh = args.ext_H + (size_t)inst * args.ext_ld * args.ext_ld;
+      for (int t = tid; t < n * n; t += NT) {
+        const int i = t / n, j = t % n;
+        if (i <= j) A.Hs[hs_index<NMAX>(i, j)] = xh[i * args.ext_ld + j];
+      }
+      __syncthreads();
+    }
     if constexpr (!ASM_ONLY) {
     // register blocks from the folded upper triangle over the reduced variables (reference order)
 #pragma unroll

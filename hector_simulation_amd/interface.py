@@ -159,6 +159,16 @@ class BatchedMPC:
         _check(self.L.hmpc_download_f64(self.h, x.ctypes.data, obj.ctypes.data), "hmpc_download_f64")
         return x, obj
 
+    def solve_external_qp(self, H: np.ndarray, g: np.ndarray, Fc: np.ndarray) -> None:
+        """Parity hook (hmpc_debug_solve_external_qp): solver stages on caller-supplied QP data; H [batch, ld, ld] and
+        g [batch, ld] in the reference's reduced order, Fc [batch, 8 nc, 6 nc]."""
+        H = np.ascontiguousarray(H, dtype=np.float32)
+        g = np.ascontiguousarray(g, dtype=np.float32)
+        Fc = np.ascontiguousarray(Fc, dtype=np.float32)
+        assert H.shape[0] == self.batch and H.shape[1] == H.shape[2] == g.shape[1]
+        _check(self.L.hmpc_debug_solve_external_qp(self.h, H.ctypes.data, g.ctypes.data, Fc.ctypes.data, H.shape[1]),
+               "hmpc_debug_solve_external_qp")
+
     # ---- rows either side of the solve (SURVEY.md section 8f)
     def build_records(self, ticks: np.ndarray, dt_mpc: float):
         """f1+f2 on the device: ticks = structured array with dtype ``TICK_DTYPE``; returns the clamped

@@ -236,6 +236,13 @@ int hmpc_debug_assemble(hmpc_handle *h, int index, int *n, int *m, int *var_ind,
  * hmpc_enable_f64_output (before the solve) makes every later solve write them; without it hmpc_download_f64 enables
  * the copy-out and runs the current batch once more (flagged instances get the safe pass of hmpc_download). */
 int hmpc_enable_f64_output(hmpc_handle *h);
+/* Parity hook: runs the SOLVER stages of the kernel (inverse, block start, dual active set, scatter) for the current batch
+ * on QP data handed in from outside instead of the kernel's own assembly: per instance the reduced Hessian H[ld][ld] and
+ * gradient g[ld] in the reference's reduced order (SolverMPC.cpp:644-697; binary32 values -- the reference's H_red / g_red
+ * are widened floats; the upper triangle of H is read) and the per-step constraint block Fc[16][12] (fmat,
+ * SolverMPC.cpp:466-548; [24][18] with three contacts).  The records of the current batch still supply the gait tables and
+ * f_max.  Forces/status are written as by hmpc_solve.  tests/test_reference_source.py feeds it the reference's own data. */
+int hmpc_debug_solve_external_qp(hmpc_handle *h, const float *H, const float *g, const float *Fc, int ld);
 int hmpc_download_f64(hmpc_handle *h, double *x, double *obj);
 
 /* Developer hook (only in builds with -DHMPC_PROFILE, scripts/phase_profile.py): per-phase shader-clock cycles of
