@@ -34,6 +34,9 @@ thread_local std::string g_hip_err;
 #ifndef HMPC_QCAP_FAST
 #define HMPC_QCAP_FAST 64  // working-set capacity of the fast 120-variable h <= 10 variant (49 KB LDS: three per CU)
 #endif
+#ifndef HMPC_QCAP_WIDE
+#define HMPC_QCAP_WIDE 128 // ... of the 240-variable variant (double support over h = 11 .. 20)
+#endif
 #ifndef HMPC_QCAP_3C
 #define HMPC_QCAP_3C 80    // ... of the fast three-contact variant (256 threads, two register blocks each, <= 80 KB LDS: two per CU)
 #endif
@@ -56,7 +59,7 @@ struct Variant {
 template <int NMAX, int HMAX, int NT, int QCAP, int NC = 2, int BPT = 1>
 Variant make_variant() {
   static_assert(sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>) <= 160 * 1024, "LDS budget of a gfx950 CU");
-  static_assert(BPT == 1 || sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>) <= 80 * 1024, "two workgroups per CU");
+  static_assert(BPT == 1 || NT >= 512 || sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>) <= 80 * 1024, "two workgroups per CU");
   return Variant{NMAX, HMAX, NT, QCAP, NC, hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, false, NC, BPT>,
                  hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, true, NC, BPT>, sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>),
                  hmpc::DbgLayout<NMAX, NC>::TOTAL};
@@ -67,16 +70,19 @@ const Variant *variants() {
                               make_variant<60, 20, 128, 60>(),   make_variant<120, 20, 256, HMPC_QCAP_FAST>(),
                               make_variant<120, 10, 256, 120>(), make_variant<120, 20, 256, 120>(),
                               make_variant<180, 10, 256, HMPC_QCAP_3C, 3, 2>(), make_variant<180, 10, 512, 140, 3>(),
-                              make_variant<180, 10, 512, 100, 3>()};
+                              make_variant<180, 10, 512, 100, 3>(), make_variant<240, 20, 512, HMPC_QCAP_WIDE, 2, 2>()};
   return v;
 }
 constexpr int N_FAST = 4;       // two-contact fast variants [0, N_FAST), their safe variants N_FAST + (h > 10)
 constexpr int V3_FAST = 6, V3_SAFE = 7, V3_FAST_512 = 8;  // (V3_FAST_512: the one-workgroup-per-CU variant of round 2, HMPC_3C_512=1)
-constexpr int N_VARIANTS = 9;
-constexpr int MAX_VARS_ANY = 180;
-constexpr int DBG_FLOATS_MAX = hmpc::DbgLayout<180, 3>::TOTAL > hmpc::DbgLayout<120, 2>::TOTAL
-                                   ? hmpc::DbgLayout<180, 3>::TOTAL
-                                   : hmpc::DbgLayout<120, 2>::TOTAL;
+// double support over more than ten steps (two contacts, 121 .. 240 reduced variables, h <= 20): 820 register blocks on 512
+// threads, two each, one workgroup per CU; working set up to HMPC_QCAP_WIDE rows (what 160 KB of LDS leave room for).
+constexpr int V2_WIDE = 9;
+constexpr int N_VARIANTS = 10;
+constexpr int MAX_VARS_ANY = 240;
+constexpr int DBG_FLOATS_MAX = hmpc::DbgLayout<240, 2>::TOTAL > hmpc::DbgLayout<180, 3>::TOTAL
+                                   ? hmpc::DbgLayout<240, 2>::TOTAL
+                                   : hmpc::DbgLayout<180, 3>::TOTAL;
 
 int fixed_floats(int nc) { return nc == 3 ? 73 : 54; }
 size_t record_stride(int h, int nc = 2) { return (size_t)(((fixed_floats(nc) + 12 * h) * 4 + nc * h + 15) / 16 * 16); }
@@ -157,6 +163,10 @@ static const Variant &pick_variant(const hmpc_handle *h, int *index) {
     if (index) *index = vi3;
     return v[vi3];
   }
+  if (h->max_stance > HMPC_MAX_VARS && hz > 10) {  // double support beyond ten steps: the wide variant
+    if (index) *index = V2_WIDE;
+    return v[V2_WIDE];
+  }
   int best = -1;
   for (int i = 0; i < N_FAST; ++i) {
     if (v[i].hmax < hz) continue;
@@ -176,10 +186,10 @@ static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int db
                   const unsigned int *d_list_count = nullptr, bool record_flagged = false) {
   int vi = 0;
   const Variant *pv = &pick_variant(h, &vi);
-  if (d_index_list) {  // safe variant: working set as large as the variable count
+  if (d_index_list && vi != V2_WIDE) {  // safe variant: working set as large as the variable count
     vi = (h->nc == 3) ? V3_SAFE : ((h->setup.horizon <= 10) ? N_FAST : N_FAST + 1);
     pv = &variants()[vi];
-  }
+  }  // (the wide variant is its own safe pass: cold start, same working-set capacity -- LDS has no room for more)
   const Variant &v = *pv;
   kernel_fn fn = assemble_only ? v.assemble : v.solve;
   if (!h->attrs_set[vi]) {

@@ -25,6 +25,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <type_traits>
+
 #ifndef HMPC_REFINE
 #define HMPC_REFINE 1  // corrections u += E (b_W - N_W x(u)) applied to the multipliers of the final working set
 #endif
@@ -129,7 +131,7 @@ struct Smem {
                                               : (hs_off(HS_D0, HMAX) > HMAX * (HMAX + 1) / 2 - hs_off(HS_D0, HMAX)
                                                      ? hs_off(HS_D0, HMAX) : HMAX * (HMAX + 1) / 2 - hs_off(HS_D0, HMAX));
   // staged mat-vec: partials of STH halves of the source leg-steps at a time (ST has NG / STH rows)
-  static constexpr int STH = (NC == 3 && BPT == 2) ? 2 : 1;
+  static constexpr int STH = (BPT == 2) ? 2 : 1;
   static constexpr int STR = NG / STH;
   static_assert(NG % 2 == 0 && (STH == 1 || STH == 2), "the staged mat-vec sums two groups of NG/2 source leg-steps");
 
@@ -182,7 +184,8 @@ struct Smem {
     alignas(8) signed char act[MMAX];
     alignas(8) unsigned char slot[MMAX];
     unsigned char flpc[MMAX];  // row has already been switched to its other bound once by the block start
-    unsigned char Wrow[NMAX];
+    typedef typename std::conditional<(MMAX > 256), unsigned short, unsigned char>::type row_t;
+    row_t Wrow[NMAX];  // working-set slot -> constraint row
     double Ep[QMAX * (QMAX + 1) / 2];  // E = (N_W M N_W')^-1, packed lower triangle: E(i,j), i>=j, at i(i+1)/2 + j
   };
   union {
@@ -1040,6 +1043,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       invd = dfma(dfma(-d, invd, 1.0), invd, invd);
 #pragma unroll
       for (int s = 0; s < BPT; ++s) {
+        if (s > 0 && ub(s * NT + wv * 64 >= NTILE)) continue;  // no lane of this wave holds a block in this slot
         double pi[GS], pj[GS];
 #pragma unroll
         for (int ii = 0; ii < GS; ii += 2) {
@@ -1347,7 +1351,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       Q.act[cl] = 0;
       if (l != last) {
         const int cm = Q.Wrow[last];
-        Q.Wrow[l] = (unsigned char)cm;
+        Q.Wrow[l] = (typename SM::Sol::row_t)cm;
         Q.slot[cm] = (unsigned char)l;
         Q.u[l] = Q.u[last];
       }
@@ -1467,7 +1471,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       const int sl = in ? base + below : 0;
       Q.act[tid] = in ? (signed char)side : (signed char)0;
       Q.slot[tid] = (unsigned char)sl;
-      if (in) Q.Wrow[sl] = (unsigned char)tid;
+      if (in) Q.Wrow[sl] = (typename SM::Sol::row_t)tid;
     }
     __syncthreads();
     if (k0 > 0) {
@@ -1870,7 +1874,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
           if (tid == q) {
             Q.Ep[q * (q + 1) / 2 + q] = idl;
             Q.u[q] = up;
-            Q.Wrow[q] = (unsigned char)p;
+            Q.Wrow[q] = (typename SM::Sol::row_t)p;
             Q.act[p] = (signed char)sgi;
             Q.slot[p] = (unsigned char)q;
           }

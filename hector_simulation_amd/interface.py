@@ -209,7 +209,7 @@ class BatchedMPC:
     def debug_assemble(self, index: int) -> dict:
         """Assembly stage only (same device code the solve kernel runs) -> the reduced QP as the solver sees it."""
         h, nc = self.horizon, self.contacts
-        nmax = 60 * nc
+        nmax = 180 if nc == 3 else 240  # HMPC_MAX_VARS_3C / HMPC_MAX_VARS_WIDE
         n, m = C.c_int(0), C.c_int(0)
         var_ind = np.zeros(nmax, dtype=np.int32)
         H = np.zeros(nmax * nmax, dtype=np.float32)

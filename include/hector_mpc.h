@@ -31,7 +31,9 @@ extern "C" {
 
 #define K_MAX_GAIT_SEGMENTS 36 /* convexMPC_interface.h:3 */
 #define HMPC_MAX_HORIZON 20    /* device scratch is sized for this (reference: 10 hard-coded, cap 19) */
-#define HMPC_MAX_VARS 120      /* reduced QP variables (6 per stance leg-step) the on-chip solver holds (two contacts; 180 with three) */
+#define HMPC_MAX_VARS 120      /* reduced QP variables (6 per stance leg-step) the fast on-chip variants hold (two contacts; 180 with three) */
+#define HMPC_MAX_VARS_WIDE 240 /* ... the wide variant (double support over h = 11 .. 20): picked when the batch needs it -- from the gait
+                                  tables of host-uploaded records, or hmpc_set_max_reduced_vars for device-resident ones */
 
 /* ---- reference PODs (convexMPC_interface.h:11-37), same field order and types ---- */
 struct problem_setup {
@@ -95,7 +97,8 @@ enum hmpc_status_code {
   HMPC_S_OK = 0,
   HMPC_S_MAXITER = 1,     /* iteration cap hit (reference analogue: nWSR = 500 exhausted) */
   HMPC_S_INFEASIBLE = 2,  /* constraints inconsistent */
-  HMPC_S_TOO_LARGE = 3,   /* more than HMPC_MAX_VARS reduced variables (e.g. double support over h > 10) */
+  HMPC_S_TOO_LARGE = 3,   /* more reduced variables than the variant the batch was launched with holds (device-resident records of
+                             double support over h > 10 without hmpc_set_max_reduced_vars(h, > 120)) */
   HMPC_S_KKT = 4,         /* final KKT check outside tolerance */
   HMPC_S_WORKSET = 5,     /* more simultaneously active constraints than the fast variant's on-chip working set holds (64 rows; the safe pass holds as many as there are variables) */
   HMPC_S_OK_RELAXED = 6   /* solved, but only after every bound was moved outward by <= 2e-6 (relative for the Fz cap):

@@ -14,7 +14,7 @@ from hector_simulation_amd import interface, records, synthetic  # noqa: E402
 
 CASES = [("standing_b8192", "standing", 10, 8192, 2), ("standing_b1024", "standing", 10, 1024, 2), ("walking_b8192", "walking", 10, 8192, 2),
          ("walking_b1024", "walking", 10, 1024, 2), ("h20_single_b4096", "single", 20, 4096, 2), ("3contact_b2048", "standing", 10, 2048, 3),
-         ("3contact_b8192", "standing", 10, 8192, 3)]
+         ("3contact_b8192", "standing", 10, 8192, 3), ("h20_double_b2048", "standing", 20, 2048, 2), ("h14_double_b2048", "standing", 14, 2048, 2)]
 only = set(sys.argv[1:])
 for name, gait, h, nb, nc in CASES:
     if only and name not in only:

@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 CASES = [("standing", 10, 6), ("walking", 10, 2), ("mixed", 10, 11), ("single", 20, 4), ("walking", 7, 13),
          ("standing", 3, 14),
          # the 120-variable variant (Toeplitz chains + full-block staging) at horizons below its scratch size
-         ("standing", 7, 15), ("standing", 9, 16), ("mixed", 8, 17), ("standing", 6, 18)]
+         ("standing", 7, 15), ("standing", 9, 16), ("mixed", 8, 17), ("standing", 6, 18),
+         # the wide variant: double support over more than ten steps (121 .. 240 reduced variables)
+         ("standing", 20, 19), ("standing", 13, 20), ("mixed", 20, 21)]
 
 
 @pytest.mark.parametrize("gait,h,seed", CASES)

@@ -83,12 +83,41 @@ def test_legacy_interface_matches_oracle(oracle):
         assert (interface.last_status() & 0xFF) == 0
 
 
-def test_too_large_is_reported():
-    """Double support over h=20 needs 240 reduced variables: reported per instance, never silently wrong."""
+def test_too_large_is_reported_for_unsized_device_records():
+    """Double support over h=20 needs 240 reduced variables.  Host-uploaded records pick the wide variant by themselves
+    (next test); device-resident records launched WITHOUT the size hint run the 120-variable variant, and every instance
+    that does not fit is reported as such -- never silently wrong."""
+    import torch
+
     f = synthetic.make_batch(2, 20, "standing", seed=5)
+    rec = records.pack_records(f, 20)
+    d_rec = torch.from_numpy(rec).cuda()
+    torch.cuda.synchronize()
     mpc = interface.BatchedMPC(synthetic.DT_MPC, 20, synthetic.F_MAX, 2)
-    mpc.upload_fields(f)
+    mpc.set_device_records(d_rec.data_ptr(), 2, keepalive=d_rec)
     mpc.solve()
     forces, status = mpc.download()
     assert (interface.status_code(status) == 3).all() and (forces == 0).all()
+    mpc.set_device_records(d_rec.data_ptr(), 2, max_reduced_vars=240, keepalive=d_rec)  # with the hint: solved
+    mpc.solve()
+    forces, status = mpc.download()
+    assert (interface.status_code(status) == 0).all() and (forces != 0).any()
     mpc.close()
+
+
+@pytest.mark.parametrize("gait,h,nb,seed", [("standing", 20, 24, 31), ("standing", 14, 24, 32), ("mixed", 20, 24, 33),
+                                            ("standing", 11, 16, 34)])
+def test_double_support_beyond_ten_steps(oracle, gait, h, nb, seed):
+    """121 .. 240 reduced variables (both feet down over h = 11 .. 20; the reference accepts h <= 19,
+    SolverMPC.cpp:140-143, but assembles correctly only at h = 10, :148-186 -- so, like BASELINE config 4, the checker here
+    is the oracle's h-generic restatement + the reference's qpOASES): forces within 1e-4 of qpOASES, eliminated variables
+    exact zeros, objective within 1e-4."""
+    rec, ref, forces, status, x64, obj64 = run_case(oracle, gait, h, nb, seed)
+    assert ref["n_bad"] == 0
+    assert (interface.status_code(status) == 0).all(), interface.status_code(status)
+    q = ref["q_soln"]
+    assert rel_inf(forces.astype(np.float64), q).max() < TOL
+    assert rel_inf(x64, q).max() < 1e-6
+    assert np.all(forces[q == 0.0] == 0.0)
+    og = np.abs(obj64 - ref["obj"]) / np.maximum(1.0, np.abs(ref["obj"]))
+    assert og.max() < TOL, og.max()
