@@ -686,17 +686,19 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   static_assert(NTILE <= BPT * NT && SM::MMAX <= NT && NMAX <= NT, "threads per block / constraint row / variable");
   int e0[BPT], e1[BPT], i0[BPT], j0[BPT];
   bool owner[BPT], diag[BPT];
+  auto own_blocks = [&]() __attribute__((always_inline)) {  // (called right before the first load: nothing of it is live during the chains)
 #pragma unroll
-  for (int s = 0; s < BPT; ++s) {
-    const int t = tid + s * NT;
-    int ea = 0;
-    while (ea < NG - 1 && (ea + 1) * NG - (ea + 1) * ea / 2 <= t) ++ea;
-    owner[s] = t < NTILE;
-    e1[s] = owner[s] ? ea + (t - (ea * NG - ea * (ea - 1) / 2)) : 0;
-    e0[s] = owner[s] ? ea : 0;
-    diag[s] = (e0[s] == e1[s]);
-    i0[s] = GS * e0[s], j0[s] = GS * e1[s];
-  }
+    for (int s = 0; s < BPT; ++s) {
+      const int t = tid + s * NT;
+      int ea = 0;
+      while (ea < NG - 1 && (ea + 1) * NG - (ea + 1) * ea / 2 <= t) ++ea;
+      owner[s] = t < NTILE;
+      e1[s] = owner[s] ? ea + (t - (ea * NG - ea * (ea - 1) / 2)) : 0;
+      e0[s] = owner[s] ? ea : 0;
+      diag[s] = (e0[s] == e1[s]);
+      i0[s] = GS * e0[s], j0[s] = GS * e1[s];
+    }
+  };
   double a[BPT][GS][GS];
   if constexpr (SM::FULLBLK) {
     // H on the matrix cores, through the block-Toeplitz structure of B_qp.  With Phi_k = Acd^k Bcd,
@@ -847,6 +849,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
             args.dbg_f[DL::H + t] = A.Hs[(SM::hs_off(dd, h) - SM::hs_off(dlo, h) + sa) * U * U + S.vcomp[lo] * U + S.vcomp[hi]];
         }
       } else {
+        if (hp == 0) own_blocks();
         load_blocks(dlo, dhi);
       }
       if (hp + 1 < SM::HSP) __syncthreads();  // the next pass overwrites the staging area
@@ -939,6 +942,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       __syncthreads();
     }
     if constexpr (!ASM_ONLY) {
+    own_blocks();
     // register blocks from the folded upper triangle over the reduced variables (reference order)
 #pragma unroll
     for (int s = 0; s < BPT; ++s)
