@@ -1,20 +1,39 @@
 #!/bin/bash
-# rocprofv3 passes for profiles/: (1) kernel trace + stats, (2) PMC FETCH_SIZE, (3) PMC WRITE_SIZE, (4) SQ counters
-# (separate passes: TCC slots do not fit both; counters never combined with other trace domains).
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/rocprof; export TMPDIR=/tmp
-python bench.py --steps 20 --warmup 3 > gpurun_out/rocprof/bench_standing.json 2> gpurun_out/rocprof/bench.err
-python bench.py --steps 20 --warmup 3 --gait walking --no-cpu-baseline > gpurun_out/rocprof/bench_walking.json 2>> gpurun_out/rocprof/bench.err
-python bench.py --steps 10 --warmup 2 --horizon 20 --gait single --batch 4096 --no-cpu-baseline > gpurun_out/rocprof/bench_h20_single.json 2>> gpurun_out/rocprof/bench.err
+# rocprofv3 passes for profiles/<round>/ (one gpurun call).  Passes are kept separate: kernel trace + stats, then one
+# --pmc pass per counter group (TCC slots do not fit both FETCH and WRITE; counters are never combined with other trace
+# domains).  scripts/summarize_rocprof.py turns the output into the tracked summaries.
+#  (1) bench lines: headline (default two launch streams, with the CPU baseline), walking, h=20 single support
+#  (2) headline workload, --streams 1: kernel trace + stats, PMC passes (HBM traffic, SQ counters, fp64 instruction mix)
+#  (3) headline workload, DEFAULT two streams: kernel trace (start/end of consecutive dispatches: the overlap the value uses)
+#  (4) every other kernel variant (walking 60 variables, h=20 single support, three contacts, wide double support):
+#      kernel trace + stats and one SQ counter pass each
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/rocprof; rm -rf gpurun_out/rocprof/*; export TMPDIR=/tmp
+O=gpurun_out/rocprof
+python bench.py --steps 20 --warmup 3 > $O/bench_standing.json 2> $O/bench.err
+python bench.py --steps 20 --warmup 3 --gait walking --no-cpu-baseline > $O/bench_walking.json 2>> $O/bench.err
+python bench.py --steps 10 --warmup 2 --horizon 20 --gait single --batch 4096 --no-cpu-baseline > $O/bench_h20_single.json 2>> $O/bench.err
 CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side-configs --check 0 --streams 1"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rocprof/kt -o kt -- $CMD > gpurun_out/rocprof/kt.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/rocprof/pmc_fetch -o pmc -- $CMD > gpurun_out/rocprof/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/rocprof/pmc_write -o pmc -- $CMD > gpurun_out/rocprof/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/rocprof/pmc_sq -o pmc -- $CMD > gpurun_out/rocprof/pmc_sq.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_FMA_F SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/rocprof/pmc_sq2 -o pmc -- $CMD > gpurun_out/rocprof/pmc_sq2.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 --output-format csv -d gpurun_out/rocprof/pmc_f64 -o pmc -- $CMD > gpurun_out/rocprof/pmc_f64.log 2>&1
-python scripts/phase_profile.py standing 10 6144 > gpurun_out/rocprof/phase_cycles.txt 2>/dev/null
-python scripts/phase_profile.py walking 10 6144 >> gpurun_out/rocprof/phase_cycles.txt 2>/dev/null
-python scripts/soak.py > gpurun_out/rocprof/soak.txt 2>&1
-find gpurun_out/rocprof -name '*.db' -delete
-cat gpurun_out/rocprof/bench_standing.json
-head -3 gpurun_out/rocprof/kt/kt_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $CMD > $O/kt.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- $CMD > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pmc -- $CMD > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq -o pmc -- $CMD > $O/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_FMA_F SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq2 -o pmc -- $CMD > $O/pmc_sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 --output-format csv -d $O/pmc_f64 -o pmc -- $CMD > $O/pmc_f64.log 2>&1
+# (3) the default two-stream mode, trace only
+rocprofv3 --kernel-trace --output-format csv -d $O/kt2 -o kt2 -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-side-configs --check 0 > $O/kt2.log 2>&1
+# (4) the other variants
+for CASE in walking_b8192 h20_single_b4096 3contact_b8192 3contact_b2048 h20_double_b2048; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/var_$CASE/kt -o kt -- python scripts/quick_times.py $CASE > $O/var_$CASE.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/var_$CASE/pmc -o pmc -- python scripts/quick_times.py $CASE >> $O/var_$CASE.log 2>&1
+done
+python scripts/phase_profile.py standing 10 6144 > $O/phase_cycles.txt 2>/dev/null
+python scripts/phase_profile.py walking 10 6144 >> $O/phase_cycles.txt 2>/dev/null
+python scripts/phase_profile.py single 20 4096 >> $O/phase_cycles.txt 2>/dev/null
+python scripts/phase_profile.py standing 10 2048 3 >> $O/phase_cycles.txt 2>/dev/null
+python scripts/dev/latency_vs_batch.py 2>/dev/null | grep -v amdgpu > $O/latency_vs_batch.txt
+python scripts/soak.py > $O/soak.txt 2>&1
+find $O -name '*.db' -delete
+find $O -name '*_agent_info.csv' -delete
+cat $O/bench_standing.json | cut -c1-600
+head -3 $O/kt/kt_kernel_stats.csv
+ls $O

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 def main():
     from hector_simulation_amd import build as hip_build
 
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
     dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
     shutil.copy(os.path.join(SRC, "kt", "kt_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
@@ -82,10 +82,102 @@ def main():
         }, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
     for r in rows:
         print("%-10s %-28s n=%3d mean %.4g" % r)
-    write_readme(dst, rnd, means)
+    for name in ("phase_cycles.txt", "latency_vs_batch.txt", "soak.txt"):
+        if os.path.exists(os.path.join(SRC, name)):
+            shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
+    extra = []
+    ts = two_stream_trace(dst)
+    if ts:
+        extra.append(ts)
+    extra += variant_lines(dst)
+    write_readme(dst, rnd, means, extra)
 
 
-def write_readme(dst, rnd, means):
+def _hmpc_dispatches(path, min_grid=0):
+    out = []
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            if "hmpc_kernel" in r["Kernel_Name"] and int(r["Grid_Size_X"]) >= min_grid:
+                out.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Stream_Id", 0) or 0), int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])))
+    return sorted(out)
+
+
+def two_stream_trace(dst):
+    """The DEFAULT bench mode alternates two launch streams: the kernel trace of that run (start / end of consecutive
+    dispatches) shows the overlap the headline value comes from, and the value follows from the trace alone."""
+    src = os.path.join(SRC, "kt2", "kt2_kernel_trace.csv")
+    if not os.path.exists(src):
+        return None
+    d = _hmpc_dispatches(src, 8192 * 128)
+    if len(d) < 24:
+        return None
+    timed = d[3:23]  # 3 warm-up steps, then the 20 timed ones (bench.py --steps 20 --warmup 3)
+    with open(os.path.join(dst, "two_stream_kernel_trace.csv"), "w") as fh:
+        fh.write("dispatch,stream,start_us,end_us,duration_us,overlap_with_previous_us\n")
+        t0 = timed[0][0]
+        prev_end = None
+        ov_total = 0.0
+        for i, (a, b, st, wgs) in enumerate(timed):
+            ov = max(0.0, (prev_end - a) / 1e3) if prev_end is not None else 0.0
+            ov_total += ov
+            fh.write("%d,%d,%.1f,%.1f,%.1f,%.1f\n" % (i, st, (a - t0) / 1e3, (b - t0) / 1e3, (b - a) / 1e3, ov))
+            prev_end = b
+    span = (timed[-1][1] - timed[0][0]) / 1e9
+    dur = sum(b - a for a, b, _, _ in timed) / len(timed) / 1e6
+    nb = timed[0][3]
+    return ("* `two_stream_kernel_trace.csv` (rocprofv3 --kernel-trace of the DEFAULT run, `python bench.py --steps 20 --warmup 3`): "
+            "the 20 timed dispatches span %.3f ms = **%.3f M solves/s** from the trace alone (%d instances each); a dispatch lasts "
+            "%.3f ms on average while a new one starts every %.3f ms -- consecutive dispatches (alternating streams) overlap by "
+            "%.3f ms on average: the partly filled last rounds of workgroups of one launch run under the first rounds of the next"
+            % (span * 1e3, len(timed) * nb / span / 1e6, nb, dur, span * 1e3 / len(timed), ov_total / (len(timed) - 1) / 1e3))
+
+
+def variant_lines(dst):
+    """One line per other kernel variant: rocprofv3 --stats duration + one SQ counter pass (scripts/gpu_rocprof.sh part 4)."""
+    lines = []
+    rowsv = []
+    for case in sorted(os.listdir(SRC)):
+        if not case.startswith("var_") or not os.path.isdir(os.path.join(SRC, case)):
+            continue
+        ks = os.path.join(SRC, case, "kt", "kt_kernel_stats.csv")
+        pm = os.path.join(SRC, case, "pmc", "pmc_counter_collection.csv")
+        if not os.path.exists(ks):
+            continue
+        name, avg, calls = None, 0.0, 0
+        with open(ks) as fh:
+            for r in csv.DictReader(fh):
+                if "hmpc_kernel" in r["Name"] and int(r["Calls"]) > calls:
+                    name, avg, calls = r["Name"].split("(")[0].replace("void hmpc::", ""), float(r["AverageNs"]) / 1e6, int(r["Calls"])
+        nb = int(case.split("_b")[-1])
+        acc = defaultdict(list)
+        if os.path.exists(pm):
+            with open(pm) as fh:
+                for r in csv.DictReader(fh):
+                    if "hmpc_kernel" in r["Kernel_Name"]:
+                        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        m = {k: sum(v) / len(v) for k, v in acc.items()}
+        wc = m.get("SQ_WAVE_CYCLES", 0.0)
+        cyc = m.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        line = "* `%s` (%s, %d instances per launch): rocprofv3 --stats %d calls, average **%.4f ms** = %.3f M solves/s" % (
+            case[4:], name, nb, calls, avg, nb / avg / 1e3)
+        if wc:
+            line += "; per solve %.0f VALU / %.0f SALU / %.0f LDS wave-instructions, SQ_WAIT_ANY %.1f %% / SQ_ACTIVE_INST_ANY %.1f %% of wave cycles" % (
+                m.get("SQ_INSTS_VALU", 0) / nb, m.get("SQ_INSTS_SALU", 0) / nb, m.get("SQ_INSTS_LDS", 0) / nb,
+                100 * m.get("SQ_WAIT_ANY", 0) / wc, 100 * m.get("SQ_ACTIVE_INST_ANY", 0) / wc)
+        if cyc:
+            line += ", VALU issue occupancy %.1f %%" % (100 * 4.0 * m.get("SQ_INSTS_VALU", 0) / (1024.0 * cyc))
+        lines.append(line)
+        rowsv.append((case[4:], name, nb, calls, avg) + tuple(m.get(k, 0.0) for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE")))
+    if rowsv:
+        with open(os.path.join(dst, "variants.csv"), "w") as fh:
+            fh.write("case,kernel,instances,calls,avg_ms,SQ_WAVES,SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_WAVE_CYCLES,SQ_WAIT_ANY,SQ_ACTIVE_INST_ANY,GRBM_GUI_ACTIVE\n")
+            for r in rowsv:
+                fh.write('%s,"%s",%d,%d,%.4f,' % r[:5] + ",".join("%.0f" % x for x in r[5:]) + "\n")
+        lines.insert(0, "* other kernel variants (`variants.csv`; `python scripts/quick_times.py <case>` under rocprofv3, counters are per-launch means):")
+    return lines
+
+
+def write_readme(dst, rnd, means, extra=()):
     """profiles/<round>/README.md generated from the CSV/JSON files next to it -- no hand-typed figures."""
     lines = ["# profiles/%s -- generated by scripts/summarize_rocprof.py from the files in this directory" % rnd, "",
              "Collected with `scripts/gpu_rocprof.sh` (one `gpurun` call; rocprofv3 passes kept separate: kernel trace + "
@@ -133,9 +225,10 @@ def write_readme(dst, rnd, means):
             if f64:
                 lines.append("* binary64 VALU instructions per solve: " + ", ".join("%s %.0f" % (k[len("sq_insts_valu_"):-len("_per_solve")], c[k]) for k in sorted(f64)))
         lines.append("* library source hash of the profiled build: `%s`" % t.get("source_hash", "?"))
-    for extra in sorted(os.listdir(dst)):
-        if extra.endswith(".txt") or (extra.endswith(".json") and extra != "bench_standing.json"):
-            lines.append("* `%s`" % extra)
+    lines += list(extra)
+    for other in sorted(os.listdir(dst)):
+        if other.endswith(".txt") or (other.endswith(".json") and other != "bench_standing.json"):
+            lines.append("* `%s`" % other)
     open(os.path.join(dst, "README.md"), "w").write("\n".join(lines) + "\n")
 
 
