@@ -5,7 +5,9 @@
 //   f2  gait table          = Gait::mpc_gait (ConvexMPC/GaitGenerator.cpp:85-103), fused into f1
 //   f3  body-frame wrenches = f_ff[leg] = -rBody [GRF; GRM] (ConvexMPCLocomotion.cpp:419-440)
 // Both are plain streaming kernels (HBM-bound): binary64 arithmetic in the order the reference writes it, no contraction
-// (this translation unit is built with -ffp-contract=off), so the packed records are bit-identical to the CPU restatement.
+// (this translation unit is built with -ffp-contract=off), so the packed records are bit-identical to the CPU restatement,
+// which is pinned bit for bit against the reference's own GaitGenerator.cpp / ConvexMPCLocomotion.cpp / LegController.cpp
+// executed (oracle/_ref/libcaller_ref.so; tests/test_caller_reference.py, also the GPU leg against reference-generated goldens).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

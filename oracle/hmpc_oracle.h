@@ -16,6 +16,11 @@
  * study switches orc_set_unfused_chain / orc_set_libm_trig on, x_0, A_ct, A_qp, B_qp, F_control, g and the upper triangle
  * of H equal the reference's source bit for bit; under the default contract the data stay within binary32 round-off.
  * Not pinned: the association inside Eigen's own kernels (see the header of oracle/mini_eigen/eigen3/Eigen/Dense).
+ * The CALLER-SIDE restatements at the end of this header (orc_mpc_gait, orc_build_record, orc_body_wrench,
+ * orc_leg_jacobian, orc_leg_torques) are pinned the same way since round 3: against
+ * oracle/_ref/libcaller_ref.so = GaitGenerator.cpp + ConvexMPCLocomotion.cpp + LegController.cpp (+ FootSwingTrajectory.cpp,
+ * DesiredCommand.cpp) compiled unmodified (tests/test_caller_reference.py: tables and records bit for bit, wrench bit for
+ * bit, Jacobian within one ulp of 1.0).
  *
  * Pinned arithmetic ("HMPC-A1"): IEEE binary32, round-to-nearest-even, no implicit
  * contraction; every matrix contraction is a k-ascending fmaf chain started at +0; trigonometry is evaluated
