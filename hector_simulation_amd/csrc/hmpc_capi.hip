@@ -35,7 +35,7 @@ thread_local std::string g_hip_err;
 #define HMPC_QCAP_FAST 64  // working-set capacity of the fast 120-variable h <= 10 variant (49 KB LDS: three per CU)
 #endif
 #ifndef HMPC_QCAP_WIDE
-#define HMPC_QCAP_WIDE 128 // ... of the 240-variable variant (double support over h = 11 .. 20)
+#define HMPC_QCAP_WIDE 152 // ... of the 240-variable variant (double support over h = 11 .. 20)
 #endif
 #ifndef HMPC_QCAP_3C
 #define HMPC_QCAP_3C 80    // ... of the fast three-contact variant (256 threads, two register blocks each, <= 80 KB LDS: two per CU)

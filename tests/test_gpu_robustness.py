@@ -113,3 +113,51 @@ def test_device_side_safe_pass_equals_the_host_driven_one(gait, h):
         m.close()
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     np.testing.assert_array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+
+
+def _hard3(nb, seed, scale):
+    """make_batch3 with the body state drawn from `scale` times the nominal ranges (as hard_batch does for two contacts)"""
+    f = synthetic.make_batch3(nb, 10, "standing", seed=seed, hand="contact")
+    g = hard_batch(nb, 10, "standing", seed, scale)
+    for k in ("q", "v", "w", "joint_angles", "traj"):
+        f[k] = g[k]
+    return f
+
+
+@pytest.mark.parametrize("scale,min_ok", [(3, 0.99), (6, 0.95)])
+def test_hard_inputs_three_contacts(oracle, scale, min_ok):
+    """The three-contact variant (256 threads, two register blocks per thread, working set 80 rows, safe pass 140) outside the
+    nominal ranges: whatever is reported ok matches qpOASES, everything else is flagged."""
+    nb = 128
+    rec = records.pack_records(_hard3(nb, 19, scale), 10, 3)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, 10, synthetic.F_MAX, nb, contacts=3)
+    mpc.upload(rec)
+    mpc.solve()
+    forces, status = mpc.download()  # with the safe pass
+    mpc.close()
+    code = interface.status_code(status)
+    ok = (code == 0) | (code == 6)
+    assert ok.mean() >= min_ok, np.unique(code, return_counts=True)
+    ref = oracle.solve_records(rec, 10, synthetic.DT_MPC, synthetic.F_MAX, nc=3)
+    q = ref["q_soln"]
+    err = np.abs(forces - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+    assert ref["n_bad"] == 0 and err[ok].max() < 1e-4
+
+
+@pytest.mark.parametrize("h,scale,min_ok", [(20, 3, 0.99), (16, 6, 0.9)])
+def test_hard_inputs_wide_variant(oracle, h, scale, min_ok):
+    """Double support over more than ten steps (wide variant, working set 152 rows) outside the nominal ranges."""
+    nb = 64
+    rec = records.pack_records(hard_batch(nb, h, "standing", 29, scale), h)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb)
+    mpc.upload(rec)
+    mpc.solve()
+    forces, status = mpc.download()
+    mpc.close()
+    code = interface.status_code(status)
+    ok = (code == 0) | (code == 6)
+    assert ok.mean() >= min_ok, np.unique(code, return_counts=True)
+    ref = oracle.solve_records(rec, h, synthetic.DT_MPC, synthetic.F_MAX)
+    q = ref["q_soln"]
+    err = np.abs(forces - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+    assert ref["n_bad"] == 0 and err[ok].max() < 1e-4
