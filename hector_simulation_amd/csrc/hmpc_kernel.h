@@ -138,6 +138,8 @@ struct Smem {
   double g[NMAX];        // gradient, sweep order
   double Cn[NC][8][6];   // per-contact constraint normals (columns: F then M of that contact)
   double ub7[NG];        // Fz cap f_max*gait of each stance leg-step
+  double relax;          // args.relax (see row_lo in the kernel)
+  double sc7[NG];        // ... and the unit scale of that row: 1/ub7 where ub7 > 1 (read where used: not a live register pair)
   unsigned char vstep[NMAX], vcomp[NMAX];  // reference-order reduced variable -> horizon step, component (0..11)
   unsigned char o2s[NMAX], s2o[NMAX];      // reference order <-> sweep order (leg-step major)
   unsigned char rmap[U * HMAX];            // original variable U*step+comp -> sweep index (255 = eliminated)
@@ -207,6 +209,11 @@ __device__ __forceinline__ double &Eref(SM &S, int i, int j) {
   return S.u.s.Ep[hi * (hi + 1) / 2 + lo];
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a binary64 value every lane agrees on, moved to scalar registers
+__device__ __forceinline__ double uni_d(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
 // a decision every lane agrees on (computed from broadcast LDS reads), told to the compiler as a scalar
 __device__ __forceinline__ bool ub(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 
@@ -416,6 +423,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     for (int t = tid; t < PS; t += NT) A.Bcd[t] = 0.0f;                           // fl(dt*0) = 0
     for (int t = tid; t < C8 * U; t += NT) A.Fc[t] = 0.0f;
     for (int t = tid; t < U * h; t += NT) S.rmap[t] = 255;
+    if (tid == 0) S.relax = args.relax;
   }
   __syncthreads();
   PROF_MARK(P_A1);
@@ -572,7 +580,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
           if (k == 0) {
             S.ls_leg[e] = (unsigned char)leg;
             S.ls_step[e] = (unsigned char)i;
-            S.ub7[e] = (double)(fz_cap(leg) * (float)gait[NC * i + leg]);
+            const double u7 = (double)(fz_cap(leg) * (float)gait[NC * i + leg]);
+            S.ub7[e] = u7;
+            S.sc7[e] = (u7 > 1.0) ? 1.0 / u7 : 1.0;  // the Fz cap is O(f_max): compare it on a unit scale
           }
         }
       }
@@ -1220,7 +1230,17 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   const double INF = __builtin_huge_val();
   const double FEAS_TOL = 1e-9;
   const int c_e = tid >> 3, c_rr = tid & 7;
-  double c_ub = INF, c_lo = 0.0, c_scale = 1.0;
+  double c_ub = INF;
+  // the lower bound of a row is 0 -- except in the last-resort pass (args.relax != 0), where it is recomputed on use
+  // rather than kept in a register pair for the whole solve
+  // (read through LDS: a value the compiler cannot prove loop-invariant across the barriers, or it hoists the whole
+  //  expression back into a register pair that lives -- and spills -- for the rest of the kernel)
+  auto row_lo = [&]() __attribute__((always_inline)) -> double {
+    const double rl = S.relax;
+    if (ub(rl == 0.0)) return 0.0;
+    const double fr = 0.6180339887498949 * (double)(tid + 1);
+    return -(rl * (1.0 + (fr - __builtin_floor(fr))));
+  };
   bool c_hasl = false, c_hasu = false;
   const double *c_cn = S.Cn[0][0];  // this row's 6 coefficients (LDS; re-read where used: cheaper than 12 live VGPRs)
   if (is_c) {
@@ -1229,11 +1249,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     c_hasl = (c_rr <= 4) || (c_rr == 7);  // every finite lower bound is 0 (SolverMPC.cpp:466-482)
     c_hasu = (c_rr >= 4);
     c_ub = (c_rr == 4) ? (double)0.01f : (c_rr == 7 ? S.ub7[c_e] : 0.0);
-    c_scale = (c_rr == 7 && c_ub > 1.0) ? 1.0 / c_ub : 1.0;  // the Fz cap is O(f_max): compare it on a unit scale
     if (args.relax != 0.0) {
       const double fr = 0.6180339887498949 * (double)(tid + 1);
       const double dl = args.relax * (1.0 + (fr - __builtin_floor(fr)));
-      c_lo = -dl;
       c_ub += dl * ((c_rr == 7 && c_ub > 1.0) ? c_ub : 1.0);
     }
   }
@@ -1269,9 +1287,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
 #pragma unroll
     for (int k = 0; k < 3; ++k) s1 = dfma(c_cn[3 + k], xp[3 + k], s1);
     const double s = s0 + s1;
-    const double sl = c_hasl ? (s - c_lo) : INF;
+    const double sl = c_hasl ? (s - row_lo()) : INF;
     const double su = c_hasu ? (c_ub - s) : INF;
-    const double ssu = su * c_scale;
+    const double ssu = su * ((c_rr == 7) ? S.sc7[c_e] : 1.0);  // (the Fz cap on a unit scale; table built with ub7)
     side = (sl <= ssu) ? 1 : -1;
     raw = (sl <= ssu) ? sl : su;
     return (sl <= ssu) ? sl : ssu;
@@ -1372,7 +1390,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         const double *xp = xv + GS * c_e;
 #pragma unroll
         for (int k = 0; k < 6; ++k) s = dfma(c_cn[k], xp[k], s);
-        const double bnd = (ac > 0) ? c_lo : c_ub;
+        const double bnd = (ac > 0) ? row_lo() : c_ub;
         Q.d[Q.slot[tid]] = (double)ac * (bnd - s);
       }
     }
@@ -1753,11 +1771,11 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       wsel = uni(wsel);
       const int p = uni(Q.rec[wsel].idx), sgi = uni(Q.rec[wsel].side);
       const int ep = p >> 3;
-      double sp = Q.rec[wsel].raw;
+      double sp = uni_d(Q.rec[wsel].raw);  // (uniform values of the iteration live in scalar registers: sp, up, delta, gamma, t1)
       const double sg = (double)sgi;
       double np[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) np[k] = sg * Q.rec[wsel].cn[k];
+      for (int k = 0; k < 6; ++k) np[k] = uni_d(sg * Q.rec[wsel].cn[k]);  // the same value in every lane: scalar registers
       double up = 0.0;
       bool added = false;
       while (!added) {
@@ -1831,7 +1849,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         double delta = 0.0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) delta = dfma(np[k], Q.z[GS * ep + k], delta);
-        const double gamma = Q.gamma;
+        delta = uni_d(delta);
+        const double gamma = uni_d(Q.gamma);
         int l = Q.redi[0];
         double t1 = Q.redv[0];
 #pragma unroll
@@ -1840,6 +1859,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
           if (ov < t1) t1 = ov, l = Q.redi[w];
         }
         l = uni(l);
+        t1 = uni_d(t1);
         const bool dep = ub(!(delta > 1e-12 * gamma));
         const double t2 = dep ? INF : -sp / delta;
         const double t = (t1 < t2) ? t1 : t2;
@@ -1853,8 +1873,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         }
         if (!dep && is_v) Q.x[tid] = dfma(t, Q.z[tid], Q.x[tid]);
         if (tid < q) Q.u[tid] = dfma(-t, Q.r[tid], Q.u[tid]);
-        up += t;
-        if (!dep) sp = dfma(t, delta, sp);
+        up = uni_d(up + t);
+        if (!dep) sp = uni_d(dfma(t, delta, sp));
         const bool fullstep = ub(!dep && !(t1 < t2));
         if (fullstep && q >= SM::QMAX) {
           code = S_WORKSET;
