@@ -101,12 +101,18 @@ class Caller:
 
     def set_backend(self, backend: str | None) -> None:
         """None: get_solution answers from set_solution(); "reference": the captured calls are forwarded to the
-        reference's own solver (oracle/_ref/libsolvempc_ref.so)."""
+        reference's own solver (oracle/_ref/libsolvempc_ref.so); a ctypes library object: forwarded to that library's
+        setup_problem / update_problem_data / get_solution."""
         L = lib()
+        cast = lambda f: C.cast(f, C.c_void_p)
         if backend == "reference":
             R = ref_py.lib()
-            cast = lambda f: C.cast(f, C.c_void_p)
             L.refc_set_backend(cast(R.setup_problem), cast(R.update_problem_data), cast(R.get_solution))
+        elif backend is not None and not isinstance(backend, str):
+            # any library that exports the reference's C interface (convexMPC_interface.h:39-43) -- the tests pass the
+            # PRODUCT library here: the reference's own controller code then drives the HIP solver, unchanged
+            L.refc_set_backend(cast(backend.setup_problem), cast(backend.update_problem_data), cast(backend.get_solution))
+            self._backend_keepalive = backend
         else:
             L.refc_set_backend(None, None, None)
 

@@ -313,3 +313,51 @@ def test_device_wrench_and_torques_vs_reference_golden(gold):
     assert np.abs(tau - gold["legs/tau_f64"]).max() <= 2.5e-13
     assert (tau.astype(np.float32) != gold["legs/tau_f32"]).mean() <= 1e-2
     mpc.close()
+
+
+@pytest.mark.gpu
+def test_reference_controller_drives_the_hip_solver_unchanged(caller_py):
+    """THE drop-in statement, executed: the reference's OWN controller code -- ConvexMPCLocomotion::run, GaitGenerator,
+    LegController::updateData/updateCommand, compiled unmodified (oracle/_ref/libcaller_ref.so) -- calls
+    setup_problem / update_problem_data / get_solution of the PRODUCT library (the HIP solver) over a 60-tick walking sequence,
+    and beside it the same code calls the reference's own solver.  Same MPC ticks fire, the feed-forward wrenches agree within
+    the end-to-end sensitivity (cond(H) x binary32 round-off of the QP data) and so do the joint torques
+    sent to the motors."""
+    from hector_simulation_amd import _lib
+    from oracle import ref_py
+
+    if not ref_py.available():
+        pytest.skip("oracle/_ref/libsolvempc_ref.so not on this box")
+    product = _lib.load()
+    runs = {}
+    for name, backend in (("hip", product), ("reference", "reference")):
+        c = caller_py.Caller(backend=backend)
+        t0 = synthetic.make_ticks(1, H, "walking", seed=5)[0]
+        rng = np.random.default_rng(9)
+        q_motor = (t0["leg_q"] - LEG_OFFSET).astype(np.float32)
+        c.set_command(t0["roll_des"], t0["pitch_des"], 0.3, -0.1, 0.2)
+        out = []
+        for tick in range(60):
+            pos = t0["position"] + 1e-3 * tick * np.array([0.3, -0.1, 0.0])
+            c.set_state(pos, t0["vWorld"], t0["omegaWorld"], t0["orientation"], t0["rpy"], t0["rBody"])
+            q_motor = (q_motor + rng.uniform(-1e-3, 1e-3, 10)).astype(np.float32)
+            c.update_leg_data_from_motors(q_motor)
+            n_before = c.capture()["n_update"]
+            c.run(2)
+            m = c.members()
+            fired = c.capture()["n_update"] != n_before
+            tau = c.update_command(m["f_ff"])
+            out.append((fired, m["f_ff"].copy(), tau.copy()))
+        runs[name] = out
+        c.close()
+    n_mpc = 0
+    worst_f = worst_t = 0.0
+    for (fa, ffa, ta), (fb, ffb, tb) in zip(runs["hip"], runs["reference"]):
+        assert fa == fb
+        n_mpc += int(fa)
+        scale = max(1.0, np.abs(ffb).max())
+        worst_f = max(worst_f, np.abs(ffa - ffb).max() / scale)
+        worst_t = max(worst_t, np.abs(ta - tb).max() / max(1.0, np.abs(tb).max()))
+    print(f"reference controller on the HIP solver vs on its own: {n_mpc} MPC ticks, f_ff rel diff {worst_f:.2e}, torque rel diff {worst_t:.2e}")
+    assert n_mpc == 12
+    assert worst_f < 1.2e-4 * 5 and worst_t < 1.2e-4 * 5  # walking sets: 4.7e-5 measured end to end (E2E_FORCE in test_reference_source)
