@@ -1739,6 +1739,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       double val = INF, raw = INF;
       int side = 1;
       if (is_c && !c_ignored && Q.act[tid] == 0) val = my_slack(Q.x, side, raw);
+      PROF_MARK(P_T1);
       {
         const double wmin = wave_min(val);
         const unsigned long long bal = __ballot(val == wmin);

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from hector_simulation_amd import _lib, build, interface, records, synthetic  # noqa: E402
 
-PH = ["asm", "H+g", "sweep", "xu", "select", "d", "E*d", "w", "matvec", "t1", "update", "polish", "final", "TOTAL", "blk:x", "blk:S0", "blk:inv", "blk:drop", "sel:a", "asm:load", "asm:trig", "asm:scalar", "H+g:g"]
+PH = ["asm", "H+g", "sweep", "xu", "select", "d", "E*d", "w", "matvec", "sel:slack", "update", "polish", "final", "TOTAL", "blk:x", "blk:S0", "blk:inv", "blk:drop", "sel:a", "asm:load", "asm:trig", "asm:scalar", "H+g:g"]
 
 
 def main():
