@@ -67,6 +67,7 @@ int main(int argc, char **argv) {
   }
   printf("rc %d, group of %d (%s), %d of %d not ok, %d gathered rows differ from the full download; instance 0: Fz_L %.3f Fz_R %.3f\n",
          rc, G, hmpc_group_transport(g) == HMPC_GROUP_RCCL ? "rccl" : "p2p", bad, N, mismatch, wrench[2], wrench[5]);
+  fflush(stdout); /* (so that the line survives a tool that aborts the process during runtime teardown, e.g. a sanitizer) */
   if (rc != HMPC_OK) fprintf(stderr, "error: %s\n", hmpc_group_last_error());
   hmpc_group_destroy(g);
   free(recs), free(wrench), free(forces), free(st), free(st2);

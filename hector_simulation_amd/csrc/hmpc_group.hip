@@ -73,7 +73,8 @@ struct Rccl {
     // The entry points above are declared by hand against rccl.h of ROCm 7.2 (RCCL 2.2x: NCCL_VERSION_CODE =
     // major * 10000 + minor * 100 + patch since 2.9).  Their signatures and ncclInt32 == 2 have been stable across the
     // whole 2.x line; any other major is refused rather than called through a guessed ABI.
-    if (GetVersion(&version) != 0 || version < 20000 || version >= 30000) {
+    if (GetVersion(&version) != 0) version = -1;
+    if (version < 20000 || version >= 30000) {
       err = "librccl reports version code " + std::to_string(version) + ": only RCCL/NCCL 2.x is supported by this binding";
       dlclose(dl);
       dl = nullptr;

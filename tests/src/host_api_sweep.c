@@ -130,6 +130,33 @@ int main(void) {
   for (int k = 0; k < N; ++k) CHECK(HMPC_STATUS_CODE(st[k]) == HMPC_S_OK && fabs(fff[12 * k + 2] + (double)forces[(size_t)k * 12 * H + 2]) < 1e-12);
   CHECK(hmpc_build_records(h, NULL, N, 0.04, wpd) == HMPC_E_ARG && hmpc_body_wrench(h, NULL, fff) == HMPC_E_ARG);
 
+  /* device-side safe pass (round 3): hard batch again, repaired on the device without hmpc_resolve_failed */
+  make_records(recs, stride, 0.6);
+  CHECK(hmpc_set_device_repair(NULL, 1) == HMPC_E_ARG && hmpc_set_device_repair(h, 1) == HMPC_OK);
+  CHECK(hmpc_set_auto_resolve(h, 0) == HMPC_OK);
+  CHECK(hmpc_upload_records(h, recs, N) == HMPC_OK && hmpc_solve(h, NULL) == HMPC_OK && hmpc_download(h, forces, st) == HMPC_OK);
+  for (int k = 0; k < N; ++k) CHECK(HMPC_STATUS_CODE(st[k]) != HMPC_S_WORKSET);
+  CHECK(hmpc_set_device_repair(h, 0) == HMPC_OK && hmpc_set_auto_resolve(h, 1) == HMPC_OK);
+
+  /* external-QP parity hook (round 3): the kernel's own QP handed back in must reproduce the kernel's own forces */
+  {
+    make_records(recs, stride, 0.05);
+    CHECK(hmpc_upload_records(h, recs, N) == HMPC_OK && hmpc_solve(h, NULL) == HMPC_OK && hmpc_download(h, forces, st) == HMPC_OK);
+    const int ld = HMPC_MAX_VARS;
+    float *Hx = (float *)calloc((size_t)N * ld * ld, sizeof(float)), *gx = (float *)calloc((size_t)N * ld, sizeof(float));
+    float *Fx = (float *)calloc((size_t)N * 16 * 12, sizeof(float)), *Hk = (float *)calloc((size_t)ld * ld, sizeof(float));
+    for (int k = 0; k < N; ++k) {
+      int nk = 0, mk = 0;
+      CHECK(hmpc_debug_assemble(h, k, &nk, &mk, NULL, Hk, gx + (size_t)k * ld, Fx + (size_t)k * 192, NULL, NULL, NULL, NULL, NULL) == HMPC_OK);
+      CHECK(nk > 0 && nk <= ld);
+      for (int i = 0; i < nk; ++i) memcpy(Hx + ((size_t)k * ld + i) * ld, Hk + (size_t)i * nk, sizeof(float) * nk);
+    }
+    CHECK(hmpc_debug_solve_external_qp(h, Hx, gx, NULL, ld) == HMPC_E_ARG);
+    CHECK(hmpc_debug_solve_external_qp(h, Hx, gx, Fx, ld) == HMPC_OK && hmpc_download(h, forces2, st) == HMPC_OK);
+    CHECK(memcmp(forces, forces2, sizeof(float) * N * 12 * H) == 0);
+    free(Hx), free(gx), free(Fx), free(Hk);
+  }
+
   /* parity hook */
   int n = 0, m = 0;
   CHECK(hmpc_debug_assemble(h, 0, &n, &m, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL) == HMPC_OK && n > 0 && m > 0);
@@ -146,6 +173,14 @@ int main(void) {
   CHECK(hmpc_group_upload_records(g, recs, N - 1) == HMPC_OK && hmpc_group_solve(g) == HMPC_OK);
   CHECK(hmpc_group_gather_wrench(g, wrench, st) == HMPC_OK && hmpc_group_download(g, forces, NULL) == HMPC_OK);
   for (int k = 0; k < N - 1; ++k) CHECK(memcmp(wrench + 12 * k, forces + (size_t)12 * H * k, 48) == 0);
+  /* round 3: a collected exchange is not handed out again -- solve, post, wait, solve, gather returns the SECOND solve */
+  make_records(recs, stride, 0.08);
+  CHECK(hmpc_group_post_gather(g) == HMPC_OK && hmpc_group_wait_gather(g) == HMPC_OK);
+  CHECK(hmpc_group_upload_records(g, recs, N) == HMPC_OK && hmpc_group_solve(g) == HMPC_OK);
+  CHECK(hmpc_group_gather_wrench(g, wrench, st) == HMPC_OK && hmpc_group_download(g, forces, NULL) == HMPC_OK);
+  for (int k = 0; k < N; ++k) CHECK(memcmp(wrench + 12 * k, forces + (size_t)12 * H * k, 48) == 0);
+  CHECK(hmpc_group_set_exchange_repair(g, 0) == HMPC_OK && hmpc_group_solve(g) == HMPC_OK && hmpc_group_gather_wrench(g, wrench, st) == HMPC_OK);
+  CHECK(hmpc_group_set_exchange_repair(g, 1) == HMPC_OK && hmpc_group_set_exchange_repair(NULL, 1) == HMPC_E_ARG);
   CHECK(hmpc_group_upload_records(g, recs, 0) == HMPC_OK && hmpc_group_solve(g) == HMPC_OK && hmpc_group_gather_wrench(g, wrench, st) == HMPC_OK);
   CHECK(hmpc_group_synchronize(g) == HMPC_OK && hmpc_group_destroy(g) == HMPC_OK);
 
