@@ -38,7 +38,7 @@ thread_local std::string g_hip_err;
 #define HMPC_QCAP_WIDE 152 // ... of the 240-variable variant (double support over h = 11 .. 20)
 #endif
 #ifndef HMPC_QCAP_3C
-#define HMPC_QCAP_3C 80    // ... of the fast three-contact variant (256 threads, two register blocks each, <= 80 KB LDS: two per CU)
+#define HMPC_QCAP_3C 96    // ... of the fast three-contact variant (256 threads, two register blocks each, <= 80 KB LDS: two per CU)
 #endif
 typedef void (*kernel_fn)(hmpc::KernelArgs);
 

@@ -126,7 +126,7 @@ def _hard3(nb, seed, scale):
 
 @pytest.mark.parametrize("scale,min_ok", [(3, 0.99), (6, 0.95)])
 def test_hard_inputs_three_contacts(oracle, scale, min_ok):
-    """The three-contact variant (256 threads, two register blocks per thread, working set 80 rows, safe pass 140) outside the
+    """The three-contact variant (256 threads, two register blocks per thread, working set 96 rows, safe pass 140) outside the
     nominal ranges: whatever is reported ok matches qpOASES, everything else is flagged."""
     nb = 128
     rec = records.pack_records(_hard3(nb, 19, scale), 10, 3)
