@@ -386,7 +386,8 @@ def main() -> None:
             for name, gait2, hh, bb in (("cfg2_walking_b1024_fixed_phase", "walking", 10, 1024),
                                         ("metric_2contact_b1024", "standing", 10, 1024),
                                         ("cfg3_walking_sweep_b8192_per_gpu", "walking", 10, 8192),
-                                        ("cfg4_h20_single_support_b4096", "single", 20, 4096)):
+                                        ("cfg4_h20_single_support_b4096", "single", 20, 4096),
+                                        ("h20_double_support_240x320_b2048_wide_variant", "standing", 20, 2048)):
                 f2 = synthetic.make_batch(bb, hh, gait2, seed=2, phase=(0 if "fixed" in name else "random"))
                 m2 = interface.BatchedMPC(synthetic.DT_MPC, hh, synthetic.F_MAX, bb, device=local_rank)
                 m2.upload(records.pack_records(f2, hh))
