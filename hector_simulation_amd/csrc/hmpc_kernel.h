@@ -13,12 +13,16 @@
 //      120/180-variable h <= 10 variants run h chains and read a finished block off after every step (bit-identical).
 //   S  M = H^-1 in binary64 by n symmetric sweeps.  The matrix lives in REGISTERS for the rest of the kernel: the
 //      reduced variables are ordered leg-step by leg-step ([F(3), M(3)] per stance leg-step), and thread t owns the
-//      6x6 block M(e,e') between two leg-steps (e <= e'): 210 blocks for 20 leg-steps.
-//   W  block warm start: every moment / line-contact row (rows 4-6 of a leg-step's 8) violated at the unconstrained
-//      minimiser enters the working set at once.  Their Schur matrix N M N' is formed block-locally (a row touches one
-//      leg-step, so n_i' M n_j needs only the 6x6 block its owner already holds), inverted in registers, rows of the
-//      foot-x moment window whose multiplier comes out negative are switched to their other bound, other rows with a
-//      negative multiplier are removed again -> a valid Goldfarb-Idnani state, ~20 iterations saved.
+//      6x6 block M(e,e') between two leg-steps (e <= e'): 210 blocks for 20 leg-steps -- or BPT = 2 such blocks (template
+//      parameter): the three-contact variant (465 blocks on 256 threads, two workgroups per CU) and the wide one (820
+//      blocks on 512 threads: double support over h = 11..20).
+//   W  block warm start, in rounds: every moment / line-contact row (rows 4-6 of a leg-step's 8) and one friction row per
+//      axis (rows 0-3) violated at the unconstrained minimiser enter the working set at once.  Their Schur matrix N M N'
+//      is formed block-locally (a row touches one leg-step, so n_i' M n_j needs only the 6x6 block its owner already
+//      holds), inverted in registers, rows of the foot-x moment window whose multiplier comes out negative are switched
+//      to their other bound, other rows with a negative multiplier are removed again -> a valid Goldfarb-Idnani state,
+//      ~20 iterations saved.  While enough further rows are violated at the point reached, another round takes the
+//      working set plus all of them.
 //   Q  dual active set (Goldfarb-Idnani, range-space form) from that state: Schur inverse E = (N M N')^-1 kept
 //      explicitly (bordering / Schur-complement downdates: no triangular solves), M applied in place from the register
 //      blocks with a fixed-order staged reduction (deterministic).  One refinement step of the multipliers at the end (HMPC_REFINE).
