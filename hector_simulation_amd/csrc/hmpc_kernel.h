@@ -299,6 +299,9 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #ifndef HMPC_BLOCK_MIN_NEW_3C
 #define HMPC_BLOCK_MIN_NEW_3C 3  // ... three-contact variant (its single-row iteration is dearer)
 #endif
+#ifndef HMPC_CHAIN_BALANCE
+#define HMPC_CHAIN_BALANCE 1     // H chains of the 120-variable h <= 10 variant: block-diagonals dealt to the waves by length
+#endif
 #ifndef HMPC_EPT_3C
 #define HMPC_EPT_3C 7            // three-contact variant on 256 threads: packed-triangle entries per thread in the block start
 #endif
@@ -739,10 +742,22 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       int off[4], vm[4];  // staging offset of the four rows this lane holds inside a block (or its spare word), 1/0
       float al[4];        // alpha on the diagonal entries of the diagonal chain, else 0
     };
+    constexpr bool CHAIN_BALANCE = HMPC_CHAIN_BALANCE && TB == 1 && SM::HSP == 1 && NW == 4 && HMAX <= 10;
     int chain_lim = nchain, chain_dlo = 0;  // the chains of the current staging pass: idx < chain_lim, diagonals from chain_dlo
     auto setup = [&](int idx, Chain &C) __attribute__((always_inline)) {
-      C.live = idx < chain_lim;
-      const int ci = C.live ? idx : 0;
+      int cidx = idx;
+      bool alive = idx < chain_lim;
+      if constexpr (CHAIN_BALANCE) {
+        // two contacts, one staging pass: chain slots -> block-diagonals so that the waves' loads even out.  Slots w and w+4
+        // run together on wave w (0|7, 1|6, 2|5, 3|4: 10, 9, 8, 7 steps), slots 10 and 11 (diagonals 8, 9) follow on waves 2
+        // and 3: 10 sequential steps on the longest wave instead of 12 (0|4 then 8).  Which wave runs a chain does not
+        // touch its arithmetic.
+        const int dd = (idx < 4) ? idx : ((idx < 8) ? 11 - idx : ((idx < 10) ? 99 : idx - 2));
+        alive = dd < h;
+        cidx = dd;
+      }
+      C.live = alive;
+      const int ci = C.live ? cidx : 0;
       C.d = ci / (TB * TB);
       const int ti = (ci / TB) % TB, tj = ci % TB;
       C.len = C.live ? h - C.d : 0;
@@ -775,7 +790,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     };
     // two chains per pass (independent accumulators hide the MFMA dependency latency); the operands of step j+1 are
     // fetched while the matrix instructions of step j run
-    auto run_chains = [&](const int idx_lo, const int idx_hi) __attribute__((always_inline)) {
+    auto run_chains = [&](const int idx_lo, const int idx_hi_in) __attribute__((always_inline)) {
+    const int idx_hi = CHAIN_BALANCE ? 12 : idx_hi_in;
     for (int idx = idx_lo + wv; idx < idx_hi; idx += 2 * NW) {
       Chain C0, C1;
       setup(idx, C0);
