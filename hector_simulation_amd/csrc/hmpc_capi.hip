@@ -54,8 +54,9 @@ struct Variant {
 // hold 64 rows (49-50 KB LDS, 168 VGPRs: three workgroups per CU, also at h = 20); the "safe"
 // variants hold NMAX rows (can never overflow)
 // and re-solve the few instances the fast pass flags (hmpc_resolve_failed).
-// The extension with a third (hand) contact -- BASELINE config 5, 180 variables x 240 rows at h = 10 -- runs 512-thread
-// workgroups (465 register blocks, one workgroup per CU).
+// The extension with a third (hand) contact -- BASELINE config 5, 180 variables x 240 rows at h = 10 -- runs 256-thread
+// workgroups with two register blocks per thread (465 blocks, two workgroups per CU; round 2: 512 threads, one per CU --
+// still the shape of its safe pass).  BPT = blocks per thread, see hmpc_kernel.h.
 template <int NMAX, int HMAX, int NT, int QCAP, int NC = 2, int BPT = 1>
 Variant make_variant() {
   static_assert(sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>) <= 160 * 1024, "LDS budget of a gfx950 CU");

@@ -100,7 +100,7 @@ enum hmpc_status_code {
   HMPC_S_TOO_LARGE = 3,   /* more reduced variables than the variant the batch was launched with holds (device-resident records of
                              double support over h > 10 without hmpc_set_max_reduced_vars(h, > 120)) */
   HMPC_S_KKT = 4,         /* final KKT check outside tolerance */
-  HMPC_S_WORKSET = 5,     /* more simultaneously active constraints than the fast variant's on-chip working set holds (64 rows; the safe pass holds as many as there are variables) */
+  HMPC_S_WORKSET = 5,     /* more simultaneously active constraints than the fast variant's on-chip working set holds (64 rows; 96 with three contacts, 152 in the wide variant; the safe pass holds as many as there are variables -- except for the wide variant, which LDS leaves no room to grow) */
   HMPC_S_OK_RELAXED = 6   /* solved, but only after every bound was moved outward by <= 2e-6 (relative for the Fz cap):
                              the last-resort pass of hmpc_resolve_failed for instances cycling at a degenerate vertex */
 };
