@@ -18,8 +18,11 @@
 namespace hmpc {
 
 // One workgroup per instance; thread t produces 32-bit word t of the packed record (coalesced 720-B burst out).
+// cls (optional): the instance's stance leg-step count -- the size class hmpc_solve routes it by (KernelArgs::cls), counted
+// with the solver's own criterion (|f_max * gait| >= 1e-4, SolverMPC.cpp:589-637).
 __global__ __launch_bounds__(256) void build_records_kernel(const hmpc_tick_inputs *ticks, int batch, int h, double dtMPC,
-                                                            unsigned char *records, int stride, double *wpd_out) {
+                                                            unsigned char *records, int stride, double *wpd_out, float f_max,
+                                                            unsigned char *cls) {
   const int inst = blockIdx.x;
   if (inst >= batch) return;
   const hmpc_tick_inputs &tk = ticks[inst];
@@ -41,6 +44,17 @@ __global__ __launch_bounds__(256) void build_records_kernel(const hmpc_tick_inpu
   if (threadIdx.x == 0 && wpd_out) {
     wpd_out[2 * inst + 0] = xStart;
     wpd_out[2 * inst + 1] = yStart;
+  }
+  if (cls && threadIdx.x == 64) {  // (a lane of the second wave: thread 0 has the clamp to write)
+    int cnt = 0;
+    for (int gi = 0; gi < 2 * h; ++gi) {
+      const int i = gi >> 1, j = gi & 1;
+      int progress = (i + tk.gait_iteration) % h - tk.gait_offsets[j];
+      if (progress < 0) progress += h;
+      const float ubc = f_max * (float)((progress < tk.gait_durations[j]) ? 1 : 0);
+      cnt += !(ubc < 0.0001 && ubc > -.0001);
+    }
+    cls[inst] = (unsigned char)cnt;
   }
   for (int t = threadIdx.x; t < nwords; t += blockDim.x) {
     uint32_t word = 0;
@@ -117,6 +131,21 @@ __global__ __launch_bounds__(256) void build_records_kernel(const hmpc_tick_inpu
   }
 }
 
+// size classes of records that are already in HBM (hmpc_set_device_records without a hint): one thread per instance counts
+// the stance leg-steps from the record's gait bytes, with the solve kernel's criterion (two-contact records)
+__global__ __launch_bounds__(256) void classify_records_kernel(const unsigned char *records, int stride, int batch, int h,
+                                                               float f_max, unsigned char *cls) {
+  const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= batch) return;
+  const unsigned char *g = records + (size_t)inst * stride + 4 * (54 + 12 * h);
+  int cnt = 0;
+  for (int i = 0; i < 2 * h; ++i) {
+    const float ubc = f_max * (float)g[i];
+    cnt += !(ubc < 0.0001 && ubc > -.0001);
+  }
+  cls[inst] = (unsigned char)(cnt > 255 ? 255 : cnt);
+}
+
 // thread g -> (instance g/12, leg (g%12)/6, row (g%6)): f_ff = -rBody * [GRF; GRM]
 __global__ __launch_bounds__(256) void body_wrench_kernel(const float *forces, int batch, int h, const double *rBody,
                                                           double *f_ff) {
@@ -132,13 +161,17 @@ __global__ __launch_bounds__(256) void body_wrench_kernel(const float *forces, i
 
 // thread g -> (instance g/2, leg g%2): body-frame wrench of that leg, force-moment Jacobian of the leg
 // (common/LegController.cpp:108-167, repeated factors named) and tau = J' f (LegController.cpp:57-61)
+// ticks != nullptr (the tick pipeline, hmpc_tick_solve_device): rBody and the joint angles are read from the tick structs
+// instead; a tick's leg_q is the motor angle when HMPC_TICK_LEG_Q_MOTOR is set and otherwise data[leg].q AFTER the
+// LegController's in-place offset -- which is exactly the value the Jacobian's formulas use (LegController.cpp:111-113).
 __global__ __launch_bounds__(256) void leg_torque_kernel(const float *forces, int batch, int h, const double *rBody,
-                                                         const double *leg_q, double *f_ff, double *tau) {
+                                                         const double *leg_q, double *f_ff, double *tau,
+                                                         const hmpc_tick_inputs *ticks) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= 2 * batch) return;
   const int inst = g >> 1, leg = g & 1;
   const float *sol = forces + (size_t)inst * 12 * h;
-  const double *R = rBody + (size_t)inst * 9;
+  const double *R = ticks ? ticks[inst].rBody : rBody + (size_t)inst * 9;
   double f[6];
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -151,9 +184,11 @@ __global__ __launch_bounds__(256) void leg_torque_kernel(const float *forces, in
 #pragma unroll
     for (int i = 0; i < 6; ++i) f_ff[(size_t)inst * 12 + 6 * leg + i] = f[i];
   }
-  const double *q = leg_q + (size_t)inst * 10 + 5 * leg;
+  const double *q = (ticks ? ticks[inst].leg_q : leg_q + (size_t)inst * 10) + 5 * leg;
+  const bool offset_applied = ticks && !(ticks[inst].flags & HMPC_TICK_LEG_Q_MOTOR);
   const double q0 = q[0], q1 = q[1];
-  const double q2 = q[2] + 0.3 * 3.14159, q3 = q[3] - 0.6 * 3.14159, q4 = q[4] + 0.3 * 3.14159;
+  const double q2 = offset_applied ? q[2] : q[2] + 0.3 * 3.14159, q3 = offset_applied ? q[3] : q[3] - 0.6 * 3.14159,
+               q4 = offset_applied ? q[4] : q[4] + 0.3 * 3.14159;
   const double side = (leg == 0) ? 1.0 : -1.0;
   double s0, c0, s1, c1, s2, c2, s23, c23, s234, c234;
   det_sincos(q0, s0, c0);

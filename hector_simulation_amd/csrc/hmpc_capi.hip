@@ -126,6 +126,12 @@ struct hmpc_handle {
   // parity hook (hmpc_debug_solve_external_qp): device copies of caller-supplied QP data, only set during that call
   const float *d_ext_H, *d_ext_g, *d_ext_Fc;
   int ext_ld;
+  int iter_cap;  // hmpc_set_max_iterations: cap on the active-set iterations of every solve (0 = the variant's own bound)
+  // size classes of a device-resident batch whose widest reduced QP the host was not told (hmpc_set_max_reduced_vars < 0):
+  // stance leg-steps per instance, written on the device by the record builder (cls_valid) or, for records handed in by
+  // pointer, by classify_records_kernel at the head of every solve
+  unsigned char *d_cls;
+  int cls_valid;
 };
 constexpr int REPAIR_GRID_CAP = 2048;  // workgroups of the device-side safe launch = most instances it can repair per solve
 
@@ -180,19 +186,30 @@ static const Variant &pick_variant(const hmpc_handle *h, int *index) {
   return v[best];
 }
 
-// warm: -1 = the handle's setting, 0/1 = override for this launch (the safe pass starts cold without touching the handle);
-// carry_wset = false keeps a repeated launch of the same batch from consuming/advancing the tick-to-tick working sets
-static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int dbg_index, const int *d_index_list = nullptr,
-                  int n_list = 0, double relax = 0.0, int warm = -1, bool carry_wset = true,
-                  const unsigned int *d_list_count = nullptr, bool record_flagged = false) {
+struct LaunchOpt {
+  bool assemble_only = false;
+  int dbg_index = 0;
+  const int *d_index_list = nullptr;  // workgroup b solves instance d_index_list[b] with the SAFE variant (re-solve of flagged ones)
+  int n_list = 0;
+  double relax = 0.0;
+  int warm = -1;           // -1 = the handle's setting, 0/1 = override for this launch (the safe pass starts cold without touching the handle)
+  bool carry_wset = true;  // false keeps a repeated launch of the same batch from consuming/advancing the tick-to-tick working sets
+  const unsigned int *d_list_count = nullptr;
+  bool record_flagged = false;
+  int variant = -1;        // -1 = pick_variant; else this entry of variants() (the size-class launches)
+  int cls_lo = 0, cls_hi = -1;  // cls_hi >= 0: only instances whose size class lies in [cls_lo, cls_hi] (h->d_cls)
+};
+
+static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   int vi = 0;
   const Variant *pv = &pick_variant(h, &vi);
-  if (d_index_list && vi != V2_WIDE) {  // safe variant: working set as large as the variable count
+  if (o.variant >= 0) vi = o.variant, pv = &variants()[vi];
+  if (o.d_index_list && vi != V2_WIDE) {  // safe variant: working set as large as the variable count
     vi = (h->nc == 3) ? V3_SAFE : ((h->setup.horizon <= 10) ? N_FAST : N_FAST + 1);
     pv = &variants()[vi];
   }  // (the wide variant is its own safe pass: cold start, same working-set capacity -- LDS has no room for more)
   const Variant &v = *pv;
-  kernel_fn fn = assemble_only ? v.assemble : v.solve;
+  kernel_fn fn = o.assemble_only ? v.assemble : v.solve;
   if (!h->attrs_set[vi]) {
     HIP_TRY(hipFuncSetAttribute((const void *)v.solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.smem));
     HIP_TRY(hipFuncSetAttribute((const void *)v.assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.smem));
@@ -209,26 +226,77 @@ static int launch(hmpc_handle *h, hipStream_t stream, bool assemble_only, int db
   a.status = h->d_status;
   a.x64 = h->d_x64;
   a.obj64 = h->d_obj64;
-  a.dbg_index = dbg_index;
+  a.dbg_index = o.dbg_index;
   a.dbg_f = h->d_dbg_f;
   a.dbg_i = h->d_dbg_i;
   a.prof = h->d_prof;
-  a.warm = (warm < 0) ? h->warm : warm;
-  a.index_list = d_index_list;
-  a.wset = (h->tick_warm && !assemble_only && carry_wset) ? h->d_wset : nullptr;
+  a.warm = (o.warm < 0) ? h->warm : o.warm;
+  a.index_list = o.d_index_list;
+  a.wset = (h->tick_warm && !o.assemble_only && o.carry_wset) ? h->d_wset : nullptr;
   a.flagged = h->d_flagged;
   a.wset_shift = h->tick_shift;
-  a.relax = relax;
-  a.flag_list = record_flagged ? h->d_flag_list : nullptr;
-  a.flag_count = record_flagged ? h->d_flag_count : nullptr;
-  a.flag_cap = record_flagged ? (h->max_batch < REPAIR_GRID_CAP ? h->max_batch : REPAIR_GRID_CAP) : 0;
-  a.list_count = d_list_count;
+  a.relax = o.relax;
+  a.flag_list = o.record_flagged ? h->d_flag_list : nullptr;
+  a.flag_count = o.record_flagged ? h->d_flag_count : nullptr;
+  a.flag_cap = o.record_flagged ? (h->max_batch < REPAIR_GRID_CAP ? h->max_batch : REPAIR_GRID_CAP) : 0;
+  a.list_count = o.d_list_count;
   a.ext_H = h->d_ext_H, a.ext_g = h->d_ext_g, a.ext_Fc = h->d_ext_Fc, a.ext_ld = h->ext_ld;
-  const int grid = assemble_only ? 1 : (d_index_list ? n_list : h->batch);
+  a.iter_cap = h->iter_cap;
+  a.cls = (o.cls_hi >= 0) ? h->d_cls : nullptr;
+  a.cls_lo = o.cls_lo, a.cls_hi = o.cls_hi;
+  const int grid = o.assemble_only ? 1 : (o.d_index_list ? o.n_list : h->batch);
   if (grid < 1) return HMPC_OK;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(v.nt), v.smem, stream, a);
   HIP_TRY(hipGetLastError());
   return HMPC_OK;
+}
+
+// One solve of the current batch, enqueued on `stream` -- what hmpc_solve does and what hmpc_time_solve times:
+//  * widest reduced QP known (host-uploaded records, or hmpc_set_max_reduced_vars >= 0): one launch of the variant
+//    that holds it;
+//  * unknown (records built on the device or handed in by device pointer; two contacts): the instances' size classes are
+//    on the device (from the record builder, else counted here from the gait bytes) and EVERY variant of the family is
+//    launched over the whole batch -- a workgroup whose instance belongs to another variant leaves at once -- so that a
+//    walking sweep built on the device runs on the 60-variable kernel without the host ever seeing a gait table;
+//  * device repair: the fast launches list what they flag, the safe variant follows over that list (trimmed on the
+//    device by the counter: workgroups beyond it leave at once).  One stream per handle at a time: the list and its
+//    counter belong to the handle, two solves of one handle in flight on two streams would race on them.
+static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
+  const bool repair = h->device_repair != 0;
+  if (repair) HIP_TRY(hipMemsetAsync(h->d_flag_count, 0, sizeof(unsigned int), stream));
+  LaunchOpt o;
+  o.carry_wset = carry_wset;
+  o.record_flagged = repair;
+  int rc = HMPC_OK;
+  if (h->nc == 2 && h->max_stance < 0 && h->d_cls) {
+    if (!h->cls_valid) {
+      hipLaunchKernelGGL(hmpc::classify_records_kernel, dim3((h->batch + 255) / 256), dim3(256), 0, stream, h->d_records,
+                         (int)h->stride, h->batch, h->setup.horizon, h->setup.f_max, h->d_cls);
+      HIP_TRY(hipGetLastError());
+    }
+    const int hz = h->setup.horizon;
+    // variants(): [0] <60,10,128>, [1] <120,10,256>, [2] <60,20,128>, [3] <120,20,256>, V2_WIDE <240,20,512>
+    o.variant = (hz <= 10) ? 0 : 2, o.cls_lo = 0, o.cls_hi = 10;
+    rc = launch(h, stream, o);
+    if (rc != HMPC_OK) return rc;
+    o.variant = (hz <= 10) ? 1 : 3, o.cls_lo = 11, o.cls_hi = (hz <= 10) ? 255 : 20;  // (> 20 at h <= 10 cannot occur)
+    rc = launch(h, stream, o);
+    if (rc != HMPC_OK) return rc;
+    if (hz > 10) {
+      o.variant = V2_WIDE, o.cls_lo = 21, o.cls_hi = 255;
+      rc = launch(h, stream, o);
+    }
+  } else {
+    rc = launch(h, stream, o);
+  }
+  if (rc != HMPC_OK || !repair) return rc;
+  LaunchOpt s;
+  s.d_index_list = h->d_flag_list;
+  s.n_list = h->batch < REPAIR_GRID_CAP ? h->batch : REPAIR_GRID_CAP;
+  s.warm = 0;
+  s.carry_wset = carry_wset;
+  s.d_list_count = h->d_flag_count;
+  return launch(h, stream, s);
 }
 
 extern "C" {
@@ -325,6 +393,11 @@ int hmpc_create_ex(hmpc_handle **out, const struct problem_setup *setup, int max
     hmpc_destroy(h);
     return HMPC_E_HIP;
   }
+  if (n_contacts == 2 && (hipMalloc(&h->d_cls, (size_t)max_batch) != hipSuccess || hipMemset(h->d_cls, 0, (size_t)max_batch) != hipSuccess)) {
+    g_hip_err = "hipMalloc failed in hmpc_create";
+    hmpc_destroy(h);
+    return HMPC_E_HIP;
+  }
   h->d_records = h->d_records_own;
   h->d_forces = h->d_forces_own;
   h->d_status = h->d_status_own;
@@ -348,6 +421,7 @@ int hmpc_destroy(hmpc_handle *h) {
   if (h->d_flagged) hipFree(h->d_flagged);
   if (h->d_flag_list) hipFree(h->d_flag_list);
   if (h->d_flag_count) hipFree(h->d_flag_count);
+  if (h->d_cls) hipFree(h->d_cls);
   delete h;
   return HMPC_OK;
 }
@@ -362,6 +436,7 @@ static int upload_common(hmpc_handle *h, const void *host_records, int batch, bo
     HIP_TRY(hipMemcpy(h->d_records_own, host_records, (size_t)batch * h->stride, hipMemcpyHostToDevice));
   h->d_records = h->d_records_own;
   h->batch = batch;
+  h->cls_valid = 0;
   // host-side scan of the gait tables: the widest reduced QP in the batch picks the kernel variant (LDS footprint)
   const int hz = h->setup.horizon;
   int mx = 0;
@@ -407,13 +482,20 @@ int hmpc_set_device_records(hmpc_handle *h, const void *device_records, int batc
   if (batch > h->max_batch) return HMPC_E_BATCH;
   h->d_records = (const unsigned char *)device_records;
   h->batch = batch;
-  h->max_stance = -1;
+  h->max_stance = -1;  // unknown: hmpc_solve counts the size classes on the device (or hmpc_set_max_reduced_vars tells)
+  h->cls_valid = 0;
   return HMPC_OK;
 }
 
 int hmpc_set_max_reduced_vars(hmpc_handle *h, int n_reduced) {
   if (!h) return HMPC_E_ARG;
   h->max_stance = n_reduced;
+  return HMPC_OK;
+}
+
+int hmpc_set_max_iterations(hmpc_handle *h, int max_iter) {
+  if (!h || max_iter < 0) return HMPC_E_ARG;
+  h->iter_cap = max_iter;
   return HMPC_OK;
 }
 
@@ -463,25 +545,27 @@ int hmpc_solve(hmpc_handle *h, void *stream) {
   if (h->batch == 0) return HMPC_OK;
   HIP_TRY(hipSetDevice(h->device));
   h->last_stream = (hipStream_t)stream;
-  if (!h->device_repair) return launch(h, (hipStream_t)stream, false, 0);
-  // fast launch that lists what it flags, then the safe variant over that list -- sized on the host for the worst case
-  // it accepts, trimmed on the device by the counter (workgroups beyond it leave at once): no host round trip
-  HIP_TRY(hipMemsetAsync(h->d_flag_count, 0, sizeof(unsigned int), (hipStream_t)stream));
-  int rc = launch(h, (hipStream_t)stream, false, 0, nullptr, 0, 0.0, -1, true, nullptr, /*record_flagged=*/true);
-  if (rc != HMPC_OK) return rc;
-  const int cap = h->batch < REPAIR_GRID_CAP ? h->batch : REPAIR_GRID_CAP;
-  return launch(h, (hipStream_t)stream, false, 0, h->d_flag_list, cap, 0.0, /*warm=*/0, true, h->d_flag_count);
+  return enqueue_solve(h, (hipStream_t)stream, /*carry_wset=*/true);
 }
 
 int hmpc_set_device_repair(hmpc_handle *h, int on) {
   if (!h) return HMPC_E_ARG;
   HIP_TRY(hipSetDevice(h->device));
-  if (on && !h->d_flag_list) {
+  if (on && (!h->d_flag_list || !h->d_flag_count)) {
+    // both buffers or neither: they are committed to the handle only once both exist and are cleared
     const int cap = h->max_batch < REPAIR_GRID_CAP ? h->max_batch : REPAIR_GRID_CAP;
-    HIP_TRY(hipMalloc(&h->d_flag_list, (size_t)cap * sizeof(int)));
-    HIP_TRY(hipMalloc(&h->d_flag_count, sizeof(unsigned int)));
-    HIP_TRY(hipMemset(h->d_flag_list, 0, (size_t)cap * sizeof(int)));
-    HIP_TRY(hipMemset(h->d_flag_count, 0, sizeof(unsigned int)));
+    int *list = nullptr;
+    unsigned int *count = nullptr;
+    if (hipMalloc(&list, (size_t)cap * sizeof(int)) != hipSuccess || hipMalloc(&count, sizeof(unsigned int)) != hipSuccess ||
+        hipMemset(list, 0, (size_t)cap * sizeof(int)) != hipSuccess || hipMemset(count, 0, sizeof(unsigned int)) != hipSuccess) {
+      if (list) (void)hipFree(list);
+      if (count) (void)hipFree(count);
+      g_hip_err = "hipMalloc failed in hmpc_set_device_repair";
+      return HMPC_E_HIP;
+    }
+    if (h->d_flag_list) (void)hipFree(h->d_flag_list);
+    if (h->d_flag_count) (void)hipFree(h->d_flag_count);
+    h->d_flag_list = list, h->d_flag_count = count;
   }
   h->device_repair = on ? 1 : 0;
   return HMPC_OK;
@@ -498,7 +582,9 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
   std::vector<int> idx;
   for (int i = 0; i < h->batch; ++i) {
     const uint32_t c = HMPC_STATUS_CODE(st[i]);
-    if (c == HMPC_S_WORKSET || c == HMPC_S_MAXITER || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT) idx.push_back(i);
+    // (a solve that ran into the caller's own iteration cap, hmpc_set_max_iterations, is the caller's answer: not re-solved)
+    if (c == HMPC_S_WORKSET || (c == HMPC_S_MAXITER && h->iter_cap <= 0) || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT)
+      idx.push_back(i);
   }
   if (idx.empty()) return HMPC_OK;
   int *d_idx = nullptr;  // lives in the handle's scratch: nothing to free on the error paths below
@@ -510,7 +596,9 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
   }
   HIP_TRY(hipMemcpy(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
   // the safe pass starts cold, as the reference does (launch parameter; the handle's own setting is not touched)
-  int rc = launch(h, h->last_stream, false, 0, d_idx, (int)idx.size(), 0.0, /*warm=*/0);
+  LaunchOpt so;
+  so.d_index_list = d_idx, so.n_list = (int)idx.size(), so.warm = 0;
+  int rc = launch(h, h->last_stream, so);
   if (rc != HMPC_OK) return rc;
   HIP_TRY(hipStreamSynchronize(h->last_stream));
   if (n_resolved) *n_resolved = (int)idx.size();
@@ -522,11 +610,12 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
     HIP_TRY(hipMemcpy(st.data(), h->d_status, (size_t)h->batch * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (int i : idx) {
       const uint32_t c = HMPC_STATUS_CODE(st[i]);
-      if (c == HMPC_S_MAXITER || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT) still.push_back(i);
+      if ((c == HMPC_S_MAXITER && h->iter_cap <= 0) || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT) still.push_back(i);
     }
     if (still.empty()) break;
     HIP_TRY(hipMemcpy(d_idx, still.data(), still.size() * sizeof(int), hipMemcpyHostToDevice));
-    rc = launch(h, h->last_stream, false, 0, d_idx, (int)still.size(), relax_levels[lvl], /*warm=*/0);
+    so.n_list = (int)still.size(), so.relax = relax_levels[lvl];
+    rc = launch(h, h->last_stream, so);
     if (rc != HMPC_OK) return rc;
     HIP_TRY(hipStreamSynchronize(h->last_stream));
   }
@@ -585,7 +674,7 @@ int hmpc_time_solve(hmpc_handle *h, void *stream, int reps, float *ms_per_launch
   for (int i = 0; i < reps; ++i) {
     // a single timed launch is a genuine solve of the current batch (it consumes and leaves the tick-to-tick working sets);
     // repetitions of the same batch must not advance them again
-    int rc = launch(h, s, false, 0, nullptr, 0, 0.0, -1, /*carry_wset=*/reps == 1);
+    int rc = enqueue_solve(h, s, /*carry_wset=*/reps == 1);  // the same launches hmpc_solve enqueues (size classes, device repair)
     if (rc != HMPC_OK) return rc;
   }
   HIP_TRY(hipEventRecord(ev.e1, s));
@@ -607,7 +696,9 @@ int hmpc_debug_assemble(hmpc_handle *h, int index, int *n, int *m, int *var_ind,
     HIP_TRY(hipMalloc(&h->d_dbg_i, sizeof(int) * (2 + MAX_VARS_ANY)));
   }
   HIP_TRY(hipMemset(h->d_dbg_i, 0, sizeof(int) * (2 + MAX_VARS_ANY)));
-  int rc = launch(h, 0, true, index);
+  LaunchOpt ao;
+  ao.assemble_only = true, ao.dbg_index = index;
+  int rc = launch(h, 0, ao);
   if (rc != HMPC_OK) return rc;
   HIP_TRY(hipDeviceSynchronize());
   std::vector<float> hf(v.dbg_floats);
@@ -639,6 +730,14 @@ int hmpc_debug_assemble(hmpc_handle *h, int index, int *n, int *m, int *var_ind,
 int hmpc_debug_solve_external_qp(hmpc_handle *h, const float *H, const float *g, const float *Fc, int ld) {
   if (!h || !H || !g || !Fc || ld < 1) return HMPC_E_ARG;
   if (h->batch == 0) return HMPC_OK;
+  {
+    // the kernel reads H[i*ld + j], g[i] for i, j < the instance's reduced-variable count: ld must cover the widest one
+    // (known for host-uploaded records; otherwise whatever the variant that will be launched can hold)
+    int vi = 0;
+    const Variant &v = pick_variant(h, &vi);
+    const int need = (h->max_stance >= 0) ? h->max_stance : v.nmax;
+    if (ld < need) return HMPC_E_ARG;
+  }
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->last_stream));
   const size_t nb = (size_t)h->batch, nfc = (size_t)8 * h->nc * 6 * h->nc;
@@ -654,7 +753,9 @@ int hmpc_debug_solve_external_qp(hmpc_handle *h, const float *H, const float *g,
   HIP_TRY(hipMemcpy(dg, g, sizeof(float) * nb * ld, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dF, Fc, sizeof(float) * nb * nfc, hipMemcpyHostToDevice));
   h->d_ext_H = dH, h->d_ext_g = dg, h->d_ext_Fc = dF, h->ext_ld = ld;
-  const int rc = launch(h, h->last_stream, false, 0, nullptr, 0, 0.0, -1, /*carry_wset=*/false);
+  LaunchOpt xo;
+  xo.carry_wset = false;
+  const int rc = launch(h, h->last_stream, xo);
   hipError_t e = hipStreamSynchronize(h->last_stream);
   h->d_ext_H = h->d_ext_g = h->d_ext_Fc = nullptr;
   h->ext_ld = 0;
@@ -675,7 +776,7 @@ int hmpc_debug_phase_cycles(hmpc_handle *h, long long *cycles /*[batch][NPROF = 
   const size_t nb = (size_t)h->max_batch * hmpc::NPROF * sizeof(long long);
   if (!h->d_prof) HIP_TRY(hipMalloc(&h->d_prof, nb));
   HIP_TRY(hipMemset(h->d_prof, 0, nb));
-  int rc = launch(h, h->last_stream, false, 0);
+  int rc = launch(h, h->last_stream, LaunchOpt());
   if (rc != HMPC_OK) return rc;
   HIP_TRY(hipStreamSynchronize(h->last_stream));
   HIP_TRY(hipMemcpy(cycles, h->d_prof, (size_t)h->batch * hmpc::NPROF * sizeof(long long), hipMemcpyDeviceToHost));
@@ -697,12 +798,13 @@ int hmpc_build_records_device(hmpc_handle *h, const void *device_ticks, int batc
     const int bs = ((nwords + 63) / 64) * 64 > 256 ? 256 : ((nwords + 63) / 64) * 64;
     hipLaunchKernelGGL(hmpc::build_records_kernel, dim3(batch), dim3(bs), 0, (hipStream_t)stream,
                        (const hmpc_tick_inputs *)device_ticks, batch, h->setup.horizon, dtMPC, h->d_records_own,
-                       (int)h->stride, device_wpd_out);
+                       (int)h->stride, device_wpd_out, h->setup.f_max, h->d_cls);
     HIP_TRY(hipGetLastError());
   }
   h->d_records = h->d_records_own;
   h->batch = batch;
-  h->max_stance = -1;
+  h->max_stance = -1;  // the builder left every instance's size class on the device: hmpc_solve routes by it
+  h->cls_valid = 1;
   h->last_stream = (hipStream_t)stream;
   return HMPC_OK;
 }
@@ -765,7 +867,8 @@ int hmpc_leg_torques_device(hmpc_handle *h, const double *device_rBody, const do
   if (h->batch > 0) {
     const int total = 2 * h->batch;
     hipLaunchKernelGGL(hmpc::leg_torque_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->d_forces,
-                       h->batch, h->setup.horizon, device_rBody, device_leg_q, device_f_ff, device_tau);
+                       h->batch, h->setup.horizon, device_rBody, device_leg_q, device_f_ff, device_tau,
+                       (const hmpc_tick_inputs *)nullptr);
     HIP_TRY(hipGetLastError());
   }
   return HMPC_OK;
@@ -788,6 +891,27 @@ int hmpc_leg_torques(hmpc_handle *h, const double *host_rBody, const double *hos
   HIP_TRY(hipStreamSynchronize(nullptr));
   if (host_f_ff) HIP_TRY(hipMemcpy(host_f_ff, d_f, sizeof(double) * 12 * nb, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(host_tau, d_t, sizeof(double) * 10 * nb, hipMemcpyDeviceToHost));
+  return HMPC_OK;
+}
+
+// One MPC tick of a whole batch without leaving the device (rows f1+f2 -> a1..a16 -> f3 of SURVEY.md section 8):
+// updateMPCIfNeeded's input construction + gait table (ConvexMPCLocomotion.cpp:283-406, GaitGenerator.cpp:85-103), the solve
+// routed by size class (a walking tick runs on the 60-variable variant), then f_ff = -rBody [GRF; GRM] and tau = J_fm' f_ff
+// (ConvexMPCLocomotion.cpp:419-440, common/LegController.cpp:57-61, 108-167) -- three or four launches on ONE stream, no
+// host synchronisation, nothing but the tick structs in and the torques out.
+int hmpc_tick_solve_device(hmpc_handle *h, const void *device_ticks, int batch, double dtMPC, double *device_wpd_out,
+                           double *device_f_ff, double *device_tau, void *stream) {
+  if (!h || !device_ticks || !device_tau || batch < 0) return HMPC_E_ARG;
+  int rc = hmpc_build_records_device(h, device_ticks, batch, dtMPC, device_wpd_out, stream);
+  if (rc != HMPC_OK) return rc;
+  if (batch == 0) return HMPC_OK;
+  rc = enqueue_solve(h, (hipStream_t)stream, /*carry_wset=*/true);
+  if (rc != HMPC_OK) return rc;
+  const int total = 2 * batch;
+  hipLaunchKernelGGL(hmpc::leg_torque_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->d_forces, batch,
+                     h->setup.horizon, (const double *)nullptr, (const double *)nullptr, device_f_ff, device_tau,
+                     (const hmpc_tick_inputs *)device_ticks);
+  HIP_TRY(hipGetLastError());
   return HMPC_OK;
 }
 
@@ -823,7 +947,7 @@ int hmpc_download_f64(hmpc_handle *h, double *x, double *obj) {
     // the tick-to-tick working sets a second time -- then give flagged instances the same safe pass hmpc_download gives
     int rc = hmpc_enable_f64_output(h);
     if (rc != HMPC_OK) return rc;
-    rc = launch(h, h->last_stream, false, 0, nullptr, 0, 0.0, -1, /*carry_wset=*/false);
+    rc = enqueue_solve(h, h->last_stream, /*carry_wset=*/false);
     if (rc != HMPC_OK) return rc;
   }
   HIP_TRY(hipStreamSynchronize(h->last_stream));
@@ -930,6 +1054,7 @@ static void solve_global(void) {
   const uint32_t *pst = (const uint32_t *)(forces + 12 * hz);
   const size_t out_bytes = sizeof(float) * 12 * hz + sizeof(uint32_t);
   uint32_t st = 0;
+  hmpc_set_max_iterations(g_handle, g_update.max_iterations > 0 ? g_update.max_iterations : 0);
   int rc = hmpc_upload_records_async(g_handle, rec, 1, nullptr);  // pinned source: a true asynchronous copy
   if (rc == HMPC_OK) rc = hmpc_solve(g_handle, nullptr);
   if (rc == HMPC_OK && (hipMemcpyAsync(g_pin + g_pin_rec_bytes, g_dev_out, out_bytes, hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
@@ -938,7 +1063,7 @@ static void solve_global(void) {
   if (rc == HMPC_OK) {
     st = *pst;
     const uint32_t c0 = HMPC_STATUS_CODE(st);
-    if (c0 == HMPC_S_WORKSET || c0 == HMPC_S_MAXITER || c0 == HMPC_S_INFEASIBLE || c0 == HMPC_S_KKT) {
+    if (c0 == HMPC_S_WORKSET || (c0 == HMPC_S_MAXITER && g_handle->iter_cap <= 0) || c0 == HMPC_S_INFEASIBLE || c0 == HMPC_S_KKT) {
       // flagged by the fast variant: the safe pass (full-size working set, then relaxed bounds), as hmpc_download gives it
       rc = hmpc_resolve_failed(g_handle, nullptr);
       if (rc == HMPC_OK && hipMemcpy(g_pin + g_pin_rec_bytes, g_dev_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess)
@@ -983,7 +1108,11 @@ double get_solution(int index) {
 
 void update_solver_settings(int max_iter, double rho, double sigma, double solver_alpha, double terminate,
                             double use_jcqp) {
-  // stored and, as in the reference (convexMPC_interface.cpp:112-118), read by nothing: the active-set solver has no knobs
+  // stored as the reference stores them (convexMPC_interface.cpp:112-118, where nothing reads them: the qpOASES path has no
+  // use for the JCQP/ADMM knobs).  The one with a meaning for an active-set solver is honoured here: max_iter > 0 caps the
+  // active-set iterations of every later legacy solve -- the analogue of the reference's nWSR = 500 (SolverMPC.cpp:706);
+  // a tick that would need more reports HMPC_S_MAXITER (and the "failed to solve!" line).  0 (the reference's zero-
+  // initialised global) = no cap.  rho, sigma, solver_alpha, terminate, use_jcqp have no counterpart and stay unread.
   g_update.max_iterations = max_iter;
   g_update.rho = rho;
   g_update.sigma = sigma;

@@ -103,15 +103,16 @@ thread_local std::string g_group_err;
     }                                                                                    \
   } while (0)
 
-constexpr int PACK_WORDS = 13;  // 12 step-0 values (F_L F_R M_L M_R) + the status word, per instance
+// per instance the exchange carries pw = 6 nc + 1 words: the step-0 wrench the controller reads (ConvexMPCLocomotion.cpp:
+// 419-440: F of each contact, then M of each contact -- 12 values for two feet, 18 with the hand contact) + the status word
 
-// forces [n][12h] float, status [n] -> packed [n][13] 32-bit words (one coalesced row per instance)
+// forces [n][6 nc h] float, status [n] -> packed [n][pw] 32-bit words (one coalesced row per instance)
 __global__ void pack_step0_kernel(const float *__restrict__ forces, const uint32_t *__restrict__ status, int n, int width,
-                                  uint32_t *__restrict__ out) {
+                                  int pw, uint32_t *__restrict__ out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * PACK_WORDS) return;
-  const int i = t / PACK_WORDS, c = t % PACK_WORDS;
-  out[t] = (c < 12) ? __float_as_uint(forces[(size_t)i * width + c]) : status[i];
+  if (t >= n * pw) return;
+  const int i = t / pw, c = t % pw;
+  out[t] = (c < pw - 1) ? __float_as_uint(forces[(size_t)i * width + c]) : status[i];
 }
 
 struct Member {
@@ -119,8 +120,8 @@ struct Member {
   hmpc_handle *h = nullptr;
   hipStream_t solve_stream = nullptr, comm_stream = nullptr;
   hipEvent_t packed = nullptr, gathered_ev = nullptr;
-  uint32_t *d_pack = nullptr;      // [cap][13]
-  uint32_t *d_gathered = nullptr;  // [G][cap][13]
+  uint32_t *d_pack = nullptr;      // [cap][pw]
+  uint32_t *d_gathered = nullptr;  // [G][cap][pw]
   int lo = 0, n = 0;               // slice of the current batch
   int posted_lo = 0, posted_n = 0; // slice of the batch whose exchange was posted last (may differ from the current one)
 };
@@ -130,10 +131,12 @@ struct Member {
 struct hmpc_group {
   problem_setup setup;
   int G = 0, cap = 0 /* instances per member buffer = largest possible slice */, max_batch = 0, batch = 0;
+  int nc = 2;  // contacts per horizon step of every member handle (hmpc_group_create_ex)
+  int pw = 13; // 32-bit words per instance in the exchange: 6 nc + 1
   int transport = HMPC_GROUP_RCCL;
   std::vector<Member> m;
   std::vector<ncclComm_t> comms;
-  uint32_t *h_stage = nullptr;  // pinned [G][cap][13]
+  uint32_t *h_stage = nullptr;  // pinned [G][cap][pw]
   // an exchange has been posted and not yet collected (by hmpc_group_wait_gather or hmpc_group_gather_wrench): the
   // pipelined pattern post(k) / solve(k+1) / gather_wrench() collects solve k's exchange, while a gather_wrench after a
   // collected exchange posts a fresh one for the solves enqueued since
@@ -181,8 +184,15 @@ int hmpc_group_destroy(hmpc_group *g) {
 
 int hmpc_group_create(hmpc_group **out, const struct problem_setup *setup, const int *devices, int n_devices,
                       int max_batch, int transport) {
+  return hmpc_group_create_ex(out, setup, devices, n_devices, max_batch, transport, 2);
+}
+
+int hmpc_group_contacts(const hmpc_group *g) { return g ? g->nc : HMPC_E_ARG; }
+
+int hmpc_group_create_ex(hmpc_group **out, const struct problem_setup *setup, const int *devices, int n_devices,
+                         int max_batch, int transport, int n_contacts) {
   GENTER();
-  if (!out || !setup || n_devices < 1 || max_batch < 1) return HMPC_E_ARG;
+  if (!out || !setup || n_devices < 1 || max_batch < 1 || (n_contacts != 2 && n_contacts != 3)) return HMPC_E_ARG;
   if (transport != HMPC_GROUP_AUTO && transport != HMPC_GROUP_RCCL && transport != HMPC_GROUP_P2P) return HMPC_E_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
@@ -201,6 +211,8 @@ int hmpc_group_create(hmpc_group **out, const struct problem_setup *setup, const
   g->G = n_devices;
   g->max_batch = max_batch;
   g->cap = (max_batch + n_devices - 1) / n_devices;
+  g->nc = n_contacts;
+  g->pw = 6 * n_contacts + 1;
   g->m.resize(n_devices);
   bool repeated = false;
   for (int i = 0; i < n_devices; ++i) {
@@ -236,10 +248,10 @@ int hmpc_group_create(hmpc_group **out, const struct problem_setup *setup, const
       return HMPC_E_HIP;                                                 \
     }                                                                    \
   } while (0)
-  const size_t slice_words = (size_t)g->cap * PACK_WORDS;
+  const size_t slice_words = (size_t)g->cap * g->pw;
   for (Member &mb : g->m) {
     GHIPD(hipSetDevice(mb.device));
-    GTRY(hmpc_create(&mb.h, setup, g->cap, mb.device));
+    GTRY(hmpc_create_ex(&mb.h, setup, g->cap, mb.device, n_contacts));
     GTRY(hmpc_set_device_repair(mb.h, 1));
     GHIPD(hipStreamCreateWithFlags(&mb.solve_stream, hipStreamNonBlocking));
     GHIPD(hipStreamCreateWithFlags(&mb.comm_stream, hipStreamNonBlocking));
@@ -307,7 +319,7 @@ int hmpc_group_upload_records(hmpc_group *g, const void *host_records, int batch
   GENTER();
   if (!g || (!host_records && batch > 0) || batch < 0) return HMPC_E_ARG;
   if (batch > g->max_batch) return HMPC_E_BATCH;
-  const size_t stride = hmpc_record_stride(g->setup.horizon);
+  const size_t stride = hmpc_record_stride_ex(g->setup.horizon, g->nc);
   static const unsigned char empty = 0;
   if (!host_records) host_records = &empty;  // batch == 0
   for (int i = 0; i < g->G; ++i) {
@@ -362,9 +374,12 @@ int hmpc_group_solve(hmpc_group *g) {
 int hmpc_group_set_exchange_repair(hmpc_group *g, int on) {
   GENTER();
   if (!g) return HMPC_E_ARG;
-  for (Member &mb : g->m) {
-    const int rc = hmpc_set_device_repair(mb.h, on);
-    if (rc != HMPC_OK) return rc;
+  for (size_t i = 0; i < g->m.size(); ++i) {
+    const int rc = hmpc_set_device_repair(g->m[i].h, on);
+    if (rc != HMPC_OK) {  // all members or none: the ones already switched go back to the previous setting
+      for (size_t j = 0; j < i; ++j) (void)hmpc_set_device_repair(g->m[j].h, g->exchange_repair ? 1 : 0);
+      return rc;
+    }
   }
   g->exchange_repair = on != 0;
   return HMPC_OK;
@@ -375,7 +390,7 @@ int hmpc_group_set_exchange_repair(hmpc_group *g, int on) {
 int hmpc_group_post_gather(hmpc_group *g) {
   GENTER();
   if (!g) return HMPC_E_ARG;
-  const int width = 12 * g->setup.horizon;
+  const int width = 6 * g->nc * g->setup.horizon, PACK_WORDS = g->pw;
   for (Member &mb : g->m) {
     GHIP(hipSetDevice(mb.device));
     // the previous gather still reads this member's d_pack (RCCL: on its own comm stream; P2P: on every destination's):
@@ -391,7 +406,7 @@ int hmpc_group_post_gather(hmpc_group *g) {
       if (rc != HMPC_OK) return rc;
       const int total = mb.n * PACK_WORDS;
       hipLaunchKernelGGL(pack_step0_kernel, dim3((total + 255) / 256), dim3(256), 0, mb.solve_stream, d_forces, d_status,
-                         mb.n, width, mb.d_pack);
+                         mb.n, width, PACK_WORDS, mb.d_pack);
       GHIP(hipGetLastError());
     }
     GHIP(hipEventRecord(mb.packed, mb.solve_stream));
@@ -436,7 +451,7 @@ int hmpc_group_post_gather(hmpc_group *g) {
   return HMPC_OK;
 }
 
-// gathered device copy held by `member`: wrench/status interleaved as [G][cap][13] words; slot s holds member s's
+// gathered device copy held by `member`: wrench/status interleaved as [G][cap][6 nc + 1] words; slot s holds member s's
 // slice (instances lo_s .. lo_s + n_s - 1 in rows 0 .. n_s - 1).  Valid after hmpc_group_wait_gather.
 int hmpc_group_device_gathered(hmpc_group *g, int member, const uint32_t **gathered, int *slot_rows) {
   if (!g || member < 0 || member >= g->G || !gathered) return HMPC_E_ARG;
@@ -468,6 +483,7 @@ int hmpc_group_gather_wrench(hmpc_group *g, float *host_wrench, uint32_t *host_s
   g->gather_posted = false;
   Member &m0 = g->m[0];
   GHIP(hipSetDevice(m0.device));
+  const int PACK_WORDS = g->pw, nw = g->pw - 1;
   const size_t slice_words = (size_t)g->cap * PACK_WORDS;
   GHIP(hipMemcpyAsync(g->h_stage, m0.d_gathered, slice_words * sizeof(uint32_t) * g->G, hipMemcpyDeviceToHost, m0.comm_stream));
   GHIP(hipStreamSynchronize(m0.comm_stream));
@@ -475,8 +491,8 @@ int hmpc_group_gather_wrench(hmpc_group *g, float *host_wrench, uint32_t *host_s
     const Member &mb = g->m[s];
     const uint32_t *rows = g->h_stage + (size_t)s * slice_words;
     for (int i = 0; i < mb.posted_n; ++i) {
-      if (host_wrench) memcpy(host_wrench + (size_t)(mb.posted_lo + i) * 12, rows + (size_t)i * PACK_WORDS, 12 * sizeof(float));
-      if (host_status) host_status[mb.posted_lo + i] = rows[(size_t)i * PACK_WORDS + 12];
+      if (host_wrench) memcpy(host_wrench + (size_t)(mb.posted_lo + i) * nw, rows + (size_t)i * PACK_WORDS, nw * sizeof(float));
+      if (host_status) host_status[mb.posted_lo + i] = rows[(size_t)i * PACK_WORDS + nw];
     }
   }
   return HMPC_OK;
@@ -487,7 +503,7 @@ int hmpc_group_gather_wrench(hmpc_group *g, float *host_wrench, uint32_t *host_s
 int hmpc_group_download(hmpc_group *g, float *forces, uint32_t *status) {
   GENTER();
   if (!g) return HMPC_E_ARG;
-  const size_t width = (size_t)12 * g->setup.horizon;
+  const size_t width = (size_t)6 * g->nc * g->setup.horizon;
   for (Member &mb : g->m) {
     const int rc = hmpc_download(mb.h, forces ? forces + (size_t)mb.lo * width : nullptr, status ? status + mb.lo : nullptr);
     if (rc != HMPC_OK) return rc;

@@ -81,6 +81,17 @@ struct KernelArgs {
   // unchanged.  nullptr = off (the product path).
   const float *ext_H, *ext_g, *ext_Fc;
   int ext_ld;
+  // cap on the active-set iterations, the analogue of the reference's nWSR = 500 (SolverMPC.cpp:706): 0 = the variant's own
+  // bound.  Block rounds and switch passes count as one iteration each; the block start itself always completes (it is one
+  // inversion that stands for ~20 single-row iterations; checking the cap inside it costs the 168-VGPR variant spills),
+  // the cap is tested before every single-row iteration after it.  A solve that would need more ends as S_MAXITER.
+  int iter_cap;
+  // Size classes (device-resident batches whose widest reduced QP the host does not know): cls[inst] = stance leg-steps of
+  // the instance, written by build_records_kernel / classify_records_kernel; a workgroup leaves at once unless
+  // cls_lo <= cls[inst] <= cls_hi, so that every variant of the family is launched over the whole batch and each instance
+  // is solved by the smallest one that holds it -- no host round trip.  nullptr = every workgroup runs.
+  const unsigned char *cls;
+  int cls_lo, cls_hi;
 };
 constexpr int NPROF = 32;
 enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A, P_A0, P_A1, P_A2, P_G };
@@ -334,6 +345,10 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   const int inst = ASM_ONLY ? args.dbg_index : (args.index_list ? args.index_list[blockIdx.x] : (int)blockIdx.x);
   const int h = args.horizon;
   if (inst >= args.batch) return;
+  if (!ASM_ONLY && args.cls) {  // uniform: this instance belongs to another variant's launch
+    const int c = args.cls[inst];
+    if (c < args.cls_lo || c > args.cls_hi) return;
+  }
   PROF_DECL;
 
   // ---------------- A0: one coalesced burst brings the instance's record into LDS ----------------
@@ -734,7 +749,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     const int l15 = ln & 15, kq = ln >> 4;
     const float wq0 = A.W[kq], wq1 = A.W[kq + 4], wq2 = A.W[kq + 8];
     constexpr int TB = (U + 15) / 16, UU = U * U;
-    constexpr int HB_SPARE = HMAX * (HMAX + 1) / 2 * UU;
+    constexpr int HB_SPARE = SM::HS_BLOCKS * UU;  // the 64 spare words behind the blocks the staging area actually holds
+    static_assert(HB_SPARE + 64 <= (int)(sizeof(A.Hs) / sizeof(float)), "spare words of the padding lanes lie inside Hs");
     const int nchain = h * TB * TB;
     struct Chain {
       bool live, av, bv;
@@ -1295,7 +1311,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   PROF_MARK(P_XU);
 
   int q = 0, iters = 0, code = S_OK;
-  const int itmax = (QCAP >= NMAX || QCAP >= 140) ? 10 * m + 64 : 4 * m + 16;  // the safe variants may take as long as a cold qpOASES run (nWSR up to ~330 seen)
+  const int itmax_v = (QCAP >= NMAX || QCAP >= 140) ? 10 * m + 64 : 4 * m + 16;  // the safe variants may take as long as a cold qpOASES run (nWSR up to ~330 seen)
+  const int itmax = (args.iter_cap > 0 && args.iter_cap < itmax_v) ? args.iter_cap : itmax_v;
   bool c_ignored = false;  // this thread's row was found redundant at a degenerate vertex (violated by round-off only)
 
   // slack of this thread's constraint row on its tighter side at xv (unit-scaled); side = +1 lower, -1 upper
@@ -1472,7 +1489,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         take = (ac != 0) || fresh;
       }
       count_candidates();
-      if (ub(k0 - q < BLOCK_MIN_NEW || k0 > KBMAX)) return false;  // not worth a round / does not fit: the iteration below goes on
+      if (ub(k0 - q < BLOCK_MIN_NEW || k0 > KBMAX)) return false;  // not worth a round / does not fit / iteration cap: the iteration below goes on
       __syncthreads();  // wcount is free again
       ++iters;
       tick = true;  // rows 0..7 may be in the set from here on

@@ -137,6 +137,17 @@ class BatchedMPC:
         """Device-side safe pass inside every solve (include/hector_mpc.h hmpc_set_device_repair)."""
         _check(self.L.hmpc_set_device_repair(self.h, 1 if on else 0), "hmpc_set_device_repair")
 
+    def set_max_iterations(self, max_iter: int) -> None:
+        """Cap on the active-set iterations (0 = none); the nWSR analogue (include/hector_mpc.h hmpc_set_max_iterations)."""
+        _check(self.L.hmpc_set_max_iterations(self.h, int(max_iter)), "hmpc_set_max_iterations")
+
+    def tick_solve_device(self, ticks_ptr: int, batch: int, dt_mpc: float, tau_ptr: int, f_ff_ptr: int = 0, wpd_ptr: int = 0,
+                          stream: int = 0) -> None:
+        """f1+f2 -> solve -> f3 on one stream, everything device-resident (include/hector_mpc.h hmpc_tick_solve_device)."""
+        _check(self.L.hmpc_tick_solve_device(self.h, C.c_void_p(ticks_ptr), int(batch), float(dt_mpc), C.c_void_p(wpd_ptr),
+                                             C.c_void_p(f_ff_ptr), C.c_void_p(tau_ptr), C.c_void_p(stream)),
+               "hmpc_tick_solve_device")
+
     def resolve_failed(self) -> int:
         n = C.c_int(0)
         _check(self.L.hmpc_resolve_failed(self.h, C.byref(n)), "hmpc_resolve_failed")
@@ -165,7 +176,10 @@ class BatchedMPC:
         H = np.ascontiguousarray(H, dtype=np.float32)
         g = np.ascontiguousarray(g, dtype=np.float32)
         Fc = np.ascontiguousarray(Fc, dtype=np.float32)
-        assert H.shape[0] == self.batch and H.shape[1] == H.shape[2] == g.shape[1]
+        if not (H.ndim == 3 and H.shape[0] == self.batch and H.shape[1] == H.shape[2] == g.shape[1] and g.shape[0] == self.batch):
+            raise ValueError(f"H {H.shape} / g {g.shape}: expected [batch={self.batch}, ld, ld] and [batch, ld]")
+        if Fc.shape != (self.batch, 8 * self.contacts, 6 * self.contacts):
+            raise ValueError(f"Fc {Fc.shape}: expected {(self.batch, 8 * self.contacts, 6 * self.contacts)}")
         _check(self.L.hmpc_debug_solve_external_qp(self.h, H.ctypes.data, g.ctypes.data, Fc.ctypes.data, H.shape[1]),
                "hmpc_debug_solve_external_qp")
 
@@ -240,18 +254,19 @@ class DeviceGroup:
     TRANSPORT = {"auto": 0, "rccl": 1, "p2p": 2}
 
     def __init__(self, dt: float, horizon: int, f_max: float, max_batch: int, devices, transport: str = "auto",
-                 mu: float = 0.25):
+                 mu: float = 0.25, contacts: int = 2):
         self.L = _lib.load()
-        self.horizon, self.max_batch = int(horizon), int(max_batch)
+        self.horizon, self.max_batch, self.contacts = int(horizon), int(max_batch), int(contacts)
         self.setup = _lib.ProblemSetup(np.float32(dt), np.float32(mu), np.float32(f_max), int(horizon))
         devs = np.ascontiguousarray(devices, dtype=np.int32)
         self.g = C.c_void_p()
-        rc = self.L.hmpc_group_create(C.byref(self.g), C.byref(self.setup), devs.ctypes.data, len(devs), self.max_batch,
-                                      self.TRANSPORT[transport])
+        rc = self.L.hmpc_group_create_ex(C.byref(self.g), C.byref(self.setup), devs.ctypes.data, len(devs), self.max_batch,
+                                         self.TRANSPORT[transport], self.contacts)
         if rc != 0:
-            raise HmpcError(f"hmpc_group_create failed with {rc}: {self.L.hmpc_group_last_error().decode()}")
+            raise HmpcError(f"hmpc_group_create_ex failed with {rc}: {self.L.hmpc_group_last_error().decode()}")
         self.size = int(self.L.hmpc_group_size(self.g))
-        self.stride = int(self.L.hmpc_record_stride(self.horizon))
+        self.stride = int(self.L.hmpc_record_stride_ex(self.horizon, self.contacts))
+        self.wrench_width = 6 * self.contacts
 
     def _check(self, rc, what):
         if rc != 0:
@@ -311,7 +326,7 @@ class DeviceGroup:
 
     def gather_wrench(self):
         b = self.batch
-        wrench = np.zeros((b, 12), dtype=np.float32)
+        wrench = np.zeros((b, self.wrench_width), dtype=np.float32)
         status = np.zeros(b, dtype=np.uint32)
         self._check(self.L.hmpc_group_gather_wrench(self.g, wrench.ctypes.data, status.ctypes.data), "hmpc_group_gather_wrench")
         return wrench, status
@@ -325,7 +340,7 @@ class DeviceGroup:
 
     def download(self):
         b = self.batch
-        forces = np.zeros((b, 12 * self.horizon), dtype=np.float32)
+        forces = np.zeros((b, self.wrench_width * self.horizon), dtype=np.float32)
         status = np.zeros(b, dtype=np.uint32)
         self._check(self.L.hmpc_group_download(self.g, forces.ctypes.data, status.ctypes.data), "hmpc_group_download")
         return forces, status

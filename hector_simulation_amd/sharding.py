@@ -15,6 +15,21 @@ def shard_bounds(global_batch: int, world: int, rank: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _host_staged(dist, group, tensor) -> bool:
+    """gloo moves host memory: a device tensor is staged through the host (the CPU tests hand in host tensors; bench.py's
+    ``--backend gloo`` test transport hands in device tensors, possibly of ranks that share one GPU)."""
+    return tensor.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_gather_into(dist, out, loc, group, async_op: bool = False):
+    if _host_staged(dist, group, loc):
+        host_out = out.new_empty(out.shape, device="cpu")
+        dist.all_gather_into_tensor(host_out, loc.cpu(), group=group)  # .cpu() waits for the producer stream
+        out.copy_(host_out)
+        return None
+    return dist.all_gather_into_tensor(out, loc, group=group, async_op=async_op)
+
+
 def gather_forces(local, global_batch: int, group=None):
     """all_gather of the per-rank force blocks [shard, 12h] into [global_batch, 12h] in instance order, on every rank."""
     import torch
@@ -27,14 +42,16 @@ def gather_forces(local, global_batch: int, group=None):
     sizes = [shard_bounds(global_batch, world, r)[1] - shard_bounds(global_batch, world, r)[0] for r in range(world)]
     if len(set(sizes)) == 1:
         out = torch.empty((global_batch, width), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        _all_gather_into(dist, out, local.contiguous(), group)
         return out
     mx = max(sizes)  # ragged: pad every block to the largest shard, gather, cut the padding out
     pad = torch.zeros((mx, width), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
-    buf = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(buf, pad, group=group)
-    return torch.cat([b[:s] for b, s in zip(buf, sizes)], dim=0)
+    staged = _host_staged(dist, group, pad)
+    src = pad.cpu() if staged else pad
+    buf = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(buf, src, group=group)
+    return torch.cat([b[:s] for b, s in zip(buf, sizes)], dim=0).to(local.device)
 
 
 class WrenchExchange:
@@ -73,7 +90,7 @@ class WrenchExchange:
         if self.world == 1 and not self.always_collective:
             self.out[slot].copy_(loc)
             return
-        self.work[slot] = self.dist.all_gather_into_tensor(self.out[slot], loc, group=self.group, async_op=True)
+        self.work[slot] = _all_gather_into(self.dist, self.out[slot], loc, self.group, async_op=True)
 
     def wait(self, slot: int):
         w = self.work[slot]

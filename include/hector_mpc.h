@@ -33,7 +33,7 @@ extern "C" {
 #define HMPC_MAX_HORIZON 20    /* device scratch is sized for this (reference: 10 hard-coded, cap 19) */
 #define HMPC_MAX_VARS 120      /* reduced QP variables (6 per stance leg-step) the fast on-chip variants hold (two contacts; 180 with three) */
 #define HMPC_MAX_VARS_WIDE 240 /* ... the wide variant (double support over h = 11 .. 20): picked when the batch needs it -- from the gait
-                                  tables of host-uploaded records, or hmpc_set_max_reduced_vars for device-resident ones */
+                                  tables of host-uploaded records, hmpc_set_max_reduced_vars, or per instance on the device */
 
 /* ---- reference PODs (convexMPC_interface.h:11-37), same field order and types ---- */
 struct problem_setup {
@@ -97,8 +97,8 @@ enum hmpc_status_code {
   HMPC_S_OK = 0,
   HMPC_S_MAXITER = 1,     /* iteration cap hit (reference analogue: nWSR = 500 exhausted) */
   HMPC_S_INFEASIBLE = 2,  /* constraints inconsistent */
-  HMPC_S_TOO_LARGE = 3,   /* more reduced variables than the variant the batch was launched with holds (device-resident records of
-                             double support over h > 10 without hmpc_set_max_reduced_vars(h, > 120)) */
+  HMPC_S_TOO_LARGE = 3,   /* more reduced variables than the variant the batch was launched with holds (only when
+                             hmpc_set_max_reduced_vars named a smaller size than the batch really contains) */
   HMPC_S_KKT = 4,         /* final KKT check outside tolerance */
   HMPC_S_WORKSET = 5,     /* more simultaneously active constraints than the fast variant's on-chip working set holds (64 rows; 96 with three contacts, 152 in the wide variant; the safe pass holds as many as there are variables -- except for the wide variant, which LDS leaves no room to grow) */
   HMPC_S_OK_RELAXED = 6   /* solved, but only after every bound was moved outward by <= 2e-6 (relative for the Fz cap):
@@ -140,8 +140,12 @@ int hmpc_set_device_outputs(hmpc_handle *h, float *device_forces, uint32_t *devi
 int hmpc_solve(hmpc_handle *h, void *stream);
 /* waits for `stream` work, copies forces [batch][12h] float and status [batch] to host (either may be NULL) */
 int hmpc_download(hmpc_handle *h, float *forces, uint32_t *status);
-/* hint for device-resident records: the widest reduced QP (6 x stance leg-steps) in the batch, or -1 = unknown;
- * picks the kernel variant (LDS footprint).  hmpc_upload_records derives it from the gait tables itself. */
+/* hint for device-resident records: the widest reduced QP (6 x stance leg-steps) in the batch: one launch of the variant
+ * that holds it.  -1 = unknown (the state after hmpc_set_device_records / hmpc_build_records_device): two-contact handles
+ * then route every instance on the device -- its stance leg-steps are counted there (by the record builder, or from the
+ * records' gait bytes at the head of the solve) and each variant of the family (60 / 120 / at h > 10 also 240 variables)
+ * is launched over the whole batch, a workgroup leaving at once when its instance belongs to another variant.
+ * hmpc_upload_records derives the hint from the gait tables itself. */
 int hmpc_set_max_reduced_vars(hmpc_handle *h, int n_reduced);
 /* Working-set start of the active-set solver.  on = 1 (default): every moment / line-contact row violated at the
  * unconstrained minimiser enters at once (block warm start); on = 0: cold start from the empty set, one row per
@@ -162,6 +166,12 @@ int hmpc_reset_tick_warm_start(hmpc_handle *h);
  * start) and overwrites its forces and status in place.  *n_resolved (may be NULL) = how many were re-solved.
  * hmpc_download does this automatically unless hmpc_set_auto_resolve(h, 0). */
 int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved);
+/* Cap on the active-set iterations of every later solve of the handle -- the analogue of the reference's nWSR = 500
+ * (SolverMPC.cpp:706).  0 (default) = the kernel variant's own bound.  Block rounds and switch passes of the block start
+ * count as one iteration each and always complete; the cap is tested before every single-row iteration after them.  An
+ * instance that would need more ends as HMPC_S_MAXITER with its last iterate in the force buffer and is NOT re-solved by
+ * the safe pass.  The legacy update_solver_settings(max_iter, ...) sets the same cap for the process-global solver. */
+int hmpc_set_max_iterations(hmpc_handle *h, int max_iter);
 int hmpc_set_auto_resolve(hmpc_handle *h, int on);
 /* Device-side safe pass (default off for a plain handle): when on, hmpc_solve enqueues, behind the fast launch and on the
  * same stream, the safe variant over the list of instances the fast launch flagged (the list and its length stay on the
@@ -170,6 +180,8 @@ int hmpc_set_auto_resolve(hmpc_handle *h, int on);
  * empty) extra launch per solve; repairs at most min(batch, 2048) instances per solve, the rest stay flagged for
  * hmpc_resolve_failed / hmpc_download. */
 int hmpc_set_device_repair(hmpc_handle *h, int on);
+/* NOTE (device repair): the list of flagged instances and its counter belong to the handle -- keep the solves of ONE handle
+ * on one stream at a time (use one handle per stream to overlap launches, as bench.py does). */
 /* Stream-ordered variants for pipelining host batches (two handles on two streams: the copies of one overlap the solve
  * of the other).  The host buffers should be pinned (hipHostMalloc / hipHostRegister) for the copies to be asynchronous
  * and must stay valid until the stream reaches them.  hmpc_download_async does not run the safe pass: check the status
@@ -226,6 +238,16 @@ int hmpc_body_wrench_device(hmpc_handle *h, const double *device_rBody, double *
 int hmpc_leg_torques(hmpc_handle *h, const double *host_rBody, const double *host_leg_q, double *host_f_ff, double *host_tau);
 int hmpc_leg_torques_device(hmpc_handle *h, const double *device_rBody, const double *device_leg_q, double *device_f_ff,
                             double *device_tau, void *stream);
+/* f1+f2 -> solve -> f3 in one call, device-resident end to end: builds the records of `batch` ticks (device_ticks:
+ * hmpc_tick_inputs[batch] in HBM) into the handle, solves them -- every instance on the smallest kernel variant that holds
+ * its reduced QP, decided on the device from the gait table the builder has just generated: a walking sweep runs on the
+ * 60-variable variant with no host hint -- and writes f_ff[batch][2][6] (may be NULL) and the stance feed-forward torques
+ * tau[batch][2][5] (rBody and the joint angles are read from the tick structs; leg_q per the tick's HMPC_TICK_LEG_Q_MOTOR
+ * flag).  device_wpd_out (may be NULL) receives the clamped world_position_desired.  Three or four launches on `stream`, no
+ * host synchronisation: forces, status, f_ff and tau are valid once the stream reaches them.  With hmpc_set_device_repair
+ * the torques are computed from repaired forces.  Two-contact handles only. */
+int hmpc_tick_solve_device(hmpc_handle *h, const void *device_ticks, int batch, double dtMPC, double *device_wpd_out,
+                           double *device_f_ff, double *device_tau, void *stream);
 /* copies the current batch's packed records device -> host (parity hook for f1/f2) */
 int hmpc_download_records(hmpc_handle *h, void *host_records);
 
@@ -271,6 +293,12 @@ int hmpc_shard_bounds(int global_batch, int n_shards, int index, int *lo, int *h
 /* devices == NULL: devices 0 .. n_devices-1.  max_batch is the GLOBAL batch the group can hold. */
 int hmpc_group_create(hmpc_group **out, const struct problem_setup *setup, const int *devices, int n_devices,
                       int max_batch, int transport);
+/* the same for handles of n_contacts = 2 or 3 (BASELINE config 5 runs the three-contact extension on 4 GPUs): records of
+ * hmpc_record_stride_ex(h, n_contacts) bytes, forces [batch][6 n_contacts h], and the exchange carries the step-0 wrench of
+ * every contact -- 6 n_contacts values [F_0 .. F_{nc-1}, M_0 .. M_{nc-1}] + the status word per instance. */
+int hmpc_group_create_ex(hmpc_group **out, const struct problem_setup *setup, const int *devices, int n_devices,
+                         int max_batch, int transport, int n_contacts);
+int hmpc_group_contacts(const hmpc_group *g);
 int hmpc_group_destroy(hmpc_group *g);
 int hmpc_group_size(const hmpc_group *g);
 int hmpc_group_transport(const hmpc_group *g);
@@ -283,14 +311,14 @@ int hmpc_group_set_device_records(hmpc_group *g, const void *const *device_recor
 int hmpc_group_solve(hmpc_group *g);       /* asynchronous on every member */
 int hmpc_group_post_gather(hmpc_group *g); /* asynchronous: the exchange step for the solves enqueued so far */
 int hmpc_group_wait_gather(hmpc_group *g);
-/* member's gathered copy in HBM: [group size][slot_rows][13] 32-bit words, slot s = member s's slice, row = 12 floats of
- * the step-0 wrench + the status word.  Valid from hmpc_group_wait_gather until the next hmpc_group_post_gather. */
+/* member's gathered copy in HBM: [group size][slot_rows][6 nc + 1] 32-bit words (13 for two contacts), slot s = member s's
+ * slice, row = the 6 nc floats of the step-0 wrench + the status word.  Valid from hmpc_group_wait_gather until the next hmpc_group_post_gather. */
 int hmpc_group_device_gathered(hmpc_group *g, int member, const uint32_t **gathered, int *slot_rows);
 /* blocking form of the exchange step: collects the exchange hmpc_group_post_gather posted if it has not been collected
  * yet (by hmpc_group_wait_gather or an earlier hmpc_group_gather_wrench) -- the pipelined pattern post(k), solve(k+1),
  * gather_wrench() returns solve k's results -- and otherwise posts one now for the solves enqueued so far; waits, and
  * returns host copies in instance order of the batch the exchange was posted for (its slices are remembered at post
- * time): wrench [batch][12], status [batch] (either may be NULL).
+ * time): wrench [batch][6 nc] (12 for two contacts), status [batch] (either may be NULL).
  * The exchange carries REPAIRED rows: every member's solve is followed on its stream, without a host round trip, by the
  * safe variant over the instances the fast variant flagged (hmpc_set_device_repair, on by default for group members; up to
  * 2048 per member per solve).  hmpc_group_set_exchange_repair(g, 0) turns that off: the exchange then carries the fast

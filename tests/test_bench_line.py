@@ -48,6 +48,10 @@ def test_bench_line_contract():
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0
     assert abs(d["value"] - 2048 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6  # value = units / timed seconds
     assert d["parity"]["max_rel_force_err_vs_qpoases"] < 1e-4 and d["solver"]["failed"] == 0
+    e2e = d["parity"]["vs_reference_source_end_to_end"]  # measured in this run, not a prose string
+    assert e2e["checked"] == 16 and 0 < e2e["max_rel_force_err"] < 1.1e-3 and 0 <= e2e["fraction_above_1e-4"] <= 1
+    assert len(cb["process_sweep"]) >= 2 and cb["process_sweep"][0]["processes"] == 1 and cb["host"]["nproc_affinity"] >= 1
+    assert cb["saturation_processes"] >= 1 and "scaling_note" in cb
     assert d["parity"]["max_rel_objective_gap"] < 1e-4 and d["parity"]["kkt"]["max_rel_row_violation"] < 1e-6
     assert abs(d["parity"]["kkt"]["max_rel_suboptimality"]) < 1e-6 and d["parity"]["kkt"]["max_rel_stationarity_residual"] < 1e-6
     for k in ("fp64_valu_frac", "iterations_per_solve", "single_stream"):
@@ -73,3 +77,48 @@ def test_bench_torchrun_code_path_on_one_gpu():
     assert "exchange code path forced on" in d["config"]["parallelism"]
     assert d["solver"]["failed"] == 0 and d["parity"]["max_rel_force_err_vs_qpoases"] < 1e-4
     assert d["parity"]["max_rel_objective_gap"] < 1e-4
+
+
+def _torchrun(nproc, port, *bench_args, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", str(nproc), *bench_args], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 alone prints
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,extra,batch", [
+    ("headline_2contact", [], 1024),
+    ("cfg3_walking_sweep", ["--gait", "walking"], 2048),
+    ("cfg5_three_contact", ["--contacts", "3"], 256),
+])
+def test_bench_two_ranks_on_one_gpu(name, extra, batch):
+    """Rank > 0 code on hardware: bench.py launched exactly as the driver launches N = 2 (torch.distributed.run, one
+    process per rank), both ranks on the one GPU of the test box, the exchange over the gloo TEST transport (RCCL refuses
+    two ranks on one device).  Everything but the collective's transport is the N > 1 path of the driver's scaling run:
+    per-rank seed / shard, two HIP runtimes per process x 2, the lock-protected library load, the posted exchange per solve
+    with its double buffering, barriers, all_reduce(MAX) of the elapsed time -- for the headline config, BASELINE config 3
+    (walking sweep) and config 5 (three contacts) -- and EVERY rank checks its own shard against the oracle."""
+    d = _torchrun(2, 29531, "--steps", "4", "--warmup", "1", "--batch", str(batch), "--check", "24", "--backend", "gloo",
+                  *extra)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 2 * batch and d["config"]["batch_per_gpu"] == batch
+    assert d["config"]["exchange_selfcheck_ok"] is True
+    assert "gloo" in d["config"]["exchange_backend"]
+    assert d["config"]["contacts"] == (3 if "--contacts" in extra else 2)
+    assert abs(d["value"] - 2 * batch * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6  # whole-job units / max-over-ranks time
+    p = d["parity"]
+    assert p["ranks_checked"] == 2 and p["checked"] == 48 and len(p["per_rank_max_rel_force_err"]) == 2
+    assert p["max_rel_force_err_vs_qpoases"] < 1e-4 and p["max_rel_objective_gap"] < 1e-4
+    assert p["not_ok_over_all_shards"] == 0 and p["qpoases_failed"] == 0
+    assert d["solver"]["failed_over_all_ranks"] == 0 and len(d["solver"]["kernel_ms_per_rank"]) == 2
+    if name == "headline_2contact":
+        e2e = p["vs_reference_source_end_to_end"]
+        assert e2e["checked"] == 48 and e2e["max_rel_force_err"] < 1.1e-3  # cond(H) x binary32 round-off (test_reference_source.py)
+    if name == "cfg5_three_contact":
+        assert p["vs_reference_source_end_to_end"] is None  # the reference has no code for this shape
+        assert "180x240" in d["config"]["workload"]

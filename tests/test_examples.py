@@ -50,14 +50,16 @@ def test_examples_run_on_gpu(tmp_path, src, cc, std):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("args", [["1"], ["3", "p2p"]])
+@pytest.mark.parametrize("args", [["1"], ["3", "p2p"], ["4", "p2p", "3"], ["1", "auto", "3"]])
 def test_multi_device_example_runs_on_gpu(tmp_path, args):
     """examples/batched_multi.c: a group of one over RCCL (what a one-GPU box can run of the real transport) and a group of
-    three members on device 0 over the P2P transport (ragged 334/333/333 slices)."""
+    three members on device 0 over the P2P transport (ragged 334/333/333 slices); with "3": groups of three-contact handles
+    (BASELINE config 5's split: four members over P2P, one over RCCL)."""
     exe = _compile(tmp_path, "batched_multi.c", "gcc", "-std=c11")
     r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 of 1000 not ok, 0 gathered rows differ" in r.stdout
+    assert f"{args[2] if len(args) > 2 else 2} contacts" in r.stdout
 
 
 def test_host_api_sweep_compiles_and_fails_loudly_without_gpu(tmp_path):

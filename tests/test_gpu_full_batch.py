@@ -1,5 +1,6 @@
-"""Full-batch oracle parity at BASELINE.json's sizes: EVERY instance of configs 2 and 4 and of the metric's b1024
-2-contact case, and one GPU's shard of configs 3 / 5 (8 192 / 2 048), against the reference's own qpOASES on the oracle's (bit-identical)
+"""Full-batch oracle parity at BASELINE.json's sizes: EVERY instance of configs 2 and 4, of the metric's b1024 2-contact
+case, and -- with the seeds bench.py gives its ranks (seed 6 + 1000 rank) -- of ALL 8 shards of config 3 (65 536 walking
+instances) and ALL 4 shards of config 5 (8 192 three-contact instances), against the reference's own qpOASES on the oracle's (bit-identical)
 QP data.  The oracle runs as a pool of processes over the host cores (oracle/pool.py) where one core would take more
 than a few seconds.  Bar: forces within north_star's 1e-4 relative of qpOASES, every instance reported ok."""
 import numpy as np
@@ -77,3 +78,36 @@ def test_cfg5_one_gpu_shard_2048_three_contact_extension(oracle):
     forces, status = _gpu(rec, 10, contacts=3)
     _compare("cfg5[:2048] (oracle extension)", forces, status,
              pool.solve_records_parallel(rec, 10, synthetic.DT_MPC, synthetic.F_MAX, nc=3))
+
+
+def _bench_shards(n_ranks, per_rank, gait, contacts):
+    """every rank's shard of a `bench.py --gpus n_ranks --batch per_rank` run, solved one after the other on this GPU"""
+    import bench
+    from oracle import pool
+
+    worst, not_ok, total = 0.0, 0, 0
+    for rank in range(n_ranks):
+        _, rec = bench.bench_shard(rank, per_rank, 10, gait, contacts)
+        forces, status = _gpu(rec, 10, contacts=contacts)
+        ref = pool.solve_records_parallel(rec, 10, synthetic.DT_MPC, synthetic.F_MAX, nc=contacts)
+        assert ref["n_bad"] == 0, (rank, ref["n_bad"])
+        q = ref["q_soln"]
+        err = np.abs(forces.astype(np.float64) - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+        worst = max(worst, float(err.max()))
+        not_ok += int((interface.status_code(status) != 0).sum())
+        total += len(err)
+    return worst, not_ok, total
+
+
+def test_cfg3_all_eight_shards_65536_with_the_bench_seeds(oracle):
+    """BASELINE config 3 as `bench.py --gpus 8 --gait walking` shards it: 8 x 8 192 instances, every one against qpOASES."""
+    worst, not_ok, total = _bench_shards(8, 8192, "walking", 2)
+    print(f"cfg3, all 8 bench shards: {total} instances, {not_ok} not ok, max rel force err vs qpOASES {worst:.2e}")
+    assert total == 65536 and not_ok == 0 and worst < TOL
+
+
+def test_cfg5_all_four_shards_8192_three_contact_with_the_bench_seeds(oracle):
+    """BASELINE config 5 as `bench.py --gpus 4 --batch 2048 --contacts 3` shards it: 4 x 2 048 instances, every one."""
+    worst, not_ok, total = _bench_shards(4, 2048, "standing", 3)
+    print(f"cfg5, all 4 bench shards (oracle extension): {total} instances, {not_ok} not ok, max rel force err vs qpOASES {worst:.2e}")
+    assert total == 8192 and not_ok == 0 and worst < TOL

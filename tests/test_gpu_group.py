@@ -185,3 +185,38 @@ def test_exchange_carries_repaired_rows():
     _, status_raw = grp.gather_wrench()
     np.testing.assert_array_equal(status_raw, st_fast)
     grp.close()
+
+
+@pytest.mark.parametrize("devices,transport,nb", [([0], "rccl", 40), ([0, 0, 0, 0], "p2p", 50)])
+def test_group_of_three_contact_handles_cfg5_split(devices, transport, nb):
+    """BASELINE config 5 is the three-contact extension split over 4 GPUs: ``hmpc_group_create_ex(..., n_contacts = 3)``
+    -- member handles of the extension, records of its stride, and an exchange that carries the 18 step-0 values
+    [F_L F_R F_H M_L M_R M_H] (ConvexMPCLocomotion.cpp:419-440 with one more contact) + status per instance."""
+    f = synthetic.make_batch3(nb, H, "standing", seed=33, phase="random", hand="window")
+    rec = records.pack_records(f, H, 3)
+    one = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb, contacts=3)
+    one.upload(rec)
+    one.solve()
+    ref_f, ref_s = one.download()
+    one.close()
+    grp = interface.DeviceGroup(synthetic.DT_MPC, H, synthetic.F_MAX, nb, devices, transport, contacts=3)
+    assert grp.wrench_width == 18 and grp.stride == records.record_stride(H, 3)
+    assert int(grp.L.hmpc_group_contacts(grp.g)) == 3
+    grp.upload(rec)
+    grp.solve()
+    wrench, status = grp.gather_wrench()
+    assert wrench.shape == (nb, 18)
+    np.testing.assert_array_equal(status, ref_s)
+    np.testing.assert_array_equal(wrench.view(np.uint32), ref_f[:, :18].view(np.uint32))
+    for i in range(grp.size):
+        ptr, rows = grp.device_gathered(i)
+        blk = _device_words(ptr, grp.size * rows * 19).reshape(grp.size, rows, 19)
+        for s in range(grp.size):
+            _, _, lo, n, _ = grp.member(s)
+            np.testing.assert_array_equal(blk[s, :n, :18], ref_f[lo:lo + n, :18].view(np.uint32))
+            np.testing.assert_array_equal(blk[s, :n, 18], ref_s[lo:lo + n])
+    full_f, full_s = grp.download()
+    assert full_f.shape == (nb, 18 * H)
+    np.testing.assert_array_equal(full_f.view(np.uint32), ref_f.view(np.uint32))
+    np.testing.assert_array_equal(full_s, ref_s)
+    grp.close()

@@ -1,6 +1,7 @@
-"""GPU tests at BASELINE.json's full sizes through size-independent properties (the oracle cannot solve 65 536
-instances in seconds): determinism, batch-order invariance, exact zeros on swing legs, warm-vs-cold start agreement,
-primal feasibility against the oracle's constraint data on a sample, oracle parity on a sample."""
+"""GPU tests at BASELINE.json's full sizes through size-independent properties: determinism, batch-order invariance, exact
+zeros on swing legs, warm-vs-cold start agreement, primal feasibility against the oracle's constraint data on a sample,
+oracle parity on a sample.  (Every-instance oracle parity at the same sizes -- all 65 536 walking instances of config 3 and
+all 8 192 three-contact instances of config 5, as a pool of oracle processes -- lives in tests/test_gpu_full_batch.py.)"""
 import numpy as np
 import pytest
 

@@ -121,3 +121,47 @@ def test_double_support_beyond_ten_steps(oracle, gait, h, nb, seed):
     assert np.all(forces[q == 0.0] == 0.0)
     og = np.abs(obj64 - ref["obj"]) / np.maximum(1.0, np.abs(ref["obj"]))
     assert og.max() < TOL, og.max()
+
+
+def test_iteration_cap_is_honoured_batched_and_legacy(oracle):
+    """The one reference-declared knob with a meaning for an active-set solver: update_solver_settings(max_iter, ...)
+    (convexMPC_interface.h:41) / hmpc_set_max_iterations cap the active-set iterations -- the analogue of the reference's
+    nWSR = 500 (SolverMPC.cpp:706).  A cap of 1 ends every instance that needs more as HMPC_S_MAXITER (and the safe pass
+    leaves the caller's cap alone); cap 0 restores the optimum."""
+    nb = 256
+    f = synthetic.make_batch(nb, 10, "standing", seed=77, phase="random")
+    rec = records.pack_records(f, 10)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, 10, synthetic.F_MAX, nb)
+    mpc.upload(rec)
+    mpc.solve()
+    _, st_free = mpc.download()
+    assert (interface.status_code(st_free) == 0).all()
+    need = interface.status_iters(st_free)
+    assert (need >= 3).sum() > nb // 8  # the set does need iterations
+    mpc.set_max_iterations(1)
+    mpc.solve()
+    _, st_cap = mpc.download()  # auto-resolve on: instances that ran into the CALLER'S cap are not "repaired"
+    code = interface.status_code(st_cap)
+    assert set(np.unique(code)) <= {0, 1}
+    assert (code[need == 0] == 0).all() and (code == 1).sum() > nb // 8
+    # (the block start always completes; what the cap cuts off is the single-row iteration after it)
+    assert (interface.status_iters(st_cap)[code == 1] >= 1).all() and (interface.status_iters(st_cap) <= need).all()
+    mpc.set_max_iterations(0)
+    mpc.solve()
+    forces, st_again = mpc.download()
+    np.testing.assert_array_equal(st_again, st_free)
+    mpc.close()
+    # the reference's own entry point
+    k = int(np.argmax(need))
+    row = {key: np.asarray(v)[k] for key, v in f.items()}
+    args = (row["p"], row["v"], row["q"], row["w"], row["r"], row["joint_angles"], float(row["yaw"]), row["weights"],
+            row["traj"], row["Alpha_K"], row["gait"])
+    interface.setup_problem(synthetic.DT_MPC, 10, 0.25, synthetic.F_MAX)
+    interface.update_solver_settings(1, 0.0, 0.0, 0.0, 0.0, 0.0)
+    interface.update_problem_data(*args)
+    assert interface.last_status() & 0xFF == 1  # HMPC_S_MAXITER
+    interface.update_solver_settings(0, 0.0, 0.0, 0.0, 0.0, 0.0)
+    interface.update_problem_data(*args)
+    assert interface.last_status() & 0xFF == 0
+    got = np.array([interface.get_solution(i) for i in range(120)])
+    np.testing.assert_array_equal(got.astype(np.float32), forces[k])

@@ -61,11 +61,11 @@ def test_two_rank_gather_matches_single_process(oracle, tmp_path, gb):
     np.testing.assert_array_equal(got, want)
 
 
-def _xch_worker(rank, world, port, shard, path):
+def _xch_worker(rank, world, port, shard, path, width=12):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    allf = torch.from_numpy(np.load(path))            # [steps, world*shard, 120]
-    xch = sharding.WrenchExchange(shard, 12, "cpu")
+    allf = torch.from_numpy(np.load(path))            # [steps, world*shard, width * h]
+    xch = sharding.WrenchExchange(shard, width, "cpu")
     got = []
     for k in range(allf.shape[0]):                    # pipelined exactly as bench.py posts it
         mine = allf[k, rank * shard:(rank + 1) * shard]
@@ -83,18 +83,19 @@ def _xch_worker(rank, world, port, shard, path):
     dist.destroy_process_group()
 
 
-def test_wrench_exchange_pipelined_two_ranks(tmp_path):
+@pytest.mark.parametrize("width", [12, 18])
+def test_wrench_exchange_pipelined_two_ranks(tmp_path, width):
     """The exchange bench.py runs for N > 1: step-0 wrench + status word of every instance on every rank, double
-    buffered (post k+1 while k is in flight)."""
+    buffered (post k+1 while k is in flight).  width 12 = two feet; 18 = BASELINE config 5's three contacts."""
     steps, world, shard = 4, 2, 5
     rng = np.random.default_rng(3)
-    allf = rng.standard_normal((steps, world * shard, 120)).astype(np.float32)
+    allf = rng.standard_normal((steps, world * shard, 10 * width)).astype(np.float32)
     path = str(tmp_path / "f.npy")
     np.save(path, allf)
-    mp.spawn(_xch_worker, args=(world, _free_port(), shard, path), nprocs=world, join=True)
+    mp.spawn(_xch_worker, args=(world, _free_port(), shard, path, width), nprocs=world, join=True)
     got = torch.load(path + ".xch.pt")
     assert len(got) == steps
     for k, (w, s) in enumerate(got):
-        np.testing.assert_array_equal(w.numpy(), allf[k, :, :12])
+        np.testing.assert_array_equal(w.numpy(), allf[k, :, :width])
         want = np.concatenate([(np.arange(shard) + 1000 * r + 100000 * k) | (1 << 30) for r in range(world)])
         np.testing.assert_array_equal(s.numpy(), want.astype(np.int32))
