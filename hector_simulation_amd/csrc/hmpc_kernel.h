@@ -321,6 +321,28 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #endif
 namespace hmpc {
 
+// A per-thread constant derived from threadIdx.x.  LAZY = false: an ordinary register.  LAZY = true (the two-blocks-per-thread
+// variants, whose 144 registers of matrix leave no room for long-lived scalars): recomputed at every use from an opaque
+// copy of the thread index -- one or two integer instructions instead of a register that lives, and spills, for the whole solve.
+template <bool LAZY, class F>
+struct LazyInt {
+  int v;
+  F f;
+  __device__ __forceinline__ operator int() const {
+    if constexpr (LAZY) {
+      int t = (int)threadIdx.x;
+      asm volatile("" : "+v"(t));
+      return f(t);
+    } else {
+      return v;
+    }
+  }
+};
+template <bool LAZY, class F>
+__device__ __forceinline__ LazyInt<LAZY, F> lazy_int(F f) {
+  return LazyInt<LAZY, F>{LAZY ? 0 : f((int)threadIdx.x), f};
+}
+
 // three waves per SIMD = 3 (256 threads) or 6 (128 threads) workgroups per CU: their LDS must fit the CU's 160 KB
 template <int NMAX, int HMAX, int NT, int QCAP, int NC, int BPT>
 constexpr bool fits_three_waves() {
@@ -342,7 +364,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
 
   const int tid = threadIdx.x, wv = uni(tid >> 6), ln = tid & 63;
   if (!ASM_ONLY && args.list_count && blockIdx.x >= *args.list_count) return;  // device-side safe pass: nothing (more) flagged
-  const int inst = ASM_ONLY ? args.dbg_index : (args.index_list ? args.index_list[blockIdx.x] : (int)blockIdx.x);
+  // (uniform by construction -- but when it comes from the index list it arrives through a vector load: told to the compiler, so
+  //  that the instance's base addresses are scalar arithmetic instead of register pairs that live for the whole kernel)
+  const int inst = uni(ASM_ONLY ? args.dbg_index : (args.index_list ? args.index_list[blockIdx.x] : (int)blockIdx.x));
   const int h = args.horizon;
   if (inst >= args.batch) return;
   if (!ASM_ONLY && args.cls) {  // uniform: this instance belongs to another variant's launch
@@ -716,19 +740,46 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // straight from the staging area of H, pass by pass where that area holds only part of the block-diagonals at a time.
   constexpr int NTILE = NG * (NG + 1) / 2;
   static_assert(NTILE <= BPT * NT && SM::MMAX <= NT && NMAX <= NT, "threads per block / constraint row / variable");
-  int e0[BPT], e1[BPT], i0[BPT], j0[BPT];
-  bool owner[BPT], diag[BPT];
+  // BPT == 1: plain registers.  BPT == 2 (256 VGPRs, 144 of them the two blocks): the coordinates of a slot travel PACKED in
+  // one register (bits 0-5 e0, 6-11 e1, 12 owner) and are unpacked where they are used, behind an opaque copy so that the
+  // compiler cannot hoist the unpacked values back into registers that live -- and spill -- for the rest of the kernel.
+  int e0_r[BPT], e1_r[BPT], i0_r[BPT], j0_r[BPT];
+  bool owner_r[BPT], diag_r[BPT];
+  unsigned pk[BPT];
+  auto PK = [&](const int s) __attribute__((always_inline)) -> unsigned { return pk[s]; };
+  // ... "behind an opaque copy": pk_fence() makes the packed words opaque at the head of a phase, so that what a phase unpacks
+  // lives in registers for that phase only (inside the sweeps that is what one wants; across the whole solve it is not)
+  auto pk_fence = [&]() __attribute__((always_inline)) {
+    if constexpr (BPT == 2) {
+#pragma unroll
+      for (int s = 0; s < BPT; ++s) asm volatile("" : "+v"(pk[s]));
+    }
+  };
+  auto E0 = [&](const int s) __attribute__((always_inline)) -> int { if constexpr (BPT == 1) return e0_r[s]; else return (int)(PK(s) & 63u); };
+  auto E1 = [&](const int s) __attribute__((always_inline)) -> int { if constexpr (BPT == 1) return e1_r[s]; else return (int)((PK(s) >> 6) & 63u); };
+  auto I0 = [&](const int s) __attribute__((always_inline)) -> int { if constexpr (BPT == 1) return i0_r[s]; else return GS * (int)(PK(s) & 63u); };
+  auto J0 = [&](const int s) __attribute__((always_inline)) -> int { if constexpr (BPT == 1) return j0_r[s]; else return GS * (int)((PK(s) >> 6) & 63u); };
+  auto OWN = [&](const int s) __attribute__((always_inline)) -> bool { if constexpr (BPT == 1) return owner_r[s]; else return ((PK(s) >> 12) & 1u) != 0; };
+  auto DIAG = [&](const int s) __attribute__((always_inline)) -> bool {
+    if constexpr (BPT == 1) return diag_r[s];
+    else { const unsigned v = PK(s); return (v & 63u) == ((v >> 6) & 63u); }
+  };
   auto own_blocks = [&]() __attribute__((always_inline)) {  // (called right before the first load: nothing of it is live during the chains)
 #pragma unroll
     for (int s = 0; s < BPT; ++s) {
       const int t = tid + s * NT;
       int ea = 0;
       while (ea < NG - 1 && (ea + 1) * NG - (ea + 1) * ea / 2 <= t) ++ea;
-      owner[s] = t < NTILE;
-      e1[s] = owner[s] ? ea + (t - (ea * NG - ea * (ea - 1) / 2)) : 0;
-      e0[s] = owner[s] ? ea : 0;
-      diag[s] = (e0[s] == e1[s]);
-      i0[s] = GS * e0[s], j0[s] = GS * e1[s];
+      const bool ow = t < NTILE;
+      const int eb = ow ? ea + (t - (ea * NG - ea * (ea - 1) / 2)) : 0;
+      ea = ow ? ea : 0;
+      if constexpr (BPT == 1) {
+        owner_r[s] = ow, e1_r[s] = eb, e0_r[s] = ea;
+        diag_r[s] = (ea == eb);
+        i0_r[s] = GS * ea, j0_r[s] = GS * eb;
+      } else {
+        pk[s] = (unsigned)ea | ((unsigned)eb << 6) | (ow ? 4096u : 0u);
+      }
     }
   };
   double a[BPT][GS][GS];
@@ -843,9 +894,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     auto load_blocks = [&](const int dlo, const int dhi) __attribute__((always_inline)) {  // blocks whose block-diagonal d = sb - sa lies in [dlo, dhi)
 #pragma unroll
       for (int s = 0; s < BPT; ++s) {
-        const bool have = owner[s] && e1[s] < ng;
-        const int sa = have ? (int)S.ls_step[e0[s]] : 0, la = have ? (int)S.ls_leg[e0[s]] : 0;
-        const int sb = have ? (int)S.ls_step[e1[s]] : 0, lb = have ? (int)S.ls_leg[e1[s]] : 0;
+        const bool have = OWN(s) && E1(s) < ng;
+        const int sa = have ? (int)S.ls_step[E0(s)] : 0, la = have ? (int)S.ls_leg[E0(s)] : 0;
+        const int sb = have ? (int)S.ls_step[E1(s)] : 0, lb = have ? (int)S.ls_leg[E1(s)] : 0;
         const int dd = sb - sa;
         // (a thread's slots that hold no live block are zero-filled in the first pass)
         const bool in_pass = (SM::HSP == 1) ? true : (have ? (dd >= dlo && dd < dhi) : (dlo == 0));
@@ -860,7 +911,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
           for (int jj = 0; jj < GS; ++jj) {
             constexpr int F = 3 * NC - 3;  // comp(l, k) - 3 l - k for a moment component
             const int cr = (ii < 3) ? ii : F + ii, cc = (jj < 3) ? jj : F + jj;
-            const bool sw = (ii >= 3 && jj < 3) ? same : ((ii > jj) ? diag[s] : false);
+            const bool sw = (ii >= 3 && jj < 3) ? same : ((ii > jj) ? DIAG(s) : false);
             const float v = sw ? bT[cc * U + cr] : bN[cr * U + cc];
             a[s][ii][jj] = have ? (double)v : 0.0;
           }
@@ -996,7 +1047,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       for (int ii = 0; ii < GS; ++ii)
 #pragma unroll
         for (int jj = 0; jj < GS; ++jj) {
-          const int i = i0[s] + ii, j = j0[s] + jj;
+          const int i = I0(s) + ii, j = J0(s) + jj;
           double v = 0.0;
           if (i < n && j < n) {
             const int oi = S.s2o[i], oj = S.s2o[j];
@@ -1060,13 +1111,14 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < BPT; ++s)
-    if (owner[s] && e0[s] == 0) {
+    if (OWN(s) && E0(s) == 0) {
 #pragma unroll
       for (int jj = 0; jj < GS; ++jj)
-        if (j0[s] + jj < n) Q.piv[0][j0[s] + jj] = a[s][0][jj];
-      if (diag[s]) Q.piv[0][0] = a[s][0][0] - 1.0, Q.pd[0] = a[s][0][0];
+        if (J0(s) + jj < n) Q.piv[0][J0(s) + jj] = a[s][0][jj];
+      if (DIAG(s)) Q.piv[0][0] = a[s][0][0] - 1.0, Q.pd[0] = a[s][0][0];
     }
   __syncthreads();
+  pk_fence();
   // waves that hold no register block at all (the second wave of the 128-thread variants: 55 blocks) only keep the barriers
   constexpr int NW_OWN = (NTILE + 63) / 64;
   const bool wave_owns = (NW_OWN >= NW) || (wv < NW_OWN);  // scalar; compile-time true where every wave holds blocks
@@ -1074,10 +1126,10 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     bool rowb[BPT], colb[BPT], rown[BPT], coln[BPT];
 #pragma unroll
     for (int s = 0; s < BPT; ++s) {
-      rowb[s] = owner[s] && (e0[s] == kb);      // my block holds matrix rows 6kb..6kb+5
-      colb[s] = owner[s] && (e1[s] == kb);      // my block holds matrix columns 6kb..6kb+5
-      rown[s] = owner[s] && (e0[s] == kb + 1);  // next leg-step's row / column blocks (publish at the seam)
-      coln[s] = owner[s] && (e1[s] == kb + 1);
+      rowb[s] = OWN(s) && (E0(s) == kb);      // my block holds matrix rows 6kb..6kb+5
+      colb[s] = OWN(s) && (E1(s) == kb);      // my block holds matrix columns 6kb..6kb+5
+      rown[s] = OWN(s) && (E0(s) == kb + 1);  // next leg-step's row / column blocks (publish at the seam)
+      coln[s] = OWN(s) && (E1(s) == kb + 1);
     }
 #pragma unroll
     for (int kk = 0; kk < GS; ++kk) {
@@ -1097,12 +1149,12 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         double pi[GS], pj[GS];
 #pragma unroll
         for (int ii = 0; ii < GS; ii += 2) {
-          const double2 t2 = *reinterpret_cast<const double2 *>(pv + i0[s] + ii);
+          const double2 t2 = *reinterpret_cast<const double2 *>(pv + I0(s) + ii);
           pi[ii] = t2.x, pi[ii + 1] = t2.y;
         }
 #pragma unroll
         for (int jj = 0; jj < GS; jj += 2) {
-          const double2 t2 = *reinterpret_cast<const double2 *>(pv + j0[s] + jj);
+          const double2 t2 = *reinterpret_cast<const double2 *>(pv + J0(s) + jj);
           pj[jj] = t2.x, pj[jj + 1] = t2.y;
         }
         double qi[GS];
@@ -1120,23 +1172,23 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
           if (rowb[s]) {
 #pragma unroll
             for (int jj = 0; jj < GS; ++jj)
-              if (!diag[s] || jj >= kk + 1) pn[j0[s] + jj] = a[s][(kk + 1) % GS][jj];
-            if (diag[s]) pn[j0[s] + (kk + 1) % GS] = a[s][(kk + 1) % GS][(kk + 1) % GS] - 1.0, Q.pd[(k + 1) & 1] = a[s][(kk + 1) % GS][(kk + 1) % GS];
+              if (!DIAG(s) || jj >= kk + 1) pn[J0(s) + jj] = a[s][(kk + 1) % GS][jj];
+            if (DIAG(s)) pn[J0(s) + (kk + 1) % GS] = a[s][(kk + 1) % GS][(kk + 1) % GS] - 1.0, Q.pd[(k + 1) & 1] = a[s][(kk + 1) % GS][(kk + 1) % GS];
           }
           if (colb[s]) {
 #pragma unroll
             for (int ii = 0; ii < GS; ++ii)
-              if (!diag[s] || ii < kk + 1) pn[i0[s] + ii] = a[s][ii][(kk + 1) % GS];
+              if (!DIAG(s) || ii < kk + 1) pn[I0(s) + ii] = a[s][ii][(kk + 1) % GS];
           }
         } else if (kb + 1 < ng) {
           if (rown[s]) {
 #pragma unroll
-            for (int jj = 0; jj < GS; ++jj) pn[j0[s] + jj] = a[s][0][jj];
-            if (diag[s]) pn[j0[s]] = a[s][0][0] - 1.0, Q.pd[(k + 1) & 1] = a[s][0][0];
+            for (int jj = 0; jj < GS; ++jj) pn[J0(s) + jj] = a[s][0][jj];
+            if (DIAG(s)) pn[J0(s)] = a[s][0][0] - 1.0, Q.pd[(k + 1) & 1] = a[s][0][0];
           }
-          if (coln[s] && !diag[s]) {
+          if (coln[s] && !DIAG(s)) {
 #pragma unroll
-            for (int ii = 0; ii < GS; ++ii) pn[i0[s] + ii] = a[s][ii][0];
+            for (int ii = 0; ii < GS; ++ii) pn[I0(s) + ii] = a[s][ii][0];
           }
         }
       }
@@ -1155,18 +1207,20 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       __syncthreads();
     }
   }
+  pk_fence();
   // M = -a.  Diagonal blocks keep the full symmetric 6x6 (their lower triangle is overwritten with the mirror of the upper
   // one, so both halves are bit-identical); off-diagonal blocks hold M(e0,e1) and stand for M(e1,e0) transposed.
 #pragma unroll
   for (int s = 0; s < BPT; ++s) {
+    const bool own_s = OWN(s), diag_s = DIAG(s);
 #pragma unroll
     for (int ii = 0; ii < GS; ++ii)
 #pragma unroll
-      for (int jj = 0; jj < GS; ++jj) a[s][ii][jj] = owner[s] ? -a[s][ii][jj] : 0.0;
+      for (int jj = 0; jj < GS; ++jj) a[s][ii][jj] = own_s ? -a[s][ii][jj] : 0.0;
 #pragma unroll
     for (int ii = 1; ii < GS; ++ii)
 #pragma unroll
-      for (int jj = 0; jj < ii; ++jj) a[s][ii][jj] = diag[s] ? a[s][jj][ii] : a[s][ii][jj];
+      for (int jj = 0; jj < ii; ++jj) a[s][ii][jj] = diag_s ? a[s][jj][ii] : a[s][ii][jj];
   }
   PROF_MARK(P_SWEEP);
 
@@ -1198,6 +1252,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // z = M w for a dense w in LDS (entries >= n exactly 0).  Every block writes its row partial to ST[e1][vars of e0]
   // and its mirrored partial to ST[e0][vars of e1]; variable i then sums ST[0..ng-1][i] in index order (deterministic).
   auto rmatvec = [&](const double *w) __attribute__((always_inline)) {
+    pk_fence();
     // the partials are staged in STH halves of the source leg-steps (STH = 1: all at once); the running sums keep the
     // same order either way: even sources into s0, odd ones into s1, ascending.  One block at a time, each product formed
     // in the stage that stores it (row product: source e1, column product: source e0) -- nothing is held across a barrier.
@@ -1208,34 +1263,34 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       const int lo = st * SM::STR;  // sources [lo, lo + STR) in this stage
 #pragma unroll
       for (int s = 0; s < BPT; ++s)
-        if (owner[s] && e1[s] < ng) {
-          const bool w1 = (SM::STH == 1) || (e1[s] >= lo && e1[s] < lo + SM::STR);
-          const bool w0 = (SM::STH == 1) || (e0[s] >= lo && e0[s] < lo + SM::STR);
+        if (OWN(s) && E1(s) < ng) {
+          const bool w1 = (SM::STH == 1) || (E1(s) >= lo && E1(s) < lo + SM::STR);
+          const bool w0 = (SM::STH == 1) || (E0(s) >= lo && E0(s) < lo + SM::STR);
           // one code path for every block: a diagonal block is stored as the full, exactly symmetric 6x6 and has wi == wj, so
           // its two products are the same bits and its two stores hit the same words with the same values
           if (w1) {
             double wj[GS], ra[GS];
 #pragma unroll
             for (int k = 0; k < GS; k += 2) {
-              const double2 u2 = *reinterpret_cast<const double2 *>(w + j0[s] + k);
+              const double2 u2 = *reinterpret_cast<const double2 *>(w + J0(s) + k);
               wj[k] = u2.x, wj[k + 1] = u2.y;
             }
             blk_rows(s, wj, ra);
 #pragma unroll
             for (int k = 0; k < GS; k += 2)
-              *reinterpret_cast<double2 *>(&Q.ST[e1[s] - lo][i0[s] + k]) = make_double2(ra[k], ra[k + 1]);
+              *reinterpret_cast<double2 *>(&Q.ST[E1(s) - lo][I0(s) + k]) = make_double2(ra[k], ra[k + 1]);
           }
           if (w0) {
             double wi[GS], ca[GS];
 #pragma unroll
             for (int k = 0; k < GS; k += 2) {
-              const double2 t2 = *reinterpret_cast<const double2 *>(w + i0[s] + k);
+              const double2 t2 = *reinterpret_cast<const double2 *>(w + I0(s) + k);
               wi[k] = t2.x, wi[k + 1] = t2.y;
             }
             blk_cols(s, wi, ca);
 #pragma unroll
             for (int k = 0; k < GS; k += 2)
-              *reinterpret_cast<double2 *>(&Q.ST[e0[s] - lo][j0[s] + k]) = make_double2(ca[k], ca[k + 1]);
+              *reinterpret_cast<double2 *>(&Q.ST[E0(s) - lo][J0(s) + k]) = make_double2(ca[k], ca[k + 1]);
           }
         }
       __syncthreads();
@@ -1245,13 +1300,22 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
           // rows >= ng of ST are never written: they are read all the same (one base address, immediate offsets -- a
           // clamped row index costs one address register per row) and masked out by the selects below
           const int hbase = (SM::STH == 1) ? hb * HB : lo;  // first source of this group of HB rows
-          double sv[HB];
+          // (BPT == 2: the rows are read in chunks -- 30-40 registers of partials in flight at once, next to two register blocks,
+          //  is what the allocator answers with spills; same summation order either way: even sources into s0, odd into s1)
+          constexpr int CH = (BPT == 2) ? 6 : HB;
 #pragma unroll
-          for (int r = 0; r < HB; ++r) sv[r] = Q.ST[((SM::STH == 1) ? hb * HB : 0) + r][tid];
+          for (int r0 = 0; r0 < HB; r0 += CH) {
+            double sv[CH];
 #pragma unroll
-          for (int r = 0; r < HB; r += 2) {
-            s0 += (hbase + r < ng) ? sv[r] : 0.0;
-            if (r + 1 < HB) s1 += (hbase + r + 1 < ng) ? sv[r + 1] : 0.0;
+            for (int r = 0; r < CH; ++r)
+              if (r0 + r < HB) sv[r] = Q.ST[((SM::STH == 1) ? hb * HB : 0) + r0 + r][tid];
+#pragma unroll
+            for (int r = 0; r < CH; ++r)
+              if (r0 + r < HB) {
+                if (((r0 + r) & 1) == 0) s0 += (hbase + r0 + r < ng) ? sv[r] : 0.0;
+                else s1 += (hbase + r0 + r < ng) ? sv[r] : 0.0;
+              }
+            if constexpr (BPT == 2) asm volatile("" ::: "memory");  // (keeps the chunks' reads from being hoisted together again)
           }
         }
         if (st + 1 == SM::STH) Q.z[tid] = s0 + s1;
@@ -1265,8 +1329,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // registers; thread i < n = variable i (leg-step i/6, position i%6).
   const double INF = __builtin_huge_val();
   const double FEAS_TOL = 1e-9;
-  const int c_e = tid >> 3, c_rr = tid & 7;
-  double c_ub = INF;
+  constexpr bool LAZY = (BPT == 2);
+  const auto c_e = lazy_int<LAZY>([](int t) { return t >> 3; });
+  const auto c_rr = lazy_int<LAZY>([](int t) { return t & 7; });
   // the lower bound of a row is 0 -- except in the last-resort pass (args.relax != 0), where it is recomputed on use
   // rather than kept in a register pair for the whole solve
   // (read through LDS: a value the compiler cannot prove loop-invariant across the barriers, or it hoists the whole
@@ -1277,22 +1342,43 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     const double fr = 0.6180339887498949 * (double)(tid + 1);
     return -(rl * (1.0 + (fr - __builtin_floor(fr))));
   };
-  bool c_hasl = false, c_hasu = false;
-  const double *c_cn = S.Cn[0][0];  // this row's 6 coefficients (LDS; re-read where used: cheaper than 12 live VGPRs)
-  if (is_c) {
-    const int leg = S.ls_leg[c_e];
-    c_cn = S.Cn[leg][c_rr];
-    c_hasl = (c_rr <= 4) || (c_rr == 7);  // every finite lower bound is 0 (SolverMPC.cpp:466-482)
-    c_hasu = (c_rr >= 4);
-    c_ub = (c_rr == 4) ? (double)0.01f : (c_rr == 7 ? S.ub7[c_e] : 0.0);
-    if (args.relax != 0.0) {
+  // upper bound of this thread's row: 0.01 for the moment window, the Fz cap for row 7, else 0 (SolverMPC.cpp:466-482);
+  // moved outward in the last-resort pass
+  auto row_ub_calc = [&]() __attribute__((always_inline)) -> double {
+    const int rr = c_rr;
+    double u = (rr == 4) ? (double)0.01f : (rr == 7 ? S.ub7[c_e] : 0.0);
+    const double rl = LAZY ? S.relax : args.relax;
+    if (LAZY ? ub(rl != 0.0) : (rl != 0.0)) {
       const double fr = 0.6180339887498949 * (double)(tid + 1);
-      const double dl = args.relax * (1.0 + (fr - __builtin_floor(fr)));
-      c_ub += dl * ((c_rr == 7 && c_ub > 1.0) ? c_ub : 1.0);
+      const double dl = rl * (1.0 + (fr - __builtin_floor(fr)));
+      u += dl * ((rr == 7 && u > 1.0) ? u : 1.0);
+    }
+    return u;
+  };
+  double c_ub_r = INF;
+  bool c_hasl_r = false, c_hasu_r = false;
+  const double *c_cn_r = S.Cn[0][0];  // this row's 6 coefficients (LDS; re-read where used: cheaper than 12 live VGPRs)
+  if constexpr (!LAZY) {
+    if (is_c) {
+      const int leg = S.ls_leg[c_e];
+      c_cn_r = S.Cn[leg][c_rr];
+      c_hasl_r = (c_rr <= 4) || (c_rr == 7);  // every finite lower bound is 0 (SolverMPC.cpp:466-482)
+      c_hasu_r = (c_rr >= 4);
+      c_ub_r = row_ub_calc();
     }
   }
-  const int v_e = tid / GS, v_k = tid % GS;
-  const int v_leg = is_v ? S.ls_leg[v_e] : 0;
+  // (callers are rows of the QP, tid < m -- except the lane that publishes a selection record when no row is a candidate)
+  auto row_cn = [&]() __attribute__((always_inline)) -> const double * {
+    if constexpr (!LAZY) return c_cn_r;
+    else return (tid < m) ? S.Cn[S.ls_leg[c_e]][c_rr] : S.Cn[0][0];
+  };
+  auto row_ub = [&]() __attribute__((always_inline)) -> double { if constexpr (!LAZY) return c_ub_r; else return row_ub_calc(); };
+  auto row_hasl = [&]() __attribute__((always_inline)) -> bool { if constexpr (!LAZY) return c_hasl_r; else { const int rr = c_rr; return rr <= 4 || rr == 7; } };
+  auto row_hasu = [&]() __attribute__((always_inline)) -> bool { if constexpr (!LAZY) return c_hasu_r; else return c_rr >= 4; };
+  const auto v_e = lazy_int<LAZY>([](int t) { return t / GS; });
+  const auto v_k = lazy_int<LAZY>([](int t) { return t % GS; });
+  const int v_leg_r = (!LAZY && is_v) ? S.ls_leg[v_e] : 0;
+  auto var_leg = [&]() __attribute__((always_inline)) -> int { if constexpr (!LAZY) return v_leg_r; else return (tid < n) ? (int)S.ls_leg[v_e] : 0; };
   for (int t = tid; t < SM::MMAX; t += NT) {
     Q.act[t] = 0;
     Q.slot[t] = 0;
@@ -1319,13 +1405,14 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   auto my_slack = [&](const double *xv, int &side, double &raw) __attribute__((always_inline)) -> double {
     double s0 = 0.0, s1 = 0.0;
     const double *xp = xv + GS * c_e;
+    const double *c_cn = row_cn();
 #pragma unroll
     for (int k = 0; k < 3; ++k) s0 = dfma(c_cn[k], xp[k], s0);
 #pragma unroll
     for (int k = 0; k < 3; ++k) s1 = dfma(c_cn[3 + k], xp[3 + k], s1);
     const double s = s0 + s1;
-    const double sl = c_hasl ? (s - row_lo()) : INF;
-    const double su = c_hasu ? (c_ub - s) : INF;
+    const double sl = row_hasl() ? (s - row_lo()) : INF;
+    const double su = row_hasu() ? (row_ub() - s) : INF;
     const double ssu = su * ((c_rr == 7) ? S.sc7[c_e] : 1.0);  // (the Fz cap on a unit scale; table built with ub7)
     side = (sl <= ssu) ? 1 : -1;
     raw = (sl <= ssu) ? sl : su;
@@ -1337,13 +1424,14 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       const unsigned long long am = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * v_e]);
       const unsigned long long sm = *reinterpret_cast<const unsigned long long *>(&Q.slot[8 * v_e]);
       double acc0 = extra, acc1 = 0.0;
+      const int vleg = var_leg();
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
         const int ac = (int)(signed char)((am >> (8 * rr)) & 0xff);
         const int sl = (int)((sm >> (8 * rr)) & 0xff);
         const double cf = coefv[sl];
         const double coef = (ac == 0) ? 0.0 : ((ac > 0) ? sgn * cf : -sgn * cf);
-        const double cv = S.Cn[v_leg][rr][v_k];
+        const double cv = S.Cn[vleg][rr][v_k];
         if (rr & 1) acc1 = dfma(coef, cv, acc1);
         else acc0 = dfma(coef, cv, acc0);
       }
@@ -1425,9 +1513,10 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       if (ac != 0) {
         double s = 0.0;
         const double *xp = xv + GS * c_e;
+        const double *c_cn = row_cn();
 #pragma unroll
         for (int k = 0; k < 6; ++k) s = dfma(c_cn[k], xp[k], s);
-        const double bnd = (ac > 0) ? row_lo() : c_ub;
+        const double bnd = (ac > 0) ? row_lo() : row_ub();
         Q.d[Q.slot[tid]] = (double)ac * (bnd - s);
       }
     }
@@ -1534,14 +1623,15 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     }
     __syncthreads();
     if (k0 > 0) {
+      pk_fence();
       // (b) S0(i,j) = n_i' M n_j: rows of leg-steps (e0, e1) meet only in my block
 #pragma unroll
       for (int s = 0; s < BPT; ++s)
-      if (owner[s] && e1[s] < ng) {
-        const unsigned long long am0 = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * e0[s]]);
-        const unsigned long long am1 = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * e1[s]]);
+      if (OWN(s) && E1(s) < ng) {
+        const unsigned long long am0 = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * E0(s)]);
+        const unsigned long long am1 = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * E1(s)]);
         if (am0 != 0ull && am1 != 0ull) {
-          const int leg0 = S.ls_leg[e0[s]], leg1 = S.ls_leg[e1[s]];
+          const int leg0 = S.ls_leg[E0(s)], leg1 = S.ls_leg[E1(s)];
           for (int r1 = rlo; r1 <= rhi; ++r1) {
             const int ac1 = (int)(signed char)((am1 >> (8 * r1)) & 0xff);
             if (ac1 == 0) continue;
@@ -1549,14 +1639,14 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
 #pragma unroll
             for (int k = 0; k < GS; ++k) cn1[k] = (double)ac1 * S.Cn[leg1][r1][k];
             blk_rows(s, cn1, t6);  // (a diagonal block is stored as the full symmetric 6x6)
-            const int s1 = Q.slot[8 * e1[s] + r1];
-            for (int r0 = rlo; r0 <= (diag[s] ? r1 : rhi); ++r0) {
+            const int s1 = Q.slot[8 * E1(s) + r1];
+            for (int r0 = rlo; r0 <= (DIAG(s) ? r1 : rhi); ++r0) {
               const int ac0 = (int)(signed char)((am0 >> (8 * r0)) & 0xff);
               if (ac0 == 0) continue;
               double v = 0.0;
 #pragma unroll
               for (int k = 0; k < GS; ++k) v = dfma((double)ac0 * S.Cn[leg0][r0][k], t6[k], v);
-              Eref(S, Q.slot[8 * e0[s] + r0], s1) = v;
+              Eref(S, Q.slot[8 * E0(s) + r0], s1) = v;
             }
           }
         }
@@ -1769,7 +1859,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
 
   // =============================== Q: dual active set (Goldfarb-Idnani, range-space form) ===============================
   for (int pass = 0; pass < 3 && code == S_OK; ++pass) {
-    const int iters_at_entry = iters;
+    const int iters_at_entry = uni(iters);  // (uniform: a scalar register)
     // ---- main loop ----
     while (true) {
       // (1) most violated constraint; the winning lane of each wave also publishes its constants
@@ -1787,6 +1877,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
           rc.raw = raw;
           rc.idx = tid;
           rc.side = side;
+          const double *c_cn = row_cn();
 #pragma unroll
           for (int k = 0; k < 6; ++k) rc.cn[k] = c_cn[k];
         }
@@ -1822,21 +1913,22 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
           code = S_MAXITER;
           break;
         }
+        pk_fence();
         // (2) d_j = n_j' M n+ for the active rows: the rows of leg-step eo meet n+ (on leg-step ep) only in block
         //     (min(eo,ep), max(eo,ep)), whose owner forms t = M(eo,ep) n+ once and dots it with each active row;
         //     the diagonal block also gives gamma = n+' M n+
 #pragma unroll
         for (int s = 0; s < BPT; ++s)
-        if (owner[s] && e1[s] < ng && (e0[s] == ep || e1[s] == ep)) {
+        if (OWN(s) && E1(s) < ng && (E0(s) == ep || E1(s) == ep)) {
           // t = M(eo, ep) n+: the row product when ep is this block's column leg-step (and on the diagonal), the column
           // product otherwise; both are formed (no divergence inside the wave) and one is kept
           double t6[GS], tc[GS];
           blk_rows(s, np, t6);
           blk_cols(s, np, tc);
-          const bool use_rows = (e1[s] == ep);
+          const bool use_rows = (E1(s) == ep);
 #pragma unroll
           for (int k = 0; k < GS; ++k) t6[k] = use_rows ? t6[k] : tc[k];
-          const int eo = (e0[s] == ep) ? e1[s] : e0[s];
+          const int eo = (E0(s) == ep) ? E1(s) : E0(s);
           const int lego = S.ls_leg[eo];
           const unsigned long long am = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * eo]);
           const unsigned long long sm = *reinterpret_cast<const unsigned long long *>(&Q.slot[8 * eo]);
@@ -1852,7 +1944,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
               }
             }
           }
-          if (diag[s]) {
+          if (DIAG(s)) {
             double gm = 0.0;
 #pragma unroll
             for (int k = 0; k < GS; ++k) gm = dfma(np[k], t6[k], gm);
@@ -2004,7 +2096,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   }
 
   // ---------------- output: scatter to the reference's 12h layout, eliminated variables exactly 0 (SolverMPC.cpp:720-732)
-  for (int t = tid; t < U * h; t += NT) {
+  int t_out = tid;
+  if constexpr (BPT == 2) asm volatile("" : "+v"(t_out));  // (or 8 * tid is formed at the top of the kernel, kept for the whole solve, and spilled)
+  for (int t = t_out; t < U * h; t += NT) {
     const int rmp = S.rmap[t];
     const double xv = (rmp == 255) ? 0.0 : Q.x[rmp];
     args.forces[(size_t)inst * U * h + t] = (float)xv;

@@ -1,0 +1,253 @@
+// Developer prototype: the inverse of a 120x120 SPD matrix by 4x4 block-pivot symmetric Gauss-Jordan sweeps with the
+// rank-4 updates on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), the matrix resident in the accumulator registers
+// (36 upper-triangle 16x16 tiles over 4 waves = 9 tiles = 72 VGPRs per lane -- the footprint of the scalar sweeps' 6x6 block).
+// Measures cycles per workgroup with three workgroups per CU (the headline variant's occupancy) and the accuracy of the
+// inverse; the scalar sweeps of hmpc_kernel.h cost ~122 k cycles per workgroup in the same setting (profiles/r03).
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off scripts/micro/sweep_mfma64.hip -o /tmp/sweep_mfma64 && /tmp/sweep_mfma64
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int N = 120, NP = 128, NT = 256, NTI = 8, TPW = 9;  // tiles per wave
+constexpr int PST = NP + 8;                                   // panel row stride (doubles)
+
+__device__ __forceinline__ double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ double rcp_nr(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = dfma(dfma(-d, r, 1.0), r, r);
+  r = dfma(dfma(-d, r, 1.0), r, r);
+  return r;
+}
+
+__device__ __forceinline__ double rcp1(double d) {  // v_rcp_f64 (2^-24) + one Newton step: 2e-15
+  double r = __builtin_amdgcn_rcp(d);
+  return dfma(dfma(-d, r, 1.0), r, r);
+}
+
+struct Smem {
+  double P[2][4][PST];  // published pivot panel rows (double buffered); the K columns carry D - I
+  double pad[5200];     // brings the footprint to the headline variant's (three workgroups per CU by LDS as well)
+};
+
+// tile t (0..35, block-row-major over I <= J) -> (I, J)
+constexpr int tile_i(int t) {
+  int i = 0, base = 0;
+  while (t >= base + (NTI - i)) base += NTI - i, ++i;
+  return i;
+}
+constexpr int tile_j(int t) {
+  int i = 0, base = 0;
+  while (t >= base + (NTI - i)) base += NTI - i, ++i;
+  return i + (t - base);
+}
+
+// one wave's share of the sweeps; WV (its index in the workgroup) is a template parameter so that the tile coordinates are
+// compile-time constants: LDS addresses become immediate offsets, no address registers, no coordinate tables
+template <int WV>
+__device__ __forceinline__ void sweep_wave(Smem &S, const double *H, double *M, long long *cyc, int n) {
+  const int tid = threadIdx.x, ln = tid & 63, g = ln >> 4, c = ln & 15;
+  // wave w owns tiles 9 w .. 9 w + 8 of the block-row-major numbering: at most four distinct tile rows per wave
+  struct TI {
+    int v[TPW];
+    constexpr TI(bool col) : v{} {
+      for (int t = 0; t < TPW; ++t) v[t] = col ? tile_j(TPW * WV + t) : tile_i(TPW * WV + t);
+    }
+    constexpr int operator[](int t) const { return v[t]; }
+  };
+  constexpr TI tI(false), tJ(true);
+  d4 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * tI[t] + g + 4 * r, j = 16 * tJ[t] + c;
+      acc[t][r] = (i < n && j < n) ? H[i * N + j] : ((i == j) ? 1.0 : 0.0);  // identity padding
+    }
+  }
+  const long long t0 = clock64();
+  // panel of step s from the accumulators: rows K = 4 s .. 4 s + 3 of the symmetric matrix, the pivot block as D - I.
+  //   row tiles (Ik, J):      lane (g, c) holds A[16 Ik + 4 rr + g][16 J + c] in register rr         (rr = s % 4)
+  //   column tiles (I < Ik):  lanes with c in [4 rr, 4 rr + 4) hold A[16 I + g + 4 r][16 Ik + c], r = 0..3
+  auto pick = [&](const d4 &v, int rr) __attribute__((always_inline)) -> double {  // rr uniform: scalar-conditioned selects
+    const double lo = (rr & 1) ? v[1] : v[0], hi = (rr & 1) ? v[3] : v[2];
+    return (rr & 2) ? hi : lo;
+  };
+  auto publish = [&](const int s, const int rr) __attribute__((always_inline)) {
+    const int Ik = s >> 2, c0 = 4 * rr;
+    double(*P)[PST] = S.P[s & 1];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      if (tI[t] == Ik) {  // uniform
+        asm volatile("");  // (a real branch: keeps the selects below from being speculated for every tile)
+        double v = pick(acc[t], rr);
+        if (tJ[t] == Ik) v -= (c == c0 + g) ? 1.0 : 0.0;
+        P[g][16 * tJ[t] + c] = v;
+      } else if (tJ[t] == Ik) {  // uniform
+        asm volatile("");
+        if (c >= c0 && c < c0 + 4) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) P[c - c0][16 * tI[t] + g + 4 * r] = acc[t][r];
+        }
+      }
+    }
+  };
+  auto step = [&](const int s, const int rr) __attribute__((always_inline)) {  // rr = s % 4, static
+    const int k0 = 4 * s, Ik = s >> 2;
+    const double(*P)[PST] = S.P[s & 1];
+    // x = row g of D^-1 (D = [A B; B' C] in 2x2 blocks; the panel carries D - I), every lane for its own g:
+    //   S = C - B' A^-1 B,  x_lo = S^-1 (v - B' A^-1 u),  x_hi = A^-1 u - (A^-1 B) x_lo      for e_g = [u; v]
+    const double a00 = P[0][k0] + 1.0, a10 = P[1][k0], a11 = P[1][k0 + 1] + 1.0;
+    const double b00 = P[2][k0], b01 = P[3][k0], b10 = P[2][k0 + 1], b11 = P[3][k0 + 1];  // B[i][j] = D[i][2 + j] = P[2 + j][k0 + i]
+    const double c00 = P[2][k0 + 2] + 1.0, c10 = P[3][k0 + 2], c11 = P[3][k0 + 3] + 1.0;
+    const double ia = rcp1(dfma(a00, a11, -(a10 * a10)));
+    const double p00 = a11 * ia, p01 = -a10 * ia, p11 = a00 * ia;              // A^-1
+    const double w00 = dfma(p00, b00, p01 * b10), w01 = dfma(p00, b01, p01 * b11);  // W = A^-1 B
+    const double w10 = dfma(p01, b00, p11 * b10), w11 = dfma(p01, b01, p11 * b11);
+    const double s00 = c00 - dfma(b00, w00, b10 * w10), s10 = c10 - dfma(b01, w00, b11 * w10);
+    const double s11 = c11 - dfma(b01, w01, b11 * w11);
+    const double is = rcp1(dfma(s00, s11, -(s10 * s10)));
+    const double q00 = s11 * is, q01 = -s10 * is, q11 = s00 * is;              // S^-1
+    const double u0 = (g == 0) ? 1.0 : 0.0, u1 = (g == 1) ? 1.0 : 0.0, v0 = (g == 2) ? 1.0 : 0.0, v1 = (g == 3) ? 1.0 : 0.0;
+    const double t0v = dfma(p00, u0, p01 * u1), t1v = dfma(p01, u0, p11 * u1);  // A^-1 u
+    const double r0 = v0 - dfma(b00, t0v, b10 * t1v), r1 = v1 - dfma(b01, t0v, b11 * t1v);
+    const double x2 = dfma(q00, r0, q01 * r1), x3 = dfma(q01, r0, q11 * r1);
+    const double x0 = t0v - dfma(w00, x2, w01 * x3), x1 = t1v - dfma(w10, x2, w11 * x3);
+    // rank-4 updates: tile(I,J) -= Q_I' P_J,  Q = D^-1 P;  A operand: lane (g, c) supplies -Q[g][16 I + c], B: P[g][16 J + c].
+    // Operands first (every LDS read in flight before the first use), then the matrix instructions back to back.
+    // Groups of three tiles, software pipelined: the operands of group k+1 are read while the matrix instructions of group k run.
+    constexpr int GT = 3, NGRP = TPW / GT;
+    double aop[2][GT], bop[2][GT];
+    double alast = 0.0;
+    auto fetch = [&](const int grp, double (&ao)[GT], double (&bo)[GT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < GT; ++u) {
+        const int t = grp * GT + u;
+        bo[u] = P[g][16 * tJ[t] + c];
+        if (t == 0 || tI[t] != tI[t - 1]) {  // uniform; the wave's tiles are sorted by I
+          const int m = 16 * tI[t] + c;
+          alast = -dfma(x3, P[3][m], dfma(x2, P[2][m], dfma(x1, P[1][m], x0 * P[0][m])));
+        }
+        ao[u] = alast;
+      }
+    };
+    fetch(0, aop[0], bop[0]);
+#pragma unroll
+    for (int grp = 0; grp < NGRP; ++grp) {
+      if (grp + 1 < NGRP) fetch(grp + 1, aop[(grp + 1) & 1], bop[(grp + 1) & 1]);
+#pragma unroll
+      for (int u = 0; u < GT; ++u) {
+        const int t = grp * GT + u;
+#ifndef NO_MFMA
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[grp & 1][u], bop[grp & 1][u], acc[t], 0, 0, 0);
+#else
+        acc[t][0] += aop[grp & 1][u] * bop[grp & 1][u];
+#endif
+      }
+    }
+    // the pivot block came out as 2 I - D^-1 (substituted multipliers on both sides): its diagonal is 2 too high
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+      if (tI[t] == Ik && tJ[t] == Ik) {  // uniform branch
+        asm volatile("");
+        const double two = (c == 4 * rr + g) ? 2.0 : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] -= (r == rr) ? two : 0.0;
+      }
+  };
+  publish(0, 0);
+  __syncthreads();
+  const int nsteps = (n + 3) >> 2;
+#pragma unroll 1
+  for (int s = 0; s < nsteps; ++s) {
+    step(s, s & 3);
+    if (s + 1 < nsteps) publish(s + 1, (s + 1) & 3);
+    __syncthreads();
+  }
+  const long long t1 = clock64();
+  if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * tI[t] + g + 4 * r, j = 16 * tJ[t] + c;
+      if (i < n && j < n) {
+        M[i * N + j] = -acc[t][r];
+        if (tI[t] != tJ[t]) M[j * N + i] = -acc[t][r];
+      }
+    }
+}
+
+__global__ __launch_bounds__(NT, 3) void sweep_kernel(const double *Hin, double *Mout, long long *cyc, int n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+  Smem &S = *reinterpret_cast<Smem *>(raw);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const double *H = Hin + (size_t)blockIdx.x * N * N;
+  double *M = Mout + (size_t)blockIdx.x * N * N;
+  switch (wv) {  // uniform
+    case 0: sweep_wave<0>(S, H, M, cyc, n); break;
+    case 1: sweep_wave<1>(S, H, M, cyc, n); break;
+    case 2: sweep_wave<2>(S, H, M, cyc, n); break;
+    default: sweep_wave<3>(S, H, M, cyc, n); break;
+  }
+}
+
+int main(int argc, char **argv) {
+  const int nb = argc > 1 ? atoi(argv[1]) : 3072, n = argc > 2 ? atoi(argv[2]) : 120;
+  std::vector<double> H((size_t)nb * N * N, 0.0), M((size_t)nb * N * N, 0.0);
+  srand(1);
+  const int ndist = nb < 8 ? nb : 8;  // distinct matrices (host time); the rest of the batch repeats them
+  for (int b = 0; b < ndist; ++b) {   // H = B'B + alpha I, B 40 x 120: rank deficient like B'SB, cond ~ 1e6
+    std::vector<double> B(40 * N);
+    for (auto &v : B) v = (rand() / (double)RAND_MAX - 0.5) * 8.0;
+    double *h = &H[(size_t)b * N * N];
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) {
+        double s = (i == j) ? 2e-4 : 0.0;
+        for (int k = 0; k < 40; ++k) s += B[k * N + i] * B[k * N + j];
+        h[i * N + j] = s;
+      }
+  }
+  for (int b = ndist; b < nb; ++b) memcpy(&H[(size_t)b * N * N], &H[(size_t)(b % ndist) * N * N], sizeof(double) * N * N);
+  double *dH, *dM;
+  long long *dc;
+  hipMalloc(&dH, H.size() * 8), hipMalloc(&dM, M.size() * 8), hipMalloc(&dc, nb * 8);
+  hipMemcpy(dH, H.data(), H.size() * 8, hipMemcpyHostToDevice);
+  hipFuncSetAttribute((const void *)sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0), hipEventCreate(&e1);
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(sweep_kernel, dim3(nb), dim3(NT), sizeof(Smem), 0, dH, dM, dc, n);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("launch %d: %.3f ms for %d matrices (incl. the global load/store of the matrices)\n", rep, ms, nb);
+  }
+  if (hipGetLastError() != hipSuccess) return printf("launch failed\n"), 1;
+  hipMemcpy(M.data(), dM, M.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<long long> cyc(nb);
+  hipMemcpy(cyc.data(), dc, nb * 8, hipMemcpyDeviceToHost);
+  double mean = 0;
+  for (auto v : cyc) mean += v;
+  printf("sweep cycles per workgroup (smem %zu B, 3 per CU): mean %.0f\n", sizeof(Smem), mean / nb);
+  // accuracy: |H M - I|_max and symmetry on the first matrices
+  for (int b = 0; b < 2; ++b) {
+    const double *h = &H[(size_t)b * N * N], *m = &M[(size_t)b * N * N];
+    double worst = 0, scale = 0;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) {
+        double s = 0;
+        for (int k = 0; k < n; ++k) s += h[i * N + k] * m[k * N + j];
+        worst = fmax(worst, fabs(s - (i == j)));
+        scale = fmax(scale, fabs(m[i * N + j]));
+      }
+    printf("matrix %d: |H M - I|_max = %.3e, |M|_max = %.3e\n", b, worst, scale);
+  }
+  return 0;
+}

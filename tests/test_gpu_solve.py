@@ -83,25 +83,35 @@ def test_legacy_interface_matches_oracle(oracle):
         assert (interface.last_status() & 0xFF) == 0
 
 
-def test_too_large_is_reported_for_unsized_device_records():
+def test_unsized_device_records_are_sized_on_the_device_and_a_wrong_hint_is_reported(oracle):
     """Double support over h=20 needs 240 reduced variables.  Host-uploaded records pick the wide variant by themselves
-    (next test); device-resident records launched WITHOUT the size hint run the 120-variable variant, and every instance
-    that does not fit is reported as such -- never silently wrong."""
+    (next test); device-resident records launched WITHOUT a size hint are sized on the device (classify_records_kernel at
+    the head of the solve) and each instance runs on the variant that holds it -- mixed here: single support (120
+    variables) and double support (240) in one batch.  A hint that names a smaller size than the batch contains is the
+    caller's error and is reported per instance, never silently wrong."""
     import torch
 
-    f = synthetic.make_batch(2, 20, "standing", seed=5)
-    rec = records.pack_records(f, 20)
+    fs = synthetic.make_batch(3, 20, "standing", seed=5)
+    f1 = synthetic.make_batch(3, 20, "single", seed=6, phase="random")
+    rec = np.concatenate([records.pack_records(fs, 20), records.pack_records(f1, 20)])
+    ref = oracle.solve_records(rec, 20, synthetic.DT_MPC, synthetic.F_MAX)
     d_rec = torch.from_numpy(rec).cuda()
     torch.cuda.synchronize()
-    mpc = interface.BatchedMPC(synthetic.DT_MPC, 20, synthetic.F_MAX, 2)
-    mpc.set_device_records(d_rec.data_ptr(), 2, keepalive=d_rec)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, 20, synthetic.F_MAX, 6)
+    mpc.set_device_records(d_rec.data_ptr(), 6, keepalive=d_rec)  # no hint
     mpc.solve()
     forces, status = mpc.download()
-    assert (interface.status_code(status) == 3).all() and (forces == 0).all()
-    mpc.set_device_records(d_rec.data_ptr(), 2, max_reduced_vars=240, keepalive=d_rec)  # with the hint: solved
+    assert (interface.status_code(status) == 0).all(), interface.status_code(status)
+    assert rel_inf(forces.astype(np.float64), ref["q_soln"]).max() < TOL
+    mpc.set_device_records(d_rec.data_ptr(), 6, max_reduced_vars=120, keepalive=d_rec)  # a hint that is too small
     mpc.solve()
     forces, status = mpc.download()
-    assert (interface.status_code(status) == 0).all() and (forces != 0).any()
+    assert (interface.status_code(status)[:3] == 3).all() and (forces[:3] == 0).all()
+    assert (interface.status_code(status)[3:] == 0).all()
+    mpc.set_device_records(d_rec.data_ptr(), 6, max_reduced_vars=240, keepalive=d_rec)  # the right hint: one wide launch
+    mpc.solve()
+    forces, status = mpc.download()
+    assert (interface.status_code(status) == 0).all() and rel_inf(forces.astype(np.float64), ref["q_soln"]).max() < TOL
     mpc.close()
 
 

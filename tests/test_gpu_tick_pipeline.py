@@ -162,7 +162,7 @@ def test_device_resident_records_without_a_hint_are_classified_on_the_device(ora
 
 def test_walking_ticks_built_on_the_device_run_on_the_small_variant():
     """The point of the routing: a walking sweep built on the device must cost about what the hinted 60-variable launch
-    costs, not the 120-variable one's ~3x (VERDICT round 3, weak #4)."""
+    costs (+ two launches whose workgroups leave at once), not what the 120-variable one does (VERDICT round 3, weak #4)."""
     nb = 8192
     t = synthetic.make_ticks(nb, H, "walking", seed=76)
     mpc = interface.BatchedMPC(synthetic.DT_MPC, H, synthetic.F_MAX, nb)
@@ -177,7 +177,7 @@ def test_walking_ticks_built_on_the_device_run_on_the_small_variant():
     mpc.close()
     print(f"walking b{nb} built on the device: routed {ms_routed:.3f} ms, hinted 60-variable {ms_small:.3f} ms, "
           f"120-variable {ms_big:.3f} ms")
-    assert ms_routed < 1.25 * ms_small and ms_routed < 0.6 * ms_big
+    assert ms_routed < 1.15 * ms_small and ms_routed < 0.75 * ms_big
 
 
 # ------------------------------------------------------------------------------------------------ closed loop in HBM
@@ -281,7 +281,9 @@ def test_closed_loop_with_the_tick_state_resident_in_hbm(oracle, gait):
                 cap = caller_py.tick_through_reference(caller, tick_in[j], gait_number)
                 _assert_records_equal(_record_from_capture(cap), rec[j], f"tick {k} robot {j}")
                 np.testing.assert_array_equal(cap["world_position_desired"][:2].view(np.uint64), wpd_want[j].view(np.uint64))
-                np.testing.assert_array_equal(cap["f_ff"].reshape(12).view(np.uint64), f_ff[j].view(np.uint64))
+                # (as values: a swing leg's exact-zero force gives -0.0 as a bare product and +0.0 under the Eigen stand-in,
+                #  whose products start from +0 -- the documented sign-of-zero exception of DESIGN.md section 2)
+                np.testing.assert_array_equal(cap["f_ff"].reshape(12), f_ff[j])
         # ---- plant, on the device
         _plant_step(torch, T, d_forces, IB)
     torch.cuda.synchronize()
