@@ -71,7 +71,8 @@ const Variant *variants() {
                               make_variant<60, 20, 128, 60>(),   make_variant<120, 20, 256, HMPC_QCAP_FAST>(),
                               make_variant<120, 10, 256, 120>(), make_variant<120, 20, 256, 120>(),
                               make_variant<180, 10, 256, HMPC_QCAP_3C, 3, 2>(), make_variant<180, 10, 512, 140, 3>(),
-                              make_variant<180, 10, 512, 100, 3>(), make_variant<240, 20, 512, HMPC_QCAP_WIDE, 2, 2>()};
+                              make_variant<180, 10, 512, 100, 3>(), make_variant<240, 20, 512, HMPC_QCAP_WIDE, 2, 2>(),
+                              make_variant<240, 20, 512, 0, 2, 2>(),   make_variant<180, 10, 512, 0, 3>()};
   return v;
 }
 constexpr int N_FAST = 4;       // two-contact fast variants [0, N_FAST), their safe variants N_FAST + (h > 10)
@@ -79,7 +80,11 @@ constexpr int V3_FAST = 6, V3_SAFE = 7, V3_FAST_512 = 8;  // (V3_FAST_512: the o
 // double support over more than ten steps (two contacts, 121 .. 240 reduced variables, h <= 20): 820 register blocks on 512
 // threads, two each, one workgroup per CU; working set up to HMPC_QCAP_WIDE rows (what 160 KB of LDS leave room for).
 constexpr int V2_WIDE = 9;
-constexpr int N_VARIANTS = 10;
+// QCAP = 0: working set as large as the variable count with the packed Schur inverse in GLOBAL memory (a scratch slice per
+// workgroup; 231 KB for 240 variables -- more than a CU's LDS): the safe pass of the wide variant, and the second safe pass of
+// the three-contact one (whose LDS-resident safe variant holds 140 of 180 possible rows)
+constexpr int V2_WIDE_SAFE = 10, V3_SAFE_G = 11;
+constexpr int N_VARIANTS = 12;
 constexpr int MAX_VARS_ANY = 240;
 constexpr int DBG_FLOATS_MAX = hmpc::DbgLayout<240, 2>::TOTAL > hmpc::DbgLayout<180, 3>::TOTAL
                                    ? hmpc::DbgLayout<240, 2>::TOTAL
@@ -132,8 +137,12 @@ struct hmpc_handle {
   // pointer, by classify_records_kernel at the head of every solve
   unsigned char *d_cls;
   int cls_valid;
+  // packed Schur inverses of the EGLOBAL safe variants: [e_slices][nmax (nmax + 1) / 2] doubles, grown on demand
+  double *d_escratch;
+  size_t e_bytes;
 };
 constexpr int REPAIR_GRID_CAP = 2048;  // workgroups of the device-side safe launch = most instances it can repair per solve
+constexpr int REPAIR_GRID_CAP_WIDE = 256;  // ... of the wide variant's, whose safe pass keeps 231 KB per workgroup in global memory
 
 // returns a device buffer of at least `bytes` owned by the handle (contents undefined)
 static int scratch(hmpc_handle *h, size_t bytes, void **out) {
@@ -197,6 +206,7 @@ struct LaunchOpt {
   const unsigned int *d_list_count = nullptr;
   bool record_flagged = false;
   int variant = -1;        // -1 = pick_variant; else this entry of variants() (the size-class launches)
+  bool ultimate = false;   // safe pass, second level (three contacts): the variant whose working set cannot overflow
   int cls_lo = 0, cls_hi = -1;  // cls_hi >= 0: only instances whose size class lies in [cls_lo, cls_hi] (h->d_cls)
 };
 
@@ -204,11 +214,27 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   int vi = 0;
   const Variant *pv = &pick_variant(h, &vi);
   if (o.variant >= 0) vi = o.variant, pv = &variants()[vi];
-  if (o.d_index_list && vi != V2_WIDE) {  // safe variant: working set as large as the variable count
-    vi = (h->nc == 3) ? V3_SAFE : ((h->setup.horizon <= 10) ? N_FAST : N_FAST + 1);
+  if (o.d_index_list) {  // safe variant: working set as large as the variable count
+    if (vi == V2_WIDE) vi = V2_WIDE_SAFE;                  // ... which for 240 variables only global memory holds
+    else if (h->nc == 3) vi = o.ultimate ? V3_SAFE_G : V3_SAFE;
+    else vi = (h->setup.horizon <= 10) ? N_FAST : N_FAST + 1;
     pv = &variants()[vi];
-  }  // (the wide variant is its own safe pass: cold start, same working-set capacity -- LDS has no room for more)
+  }
   const Variant &v = *pv;
+  const int grid = o.assemble_only ? 1 : (o.d_index_list ? o.n_list : h->batch);
+  if (grid < 1) return HMPC_OK;
+  if (v.qcap == 0) {  // EGLOBAL: one slice of packed triangle per workgroup of this launch
+    const size_t need = (size_t)grid * ((size_t)v.nmax * (v.nmax + 1) / 2) * sizeof(double);
+    if (need > h->e_bytes) {
+      if (h->d_escratch) {
+        HIP_TRY(hipStreamSynchronize(stream));  // (an earlier launch on this stream may still be using the old buffer)
+        HIP_TRY(hipFree(h->d_escratch));
+        h->d_escratch = nullptr, h->e_bytes = 0;
+      }
+      HIP_TRY(hipMalloc(&h->d_escratch, need));
+      h->e_bytes = need;
+    }
+  }
   kernel_fn fn = o.assemble_only ? v.assemble : v.solve;
   if (!h->attrs_set[vi]) {
     HIP_TRY(hipFuncSetAttribute((const void *)v.solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.smem));
@@ -244,8 +270,7 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   a.iter_cap = h->iter_cap;
   a.cls = (o.cls_hi >= 0) ? h->d_cls : nullptr;
   a.cls_lo = o.cls_lo, a.cls_hi = o.cls_hi;
-  const int grid = o.assemble_only ? 1 : (o.d_index_list ? o.n_list : h->batch);
-  if (grid < 1) return HMPC_OK;
+  a.e_scratch = h->d_escratch;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(v.nt), v.smem, stream, a);
   HIP_TRY(hipGetLastError());
   return HMPC_OK;
@@ -293,6 +318,11 @@ static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
   LaunchOpt s;
   s.d_index_list = h->d_flag_list;
   s.n_list = h->batch < REPAIR_GRID_CAP ? h->batch : REPAIR_GRID_CAP;
+  {
+    int vsel = 0;
+    (void)pick_variant(h, &vsel);
+    if (vsel == V2_WIDE && s.n_list > REPAIR_GRID_CAP_WIDE) s.n_list = REPAIR_GRID_CAP_WIDE;  // (231 KB of global scratch per workgroup)
+  }
   s.warm = 0;
   s.carry_wset = carry_wset;
   s.d_list_count = h->d_flag_count;
@@ -422,6 +452,7 @@ int hmpc_destroy(hmpc_handle *h) {
   if (h->d_flag_list) hipFree(h->d_flag_list);
   if (h->d_flag_count) hipFree(h->d_flag_count);
   if (h->d_cls) hipFree(h->d_cls);
+  if (h->d_escratch) hipFree(h->d_escratch);
   delete h;
   return HMPC_OK;
 }
@@ -604,13 +635,29 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
   if (n_resolved) *n_resolved = (int)idx.size();
   // last resort for instances that cycle at a degenerate vertex even with the full-size working set: bounds moved outward
   // by 1e-7, then 1e-6 (a different amount per row), reported as HMPC_S_OK_RELAXED
-  const double relax_levels[2] = {1e-7, 1e-6};
-  for (int lvl = 0; lvl < 2; ++lvl) {
+  if (h->nc == 3) {
+    // second level for three contacts: instances whose working set outgrew even the LDS-resident safe variant (140 of 180 rows)
+    std::vector<int> full;
+    HIP_TRY(hipMemcpy(st.data(), h->d_status, (size_t)h->batch * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int i : idx)
+      if (HMPC_STATUS_CODE(st[i]) == HMPC_S_WORKSET) full.push_back(i);
+    if (!full.empty()) {
+      HIP_TRY(hipMemcpy(d_idx, full.data(), full.size() * sizeof(int), hipMemcpyHostToDevice));
+      so.n_list = (int)full.size(), so.ultimate = true;
+      rc = launch(h, h->last_stream, so);
+      if (rc != HMPC_OK) return rc;
+      HIP_TRY(hipStreamSynchronize(h->last_stream));
+    }
+  }
+  // (with the exact re-solve that ends a relaxed pass -- see the kernel -- a larger perturbation costs nothing when its working
+  //  set turns out to be optimal for the exact bounds: such an instance is reported HMPC_S_OK, exact)
+  const double relax_levels[3] = {1e-7, 1e-6, 1e-5};
+  for (int lvl = 0; lvl < 3; ++lvl) {
     std::vector<int> still;
     HIP_TRY(hipMemcpy(st.data(), h->d_status, (size_t)h->batch * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (int i : idx) {
       const uint32_t c = HMPC_STATUS_CODE(st[i]);
-      if ((c == HMPC_S_MAXITER && h->iter_cap <= 0) || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT) still.push_back(i);
+      if ((c == HMPC_S_MAXITER && h->iter_cap <= 0) || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT || c == HMPC_S_WORKSET) still.push_back(i);
     }
     if (still.empty()) break;
     HIP_TRY(hipMemcpy(d_idx, still.data(), still.size() * sizeof(int), hipMemcpyHostToDevice));

@@ -92,6 +92,9 @@ struct KernelArgs {
   // is solved by the smallest one that holds it -- no host round trip.  nullptr = every workgroup runs.
   const unsigned char *cls;
   int cls_lo, cls_hi;
+  // scratch for the variants that keep the packed Schur inverse in global memory (Smem::EGLOBAL): NMAX (NMAX + 1) / 2
+  // doubles per WORKGROUP of the launch (indexed by blockIdx.x)
+  double *e_scratch;
 };
 constexpr int NPROF = 32;
 enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A, P_A0, P_A1, P_A2, P_G };
@@ -134,7 +137,12 @@ struct Smem {
   static constexpr int NG = NMAX / GS;   // leg-steps (blocks per matrix side)
   static constexpr int MMAX = NG * 8;    // constraint rows
   static constexpr int NW = NT / 64;
-  static constexpr int QMAX = QCAP;      // working-set capacity (packed Schur inverse); QCAP = NMAX can never overflow
+  // working-set capacity (packed Schur inverse E); QCAP = NMAX can never overflow.  QCAP = 0: capacity NMAX with E in GLOBAL
+  // memory (a per-workgroup scratch slice, L2-resident) instead of LDS -- the safe pass of the wide variant, whose 240 x 240
+  // packed triangle (231 KB) no CU's LDS holds
+  static constexpr bool EGLOBAL = (QCAP == 0);
+  static constexpr int QMAX = EGLOBAL ? NMAX : QCAP;
+  static constexpr int EP_LDS = EGLOBAL ? 1 : QMAX * (QMAX + 1) / 2;
   static constexpr int RECW = ((RecLayout<NC>::NF + 12 * HMAX) * 4 + NC * HMAX + 15) / 16 * 4;  // record words
   static constexpr bool FULLBLK = (HMAX <= 10 && NMAX >= 120);  // staging layout of H (struct Asm)
   // FULLBLK staging passes: pass p holds the blocks of the block-diagonals d in [hs_dlo(p), hs_dlo(p+1))
@@ -203,7 +211,7 @@ struct Smem {
     unsigned char flpc[MMAX];  // row has already been switched to its other bound once by the block start
     typedef typename std::conditional<(MMAX > 256), unsigned short, unsigned char>::type row_t;
     row_t Wrow[NMAX];  // working-set slot -> constraint row
-    double Ep[QMAX * (QMAX + 1) / 2];  // E = (N_W M N_W')^-1, packed lower triangle: E(i,j), i>=j, at i(i+1)/2 + j
+    double Ep[EP_LDS];  // E = (N_W M N_W')^-1, packed lower triangle: E(i,j), i>=j, at i(i+1)/2 + j (EGLOBAL: in args.e_scratch)
   };
   union {
     Asm a;
@@ -217,11 +225,6 @@ template <int NMAX>
 __device__ __forceinline__ int hs_index(int i, int j) {
   const bool first = 2 * i < NMAX;
   return (first ? i : NMAX - 1 - i) * (NMAX + 1) + (first ? j - i : j + 1);
-}
-template <class SM>
-__device__ __forceinline__ double &Eref(SM &S, int i, int j) {
-  const int lo = i < j ? i : j, hi = i < j ? j : i;
-  return S.u.s.Ep[hi * (hi + 1) / 2 + lo];
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // a binary64 value every lane agrees on, moved to scalar registers
@@ -361,8 +364,18 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   SM &S = *reinterpret_cast<SM *>(smem_raw);
   auto &A = S.u.a;
   auto &Q = S.u.s;
+  // the packed Schur inverse: LDS, or this workgroup's slice of the global scratch
+  double *const Ep = [&]() __attribute__((always_inline)) -> double * {
+    if constexpr (SM::EGLOBAL) return args.e_scratch + (size_t)blockIdx.x * (size_t)(NMAX * (NMAX + 1) / 2);
+    else return S.u.s.Ep;
+  }();
+  auto Eat = [&](int i, int j) __attribute__((always_inline)) -> double & {
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    return Ep[(unsigned)(hi * (hi + 1) / 2 + lo)];  // (unsigned: a scalar base + 32-bit lane offset when E is in global memory)
+  };
 
-  const int tid = threadIdx.x, wv = uni(tid >> 6), ln = tid & 63;
+  const int tid = threadIdx.x, wv = uni(tid >> 6);
+  const auto ln = lazy_int<(BPT == 2)>([](int t) { return t & 63; });  // lane (recomputed at every use in the two-block variants)
   if (!ASM_ONLY && args.list_count && blockIdx.x >= *args.list_count) return;  // device-side safe pass: nothing (more) flagged
   // (uniform by construction -- but when it comes from the index list it arrives through a vector load: told to the compiler, so
   //  that the instance's base addresses are scalar arithmetic instead of register pairs that live for the whole kernel)
@@ -1347,8 +1360,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   auto row_ub_calc = [&]() __attribute__((always_inline)) -> double {
     const int rr = c_rr;
     double u = (rr == 4) ? (double)0.01f : (rr == 7 ? S.ub7[c_e] : 0.0);
-    const double rl = LAZY ? S.relax : args.relax;
-    if (LAZY ? ub(rl != 0.0) : (rl != 0.0)) {
+    const double rl = S.relax;
+    if (ub(rl != 0.0)) {
       const double fr = 0.6180339887498949 * (double)(tid + 1);
       const double dl = rl * (1.0 + (fr - __builtin_floor(fr)));
       u += dl * ((rr == 7 && u > 1.0) ? u : 1.0);
@@ -1397,7 +1410,11 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   PROF_MARK(P_XU);
 
   int q = 0, iters = 0, code = S_OK;
-  const int itmax_v = (QCAP >= NMAX || QCAP >= 140) ? 10 * m + 64 : 4 * m + 16;  // the safe variants may take as long as a cold qpOASES run (nWSR up to ~330 seen)
+  constexpr bool SAFE = SM::EGLOBAL || QCAP >= NMAX;  // the working set cannot overflow
+  // ... and of those, the variants hmpc_resolve_failed / the device-side repair launch (always cold): the only ones that ever run
+  // for hundreds of iterations (the 60-variable fast variants also have QCAP = NMAX, but are fast variants)
+  constexpr bool LONGRUN = SM::EGLOBAL || (QCAP >= NMAX && NMAX >= 120);
+  const int itmax_v = (SAFE || QCAP >= 140) ? 10 * m + 64 : 4 * m + 16;  // the safe variants may take as long as a cold qpOASES run (nWSR up to ~330 seen)
   const int itmax = (args.iter_cap > 0 && args.iter_cap < itmax_v) ? args.iter_cap : itmax_v;
   bool c_ignored = false;  // this thread's row was found redundant at a degenerate vertex (violated by round-off only)
 
@@ -1447,7 +1464,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         for (int i = part; i < q; i += 16) {
           const int i1 = (i + 4 < q) ? i + 4 : i, i2 = (i + 8 < q) ? i + 8 : i, i3 = (i + 12 < q) ? i + 12 : i;
-          const double x0 = Eref(S, j, i), x1 = Eref(S, j, i1), x2 = Eref(S, j, i2), x3 = Eref(S, j, i3);
+          const double x0 = Eat(j, i), x1 = Eat(j, i1), x2 = Eat(j, i2), x3 = Eat(j, i3);
           const double d0 = din[i], d1 = din[i1], d2 = din[i2], d3 = din[i3];
           a0 = dfma(x0, d0, a0);
           a1 = (i + 4 < q) ? dfma(x1, d1, a1) : a1;
@@ -1472,17 +1489,17 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // moves into l.  Two barriers inside.
   // With follow_u the multipliers of the remaining rows follow the removal, u_R <- u_R - E(R,l) u_l / E(l,l)  (= E' d_R).
   auto drop_slot = [&](int l, bool follow_u = false, double ul = 0.0) __attribute__((always_inline)) {
-    const double iel = 1.0 / Eref(S, l, l);
+    const double iel = 1.0 / Eat(l, l);
     const int ti = tid >> 4, tj = tid & 15;
-    if (follow_u && tid < q && tid != l) Q.u[tid] = dfma(-(Eref(S, tid, l) * iel), ul, Q.u[tid]);
+    if (follow_u && tid < q && tid != l) Q.u[tid] = dfma(-(Eat(tid, l) * iel), ul, Q.u[tid]);
     for (int ib = 0; ib < q; ib += NT / 16) {
       const int i = ib + ti;
       if (i < q && i != l) {
-        const double ci = Eref(S, i, l) * iel;
+        const double ci = Eat(i, l) * iel;
         for (int j = tj; j <= i; j += 16) {
           if (j != l) {
-            double &ee = Q.Ep[i * (i + 1) / 2 + j];
-            ee = dfma(-ci, Eref(S, j, l), ee);
+            double &ee = Ep[(unsigned)(i * (i + 1) / 2 + j)];
+            ee = dfma(-ci, Eat(j, l), ee);
           }
         }
       }
@@ -1490,8 +1507,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     __syncthreads();
     const int last = q - 1;
     if (l != last) {
-      if (tid < last && tid != l) Eref(S, l, tid) = Eref(S, last, tid);
-      if (tid == l) Eref(S, l, l) = Eref(S, last, last);
+      if (tid < last && tid != l) Eat(l, tid) = Eat(last, tid);
+      if (tid == l) Eat(l, l) = Eat(last, last);
     }
     if (tid == 0) {
       const int cl = Q.Wrow[l];
@@ -1523,7 +1540,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   };
 
   // =============================== W: block warm start ===============================
-  if (args.warm) {
+  // (the machinery is declared at function scope: the safe variants call a round again from the main loop, as a refresh of E)
     // (a) rows 4-6 (foot-x moment window, toe and heel line contact) violated at x_u take consecutive slots.  The three
     //     rows of a leg-step are linearly independent, rows of different leg-steps touch disjoint variables, so the
     //     Schur matrix of any such set is positive definite.
@@ -1563,14 +1580,16 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     static_assert(KBMAX * (KBMAX + 1) / 2 <= EPT * NT && KBMAX <= SM::QMAX, "block start capacity");
     // (one round as a lambda instantiated once per round rather than a loop: with the loop the register allocator keeps
     //  ~50 more VGPRs alive across the whole phase -- measured 185 -> 244 on the unconstrained variants)
-    auto block_round = [&](const int round) __attribute__((always_inline)) -> bool {  // true: another round may follow
+    // refresh (safe variants only): the round is there to REBUILD E for the current working set (plus whatever is violated) --
+    // no minimum of new rows, and working sets beyond the register-resident inversion's capacity go through the in-place one
+    auto block_round = [&](const int round, const bool refresh) __attribute__((always_inline)) -> bool {  // true: another round may follow
     if (round > 0) {
       take = false;
       bool fresh = false;
       if (is_c) {
         const int ac = Q.act[tid];
         bool viol = false;
-        if (ac == 0 && c_rr <= 6) viol = my_slack(Q.x, side, raw) < -FEAS_TOL;
+        if (!refresh && ac == 0 && c_rr <= 6) viol = my_slack(Q.x, side, raw) < -FEAS_TOL;  // (a refresh rebuilds E for the working set AS IT IS)
         if (ac != 0) side = ac;
         const unsigned long long bal = __ballot(viol || ac != 0);
         const bool partner = (c_rr < 4) && ((bal >> (ln ^ 1)) & 1ull);
@@ -1578,7 +1597,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         take = (ac != 0) || fresh;
       }
       count_candidates();
-      if (ub(k0 - q < BLOCK_MIN_NEW || k0 > KBMAX)) return false;  // not worth a round / does not fit / iteration cap: the iteration below goes on
+      if (ub((!refresh && k0 - q < BLOCK_MIN_NEW) || k0 > (LONGRUN ? SM::QMAX : KBMAX))) return false;  // not worth a round / does not fit: the iteration below goes on
       __syncthreads();  // wcount is free again
       ++iters;
       tick = true;  // rows 0..7 may be in the set from here on
@@ -1613,7 +1632,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     }
     const int rlo = (tick || BLOCK_FRICTION) ? 0 : 4, rhi = tick ? 7 : 6;
     bool bad_start = false;
-    if (k0 > KBMAX) k0 = KBMAX;
+    if (k0 > (LONGRUN ? SM::QMAX : KBMAX)) k0 = LONGRUN ? SM::QMAX : KBMAX;
     if (is_c) {  // slots are dealt afresh every round (E is rebuilt from scratch)
       const bool in = take && base + below < k0;
       const int sl = in ? base + below : 0;
@@ -1646,7 +1665,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
               double v = 0.0;
 #pragma unroll
               for (int k = 0; k < GS; ++k) v = dfma((double)ac0 * S.Cn[leg0][r0][k], t6[k], v);
-              Eref(S, Q.slot[8 * E0(s) + r0], s1) = v;
+              Eat(Q.slot[8 * E0(s) + r0], s1) = v;
             }
           }
         }
@@ -1654,8 +1673,36 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       __syncthreads();
       PROF_MARK(P_B_S0);
       // (c) inversion of the k0 x k0 Schur matrix by symmetric sweeps with the packed triangle spread over the threads'
-      //     registers (<= EPT entries each)
-      {
+      //     registers (<= EPT entries each); the safe variants also take sets beyond that capacity, swept in place
+      //     (LDS, or global for the EGLOBAL variant), one pivot per two barriers -- slow, and only ever run for the handful of
+      //     instances per thousand that need hundreds of working-set changes at many times the nominal input ranges
+      if (LONGRUN && (SM::EGLOBAL || ub(k0 > KBMAX))) {  // (EGLOBAL: always in place -- one inversion path less to hold registers for)
+        bad_start = false;
+        const int ti = tid >> 4, tj = tid & 15;
+        for (int sp = 0; sp < k0; ++sp) {
+          for (int i = tid; i < k0; i += NT) Q.col[i] = Eat(i, sp);
+          __syncthreads();
+          const double dv = Q.col[sp];
+          bad_start = bad_start || !(dv > 1e-7);
+          double idv = __builtin_amdgcn_rcp(dv);
+          idv = dfma(dfma(-dv, idv, 1.0), idv, idv);
+          idv = dfma(dfma(-dv, idv, 1.0), idv, idv);
+          for (int ib = 0; ib < k0; ib += NT / 16) {
+            const int i = ib + ti;
+            if (i < k0) {
+              const double ci = Q.col[i] * idv;
+              for (int j = tj; j <= i; j += 16) {
+                double &ee = Ep[(unsigned)(i * (i + 1) / 2 + j)];
+                const double cj = Q.col[j];
+                ee = (i == sp) ? ((j == sp) ? -idv : cj * idv) : ((j == sp) ? ci : dfma(-ci, cj, ee));
+              }
+            }
+          }
+          __syncthreads();
+        }
+        for (int t = tid; t < k0 * (k0 + 1) / 2; t += NT) Ep[(unsigned)(t)] = -Ep[(unsigned)(t)];  // the sweeps leave -S0^-1
+        __syncthreads();
+      } else {
         const int npair = k0 * (k0 + 1) / 2;
         const int nept = (npair + NT - 1) / NT;
         bad_start = false;
@@ -1671,7 +1718,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
             while ((i + 1) * (i + 2) / 2 <= t) ++i;
             while (i * (i + 1) / 2 > t) --i;
             j = t - i * (i + 1) / 2;
-            v = Q.Ep[t];
+            v = Ep[(unsigned)(t)];
           } else {
             i = -1, j = -1;
           }
@@ -1743,7 +1790,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         }
 #pragma unroll
         for (int u = 0; u < EPT; ++u)
-          if (ei[u] >= 0) Q.Ep[tid + NT * u] = -er[u];  // the sweeps leave -S0^-1
+          if (ei[u] >= 0) Ep[(unsigned)(tid + NT * u)] = -er[u];  // the sweeps leave -S0^-1
       }
       q = k0;
       PROF_MARK(P_B_INV);
@@ -1772,7 +1819,10 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       // each row at most once -- instead of being released and added again later: n_j -> -n_j, b_j -> the other bound, so
       // E(a,b) -> s_a s_b E(a,b) (no new inversion), then u = E (b - N x_u) again.  Measured on the 2-contact set: 8.9 ->
       // about 4.4 working-set changes per solve (offline emulation; GPU: mean iterations 9.1 -> see profiles/r02).  Same optimum (the QP is strictly convex; the final KKT check is unchanged).
-      while (true) {
+      // (not in a refresh: there the working set is a Goldfarb-Idnani state already -- jumping to another dual-feasible set could
+      //  lower the dual objective and make the iteration cycle; multipliers that come out negative by round-off are left to the
+      //  ratio test of the next step)
+      while (!refresh) {
         double um = (tid < q) ? Q.u[tid] : INF;
         bool cand = false;
         if (tid < q && um < -1e-12) {
@@ -1813,7 +1863,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
               const int i = ib + ti;
               if (i < q) {
                 const double si = Q.r[i];
-                for (int j = tj; j < i; j += 16) Q.Ep[i * (i + 1) / 2 + j] *= si * Q.r[j];
+                for (int j = tj; j < i; j += 16) Ep[(unsigned)(i * (i + 1) / 2 + j)] *= si * Q.r[j];
               }
             }
           }
@@ -1846,22 +1896,39 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     }
     return !ub(k0 == 0 || q == 0);  // (nothing to build on otherwise)
     };  // block_round
-    bool more = block_round(0);
+  if constexpr (!LONGRUN)  // (the safe-pass variants are only ever launched cold: the opening rounds are not even compiled for them)
+  if (args.warm) {
+    bool more = block_round(0, false);
     if constexpr (BLOCK_ROUNDS > 1) {
-      if (more) more = block_round(1);
+      if (more) more = block_round(1, false);
     }
     if constexpr (BLOCK_ROUNDS > 2) {
-      if (more) more = block_round(2);
+      if (more) more = block_round(2, false);
     }
     static_assert(BLOCK_ROUNDS <= 3, "rounds are instantiated one by one");
   }
   PROF_MARK(P_BLOCK);
 
   // =============================== Q: dual active set (Goldfarb-Idnani, range-space form) ===============================
+  // Safe-pass variants (LONGRUN): E = (N_W M N_W')^-1 is kept current by rank-one updates (bordering / Schur downdates), whose round-off adds up
+  // over the hundreds of working-set changes a run at many times the nominal input ranges takes (measured: a 470-iteration
+  // run ended 3.5 N off its constraints while every multiplier looked fine).  So every REFRESH_EVERY changes -- and once more
+  // before the final refinement when enough have happened since -- E is REBUILT from the register blocks of M for the
+  // current working set (a block round in refresh mode: S0 formed block-locally, inverted from scratch, multipliers and
+  // point recomputed, rows whose multiplier comes out negative released).  The fast variants never run long enough to need it.
+  constexpr int REFRESH_EVERY = 48, REFRESH_FINAL = 12;
+  int since_refresh = 0;
   for (int pass = 0; pass < 3 && code == S_OK; ++pass) {
     const int iters_at_entry = uni(iters);  // (uniform: a scalar register)
     // ---- main loop ----
     while (true) {
+      if constexpr (LONGRUN) {
+        if (ub(since_refresh >= REFRESH_EVERY && q > 0)) {
+          __syncthreads();
+          (void)block_round(3, true);
+          since_refresh = 0;
+        }
+      }
       // (1) most violated constraint; the winning lane of each wave also publishes its constants
       double val = INF, raw = INF;
       int side = 1;
@@ -2019,14 +2086,14 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
             if (i < q) {
               const double ri = Q.r[i] * idl;
               for (int j = tj; j <= i; j += 16) {
-                double &ee = Q.Ep[i * (i + 1) / 2 + j];
+                double &ee = Ep[(unsigned)(i * (i + 1) / 2 + j)];
                 ee = dfma(ri, Q.r[j], ee);
               }
             }
           }
-          if (tid < q) Q.Ep[q * (q + 1) / 2 + tid] = -Q.r[tid] * idl;
+          if (tid < q) Ep[(unsigned)(q * (q + 1) / 2 + tid)] = -Q.r[tid] * idl;
           if (tid == q) {
-            Q.Ep[q * (q + 1) / 2 + q] = idl;
+            Ep[(unsigned)(q * (q + 1) / 2 + q)] = idl;
             Q.u[q] = up;
             Q.Wrow[q] = (typename SM::Sol::row_t)p;
             Q.act[p] = (signed char)sgi;
@@ -2038,6 +2105,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         } else {
           drop_slot(l);  // partial (or pure dual) step: slot l leaves
         }
+        if constexpr (LONGRUN) ++since_refresh;
         PROF_MARK(P_UPD);
       }
       if (code != S_OK) break;
@@ -2046,6 +2114,14 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     // nothing happened in this pass: either the refined point of the previous pass is feasible, or (first pass) the block
     // start already is the optimum -- its x, u, E come straight from the inversion, there is nothing to refine
     if (iters == iters_at_entry) break;
+    if constexpr (LONGRUN) {
+      if (ub(since_refresh >= REFRESH_FINAL)) {  // the answer is read off a freshly built E; the loop above then confirms it
+        __syncthreads();
+        (void)block_round(3, true);
+        since_refresh = 0;
+        continue;
+      }
+    }
 
     // ---- refinement of the multipliers on the final working set: u += E (b_W - N_W x(u)), x(u) = x_u + M N_W' u ----
     for (int it = 0; it <= HMPC_REFINE; ++it) {
@@ -2067,12 +2143,29 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   }
 
   PROF_MARK(P_POLISH);
-  // final KKT check: primal slack and multiplier signs
+  // final KKT check: primal slack (every row not in the working set), residual of the working set's rows, multiplier signs
   __syncthreads();
-  {
+  auto kkt_ok = [&]() __attribute__((always_inline)) -> bool {
     double val = INF, raw;
     int side;
-    if (is_c && Q.act[tid] == 0) val = my_slack(Q.x, side, raw);  // set-aside rows are checked again here
+    if (is_c) {
+      const int ac = Q.act[tid];
+      if (ac == 0) {
+        val = my_slack(Q.x, side, raw);  // set-aside rows are checked again here
+      } else {
+        // a row of the working set must sit ON its bound: x comes from x_u + M N' u with u from the explicitly updated Schur
+        // inverse E, and hundreds of rank-one updates of E (safe-variant runs at many times the nominal input ranges) can
+        // drift until N_W x = b_W no longer holds -- that must end as HMPC_S_KKT, never as a quietly wrong "ok"
+        double sx = 0.0;
+        const double *xp = Q.x + GS * c_e;
+        const double *c_cn = row_cn();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sx = dfma(c_cn[k], xp[k], sx);
+        const double bnd = (ac > 0) ? row_lo() : row_ub();
+        const double sc = ((tid & 7) == 7 && ac < 0) ? S.sc7[c_e] : 1.0;  // (the Fz cap on a unit scale, as in my_slack)
+        val = -__builtin_fabs(sx - bnd) * sc;
+      }
+    }
     double umin = (tid < q) ? Q.u[tid] : INF;
     val = wave_min(val);
     umin = wave_min(umin);
@@ -2090,9 +2183,42 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     double xmax = 1.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) xmax = (-Q.redw[w] > xmax) ? -Q.redw[w] : xmax;
-    constexpr double KKT_TOL = (QCAP >= NMAX && NMAX >= 120) ? 2e-5 : 2e-6;
-    if (code == S_OK && (val < -KKT_TOL * xmax || umin < -1e-6 * xmax)) code = S_KKT;  // relative to the force scale
-    if (code == S_OK && args.relax != 0.0) code = S_OK_RELAXED;
+    constexpr double KKT_TOL = LONGRUN ? 2e-5 : 2e-6;
+    return !(val < -KKT_TOL * xmax || umin < -1e-6 * xmax);  // relative to the force scale
+  };
+  if (code == S_OK && !ub(kkt_ok())) code = S_KKT;  // (the reductions leave the same values in every lane: a scalar decision)
+  if (ub(args.relax != 0.0) && code == S_OK) {
+    // Last-resort pass (bounds moved outward, hmpc_resolve_failed): the perturbation was only there to separate coinciding
+    // vertices.  With the working set it ended on, the multipliers and the point are re-solved for the EXACT bounds
+    // (x(u) is linear in u: one correction u += E (b_W - N_W x(u)) lands on the exact vertex) and the KKT check is repeated
+    // with the exact bounds.  Passed: the instance is solved exactly, HMPC_S_OK.  Not passed (the perturbed problem's
+    // working set is not optimal for the exact one): the perturbed answer is kept and reported as HMPC_S_OK_RELAXED.
+    __syncthreads();
+    if (is_v) Q.col[tid] = Q.x[tid];
+    if (tid == 0) S.relax = 0.0;
+    __syncthreads();
+    if constexpr (!LAZY) {
+      if (is_c) c_ub_r = row_ub_calc();
+    }
+    active_residual(Q.x);
+    __syncthreads();
+    {
+      double dmy = INF;
+      int dj = 0;
+      e_times(Q.d, Q.u, true, dmy, dj, false);
+    }
+    __syncthreads();
+    gather_w(Q.u, 1.0, 0.0);
+    __syncthreads();
+    rmatvec(Q.w);
+    if (is_v) Q.x[tid] = Q.xu[tid] + Q.z[tid];
+    __syncthreads();
+    if (!ub(kkt_ok())) {
+      __syncthreads();
+      if (is_v) Q.x[tid] = Q.col[tid];
+      code = S_OK_RELAXED;
+      __syncthreads();
+    }
   }
 
   // ---------------- output: scatter to the reference's 12h layout, eliminated variables exactly 0 (SolverMPC.cpp:720-732)

@@ -1,27 +1,64 @@
-import sys, numpy as np
-sys.path.insert(0,'/root/repo')
-from hector_simulation_amd import interface, records, synthetic
-from oracle import oracle_py as O
+#!/usr/bin/env python3
+"""Developer tool: robustness sweep at 1x / 3x / 6x / 10x the nominal input ranges, every instance against qpOASES.
+Prints, per case, the status codes after the fast pass and after the safe / last-resort passes, and the worst error of
+everything reported solved.    python scripts/stress.py [nb]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402,F401
+
+torch.zeros(1, device="cuda")
+from hector_simulation_amd import interface, records, synthetic  # noqa: E402
+from oracle import pool  # noqa: E402
+
+
 def hard_batch(nb, h, gait, seed, scale):
     f = synthetic.make_batch(nb, h, gait, seed=seed, phase="random", yaw_rate_cmd=True)
-    rng = np.random.default_rng(seed+1)
-    rpy = rng.uniform(-0.1*scale, 0.1*scale, (nb,3))
-    f["q"] = synthetic.quat_from_rpy(rpy[:,0], rpy[:,1], rpy[:,2])
-    f["v"] = rng.uniform(-0.3*scale, 0.3*scale, (nb,3))
-    f["w"] = rng.uniform(-0.5*scale, 0.5*scale, (nb,3))
-    f["joint_angles"] = rng.uniform(-0.15*scale, 0.15*scale, (nb,10))
-    tr = f["traj"].reshape(nb,h,12); tr[:,:,9] *= scale; f["traj"]=tr.reshape(nb,-1)
+    rng = np.random.default_rng(seed + 1)
+    rpy = rng.uniform(-0.1 * scale, 0.1 * scale, (nb, 3))
+    f["q"] = synthetic.quat_from_rpy(rpy[:, 0], rpy[:, 1], rpy[:, 2])
+    f["v"] = rng.uniform(-0.3 * scale, 0.3 * scale, (nb, 3))
+    f["w"] = rng.uniform(-0.5 * scale, 0.5 * scale, (nb, 3))
+    f["joint_angles"] = rng.uniform(-0.15 * scale, 0.15 * scale, (nb, 10))
+    tr = f["traj"].reshape(nb, h, 12)
+    tr[:, :, 9] *= scale
+    f["traj"] = tr.reshape(nb, -1)
     return f
-for gait,h in (("standing",10),("walking",10),("mixed",10),("single",20)):
-  for scale in (1,3,6):
-    nb=256
-    f = hard_batch(nb,h,gait,17,scale); rec = records.pack_records(f,h)
-    mpc = interface.BatchedMPC(synthetic.DT_MPC,h,synthetic.F_MAX,nb); mpc.set_auto_resolve(False); mpc.upload(rec); mpc.solve(); forces0,status0 = mpc.download(); nres = mpc.resolve_failed(); forces,status = mpc.download(); mpc.close()
-    print('   fast-pass codes', dict(zip(*np.unique(interface.status_code(status0),return_counts=True))), 're-solved', nres)
-    code = interface.status_code(status)
-    ref = O.solve_records(rec,h,synthetic.DT_MPC,synthetic.F_MAX)
-    ok = (code==0) | (code==6)
-    rel = (code==6)
-    q = ref["q_soln"]; err = np.abs(forces-q).max(axis=1)/np.maximum(1,np.abs(q).max(axis=1))
-    # per-instance qpOASES status unknown (n_bad total); report
-    print(gait,h,"scale",scale,"gpu codes",dict(zip(*np.unique(code,return_counts=True))),"qpoases bad",ref["n_bad"],"nwsr max",ref["nwsr"].max(),"iters max",interface.status_iters(status).max(),"act max",interface.status_nactive(status).max(),"max err(ok)",err[ok].max() if ok.any() else None, "n err>1e-4", int((err[ok]>1e-4).sum()), "max err(relaxed)", err[rel].max() if rel.any() else None)
+
+
+def hard3(nb, seed, scale):
+    f = synthetic.make_batch3(nb, 10, "standing", seed=seed, phase="random", hand="window")
+    g = hard_batch(nb, 10, "standing", seed, scale)
+    for k in ("q", "v", "w", "joint_angles", "traj"):
+        f[k] = g[k]
+    return f
+
+
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+cases = [("standing", 10, 2), ("walking", 10, 2), ("mixed", 10, 2), ("single", 20, 2), ("standing", 16, 2), ("standing", 20, 2), ("3contact", 10, 3)]
+for gait, h, nc in cases:
+    for scale in (1, 3, 6, 10):
+        f = hard3(nb, 19, scale) if nc == 3 else hard_batch(nb, h, gait, 17, scale)
+        rec = records.pack_records(f, h, nc)
+        mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb, contacts=nc)
+        mpc.set_auto_resolve(False)
+        mpc.upload(rec)
+        mpc.solve()
+        _, status0 = mpc.download()
+        nres = mpc.resolve_failed()
+        forces, status = mpc.download()
+        mpc.close()
+        code = interface.status_code(status)
+        ref = pool.solve_records_parallel(rec, h, synthetic.DT_MPC, synthetic.F_MAX, nc=nc)
+        ok = (code == 0) | (code == 6)
+        rel = code == 6
+        q = ref["q_soln"]
+        err = np.abs(forces - q).max(axis=1) / np.maximum(1, np.abs(q).max(axis=1))
+        cnt = lambda c: {int(k): int(v) for k, v in zip(*np.unique(c, return_counts=True))}
+        print(f"{gait:9s} h={h:2d} x{scale:<2d} fast {cnt(interface.status_code(status0))} re-solved {nres} final {cnt(code)} "
+              f"qpOASES bad {ref['n_bad']} nWSR max {ref['nwsr'].max()} |W| max {interface.status_nactive(status).max()} "
+              f"err(ok) max {err[ok].max() if ok.any() else 0:.1e} err(relaxed) max {err[rel].max() if rel.any() else 0:.1e}", flush=True)

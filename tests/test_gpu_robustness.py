@@ -26,8 +26,14 @@ def hard_batch(nb, h, gait, seed, scale):
 
 
 @pytest.mark.parametrize("gait,h,scale,min_ok", [("standing", 10, 3, 1.0), ("walking", 10, 3, 1.0), ("single", 20, 3, 1.0),
-                                                  ("standing", 10, 6, 0.99), ("single", 20, 6, 0.99)])
+                                                  ("standing", 10, 6, 1.0), ("single", 20, 6, 1.0), ("walking", 10, 10, 1.0),
+                                                  ("standing", 10, 10, 1.0), ("single", 20, 10, 1.0)])
 def test_hard_inputs(oracle, gait, h, scale, min_ok):
+    """1x .. 10x the nominal input ranges (10x: +-1 rad of tilt, +-5 rad/s): "solved" here <=> solved by qpOASES.  Since round 4
+    the safe pass rebuilds E every 48 working-set changes (its round-off used to add up over the 300-470 changes such inputs
+    take -- a run ended 3.5 N off its constraints with every multiplier looking fine), the final check also holds the working
+    set's rows to their bounds, and a relaxed last-resort pass ends with an exact re-solve on its working set: every instance
+    is HMPC_S_OK, exact."""
     nb = 192
     rec = records.pack_records(hard_batch(nb, h, gait, 17, scale), h)
     mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb)
@@ -41,8 +47,7 @@ def test_hard_inputs(oracle, gait, h, scale, min_ok):
     mpc.close()
     code = interface.status_code(status)
     ok = (code == 0) | (code == 6)  # 6 = solved with bounds relaxed by <= 2e-6 (hmpc_status_code HMPC_S_OK_RELAXED)
-    if scale <= 3:
-        assert (code == 0).all()
+    assert (code == 0).all(), np.unique(code, return_counts=True)  # exact: not even HMPC_S_OK_RELAXED
     assert ok.mean() >= min_ok, (ok.mean(), np.unique(interface.status_code(status), return_counts=True))
     if scale >= 6:
         assert n_flagged > 0  # the regime really exercises the safe pass
@@ -96,11 +101,15 @@ def test_device_side_safe_pass_equals_the_host_driven_one(gait, h):
     a.set_auto_resolve(True)
     f_host, st_host = a.download()
     a.close()
-    exact = interface.status_code(st_host) == 0
+    # what the safe variant itself solves is the same bits either way; the few instances that also need the host-driven
+    # last-resort passes (perturbed bounds + exact re-solve: exact on the host side since round 4) stay flagged on the device
+    exact = (interface.status_code(st_host) == 0) & (interface.status_code(st_dev) == 0)
+    assert (interface.status_code(st_host) == 0).all()
+    assert exact.sum() >= nb - 8 and exact.sum() >= (interface.status_code(st_fast) == 0).sum() + n_flagged - 8
     np.testing.assert_array_equal(st_dev[exact], st_host[exact])
     np.testing.assert_array_equal(f_dev[exact].view(np.uint32), f_host[exact].view(np.uint32))
     assert (interface.status_code(st_dev) != 5).all()
-    assert (interface.status_code(st_dev)[~exact] != 0).all()
+    assert np.isin(interface.status_code(st_dev)[~exact], (1, 4)).all()  # flagged (max-iter / KKT), never silently wrong
     # a nominal batch: nothing flagged, same bits with and without the extra (empty) launch
     rec2 = records.pack_records(synthetic.make_batch(nb, h, gait, seed=3, phase="random"), h)
     outs = []
@@ -124,10 +133,10 @@ def _hard3(nb, seed, scale):
     return f
 
 
-@pytest.mark.parametrize("scale,min_ok", [(3, 0.99), (6, 0.95)])
+@pytest.mark.parametrize("scale,min_ok", [(3, 1.0), (6, 1.0), (10, 1.0)])
 def test_hard_inputs_three_contacts(oracle, scale, min_ok):
-    """The three-contact variant (256 threads, two register blocks per thread, working set 96 rows, safe pass 140) outside the
-    nominal ranges: whatever is reported ok matches qpOASES, everything else is flagged."""
+    """The three-contact variant (256 threads, two register blocks per thread, working set 96 rows; safe pass 140 rows in LDS,
+    then 180 with E in global memory) outside the nominal ranges: every instance solved, exactly as qpOASES solves it."""
     nb = 128
     rec = records.pack_records(_hard3(nb, 19, scale), 10, 3)
     mpc = interface.BatchedMPC(synthetic.DT_MPC, 10, synthetic.F_MAX, nb, contacts=3)
@@ -144,9 +153,11 @@ def test_hard_inputs_three_contacts(oracle, scale, min_ok):
     assert ref["n_bad"] == 0 and err[ok].max() < 1e-4
 
 
-@pytest.mark.parametrize("h,scale,min_ok", [(20, 3, 0.99), (16, 6, 0.9)])
+@pytest.mark.parametrize("h,scale,min_ok", [(20, 3, 1.0), (16, 6, 1.0), (20, 6, 1.0), (16, 10, 1.0)])
 def test_hard_inputs_wide_variant(oracle, h, scale, min_ok):
-    """Double support over more than ten steps (wide variant, working set 152 rows) outside the nominal ranges."""
+    """Double support over more than ten steps (wide variant, working set 152 rows) outside the nominal ranges: instances that
+    outgrow the working set go to the safe pass whose packed Schur inverse lives in global memory (240 rows: cannot overflow;
+    VERDICT round 3 item 4) -- 100 % solved where round 3 accepted 1 % / 10 % flagged."""
     nb = 64
     rec = records.pack_records(hard_batch(nb, h, "standing", 29, scale), h)
     mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb)
