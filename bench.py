@@ -142,7 +142,7 @@ def cpu_baseline(fields: dict, horizon: int, per_core: int) -> dict:
 
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "fields.npz")
-        per_sweep = max(8, min(per_core, 48))
+        per_sweep = max(8, min(per_core, 128))  # (0.3-0.4 s of solves per process: shorter samples were dominated by start-up noise)
         n_saved = min(nb, max(total, 32 * per_sweep))
         np.savez(path, **{k: np.asarray(v)[:n_saved] for k, v in fields.items()})
         # P = 1: one process alone on the box (the reference's own operating point: one controller, one core)

@@ -99,10 +99,15 @@ enum hmpc_status_code {
   HMPC_S_INFEASIBLE = 2,  /* constraints inconsistent */
   HMPC_S_TOO_LARGE = 3,   /* more reduced variables than the variant the batch was launched with holds (only when
                              hmpc_set_max_reduced_vars named a smaller size than the batch really contains) */
-  HMPC_S_KKT = 4,         /* final KKT check outside tolerance */
-  HMPC_S_WORKSET = 5,     /* more simultaneously active constraints than the fast variant's on-chip working set holds (64 rows; 96 with three contacts, 152 in the wide variant; the safe pass holds as many as there are variables -- except for the wide variant, which LDS leaves no room to grow) */
-  HMPC_S_OK_RELAXED = 6   /* solved, but only after every bound was moved outward by <= 2e-6 (relative for the Fz cap):
-                             the last-resort pass of hmpc_resolve_failed for instances cycling at a degenerate vertex */
+  HMPC_S_KKT = 4,         /* final KKT check outside tolerance (rows outside the working set, the residual of the rows in it,
+                             multiplier signs; relative to the force scale) */
+  HMPC_S_WORKSET = 5,     /* more simultaneously active constraints than the FAST variant's on-chip working set holds (64 rows; 96
+                             with three contacts, 152 in the wide variant).  The safe pass holds as many rows as there are
+                             variables -- in LDS for 120 variables, in global memory for 180 / 240 -- and cannot overflow */
+  HMPC_S_OK_RELAXED = 6   /* solved only after every bound was moved outward by <= 2e-5 (relative for the Fz cap) AND the exact
+                             re-solve on the working set so found did not pass the exact KKT check: the last-resort pass of
+                             hmpc_resolve_failed for instances cycling at a degenerate vertex.  (When the exact re-solve passes --
+                             every case seen up to 10x the nominal input ranges -- the instance is HMPC_S_OK, exact.) */
 };
 
 size_t hmpc_record_stride(int horizon);  /* bytes per packed record: (54+12h)*4 + 2h rounded up to 16 */
@@ -163,8 +168,13 @@ int hmpc_set_tick_warm_start(hmpc_handle *h, int on, int horizon_shift);
 int hmpc_reset_tick_warm_start(hmpc_handle *h);
 /* Safe pass: waits for the last solve, then re-solves every instance whose status is working-set-full / max-iter /
  * infeasible / KKT with the large-working-set kernel variant (capacity = number of variables: cannot overflow; cold
- * start) and overwrites its forces and status in place.  *n_resolved (may be NULL) = how many were re-solved.
- * hmpc_download does this automatically unless hmpc_set_auto_resolve(h, 0). */
+ * start; the Schur inverse is rebuilt from scratch every 48 working-set changes, so that hundreds of them do not add up
+ * round-off) and overwrites its forces and status in place.  Instances still flagged after that get up to three
+ * last-resort passes with every bound moved outward by 1e-7, 1e-6, 1e-5 (a different amount per row: separates
+ * coinciding vertices), each ending with an exact re-solve on the working set it found -- HMPC_S_OK when that passes the
+ * exact KKT check, HMPC_S_OK_RELAXED otherwise.  Measured at 1x .. 10x the nominal input ranges (scripts/stress.py,
+ * profiles/r04/stress.txt): every instance qpOASES solves ends HMPC_S_OK.  *n_resolved (may be NULL) = how many were
+ * re-solved.  hmpc_download does this automatically unless hmpc_set_auto_resolve(h, 0). */
 int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved);
 /* Cap on the active-set iterations of every later solve of the handle -- the analogue of the reference's nWSR = 500
  * (SolverMPC.cpp:706).  0 (default) = the kernel variant's own bound.  Block rounds and switch passes of the block start
