@@ -23,10 +23,25 @@ run() {  # name, compiler driver mode, source, args...
   echo "== $name $* -> exit $rc"
   [ $rc -eq 0 ] || fail=1
 }
-run host_api_sweep "-x c -std=c11" tests/src/host_api_sweep.c
+# (round 4: with twelve kernel variants in the code object the sanitizer runtime's own exit-time CHECK described below for the
+#  RCCL case also fires for this program; same rule: its result line + no sanitizer report of ours = clean)
+tolerant() {  # name, expected result line, compile/run arguments of run()...
+  local name=$1 want=$2; shift 2
+  local prev=$fail
+  run $name "$@" > $OUT/$name.log 2>&1
+  cat $OUT/$name.log | grep -v "^    #"
+  if grep -q "$want" $OUT/$name.log && ! grep -E "ERROR: AddressSanitizer|runtime error:" $OUT/$name.log > /dev/null; then
+    if grep -q "sanitizer_allocator_device.h" $OUT/$name.log; then
+      echo "== $name: program completed with the expected result; the sanitizer runtime's own exit-time CHECK (above) is not counted"
+      fail=$prev
+    fi
+  fi
+}
+tolerant host_api_sweep "host API sweep ok" "-x c -std=c11" tests/src/host_api_sweep.c
 run legacy_tick "-x c++ -std=c++17" examples/legacy_tick.cpp
 run batched "-x c -std=c11" examples/batched.c
 run batched_multi "-x c -std=c11" examples/batched_multi.c 3 p2p
+run batched_multi_3contact "-x c -std=c11" examples/batched_multi.c 4 p2p 3
 # The RCCL transport (group of one).  Since round 3 this build of ROCm's ASan runtime trips over one of ITS OWN internal
 # checks while the process exits -- "sanitizer_allocator_device.h:125 CHECK failed: !dev_runtime_unloaded_", raised under
 # __cxa_finalize -> libamdhip64 -> libhsa-runtime64 with no frame of this library -- whenever librccl is loaded next to the

@@ -1,7 +1,8 @@
 /* Host-side API sweep in plain C (tests/test_examples.py; also run under AddressSanitizer + UBSan by
  * scripts/sanitize_host.sh): every batched entry point of include/hector_mpc.h at least once,
  * including the argument-error paths, an empty batch, the host-pointer convenience calls that use the handle's scratch,
- * the safe pass, the binary64 copy-out enabled before and after a solve, tick-to-tick warm start and a device group.
+ * the safe pass, the binary64 copy-out enabled before and after a solve, tick-to-tick warm start, a device group, and (round 4)
+ * the iteration cap, the wide variant's global-memory safe pass on hard inputs and a group of three-contact handles.
  * Exit code 0 = every call behaved as documented. */
 #include <math.h>
 #include <stdio.h>
@@ -157,6 +158,24 @@ int main(void) {
     free(Hx), free(gx), free(Fx), free(Hk);
   }
 
+  /* round 4: the iteration cap (update_solver_settings' max_iter for the batched interface) and the one-call tick entry */
+  CHECK(hmpc_set_max_iterations(NULL, 1) == HMPC_E_ARG && hmpc_set_max_iterations(h, -1) == HMPC_E_ARG);
+  make_records(recs, stride, 0.05);
+  CHECK(hmpc_upload_records(h, recs, N) == HMPC_OK && hmpc_set_max_iterations(h, 1) == HMPC_OK);
+  CHECK(hmpc_solve(h, NULL) == HMPC_OK && hmpc_download(h, forces, st) == HMPC_OK);
+  {
+    int capped = 0;
+    for (int k = 0; k < N; ++k) {
+      CHECK(HMPC_STATUS_CODE(st[k]) == HMPC_S_OK || HMPC_STATUS_CODE(st[k]) == HMPC_S_MAXITER);
+      capped += HMPC_STATUS_CODE(st[k]) == HMPC_S_MAXITER;
+    }
+    CHECK(capped > 0); /* ... and the safe pass of hmpc_download left the caller's cap alone */
+  }
+  CHECK(hmpc_set_max_iterations(h, 0) == HMPC_OK && hmpc_solve(h, NULL) == HMPC_OK && hmpc_download(h, forces, st) == HMPC_OK);
+  for (int k = 0; k < N; ++k) CHECK(HMPC_STATUS_CODE(st[k]) == HMPC_S_OK);
+  CHECK(hmpc_tick_solve_device(h, NULL, N, 0.04, NULL, NULL, NULL, NULL) == HMPC_E_ARG);
+  CHECK(hmpc_tick_solve_device(NULL, ticks, N, 0.04, NULL, NULL, tau, NULL) == HMPC_E_ARG);
+
   /* parity hook */
   int n = 0, m = 0;
   CHECK(hmpc_debug_assemble(h, 0, &n, &m, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL) == HMPC_OK && n > 0 && m > 0);
@@ -184,7 +203,67 @@ int main(void) {
   CHECK(hmpc_group_upload_records(g, recs, 0) == HMPC_OK && hmpc_group_solve(g) == HMPC_OK && hmpc_group_gather_wrench(g, wrench, st) == HMPC_OK);
   CHECK(hmpc_group_synchronize(g) == HMPC_OK && hmpc_group_destroy(g) == HMPC_OK);
 
+  /* round 4: double support over h = 20 far outside the nominal ranges -- instances that outgrow the wide variant's working set
+   * go through the safe pass whose packed Schur inverse lives in global memory (scratch grown on demand inside hmpc_download) */
+  {
+    enum { H2 = 20, N2 = 24 };
+    struct problem_setup ps2 = {0.04f, 0.25f, 500.f, H2};
+    hmpc_handle *hw = NULL;
+    CHECK(hmpc_create(&hw, &ps2, N2, 0) == HMPC_OK);
+    const size_t st2 = hmpc_record_stride(H2);
+    unsigned char *r2 = (unsigned char *)calloc(N2, st2);
+    double Q[12] = {100, 100, 250, 200, 200, 300, 1, 1, 1, 1, 1, 1};
+    double A[12] = {1e-4, 1e-4, 5e-4, 1e-4, 1e-4, 5e-4, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2};
+    for (int k = 0; k < N2; ++k) {
+      double tl = 0.9 * sin(1.1 * k + 0.3), p[3] = {0, 0, 0.55}, v[3] = {1.5 * cos(0.4 * k), 1.2 * sin(0.9 * k), 0.4}, w[3] = {3.0 * tl, -2.5 * tl, 2.0 * cos(k)};
+      double q[4] = {cos(tl / 2), sin(tl / 2), 0, 0}, r[6] = {0.05, -0.04, 0.06, -0.06, -0.55, -0.55}, ja[10] = {0}, traj[12 * H2] = {0};
+      int gait[2 * H2];
+      for (int i = 0; i < H2; ++i) traj[12 * i + 5] = 0.55, traj[12 * i + 9] = 2.0 * sin(k), gait[2 * i] = gait[2 * i + 1] = 1;
+      CHECK(hmpc_pack_record(r2 + k * st2, H2, p, v, q, w, r, ja, 0.0, Q, traj, A, gait) == HMPC_OK);
+    }
+    float *f2 = (float *)calloc((size_t)N2 * 12 * H2, sizeof(float));
+    uint32_t *s2 = (uint32_t *)calloc(N2, sizeof(uint32_t));
+    CHECK(hmpc_upload_records(hw, r2, N2) == HMPC_OK && hmpc_set_auto_resolve(hw, 0) == HMPC_OK);
+    CHECK(hmpc_solve(hw, NULL) == HMPC_OK && hmpc_download(hw, f2, s2) == HMPC_OK);
+    int flagged = 0, nres = -1, left = 0;
+    for (int k = 0; k < N2; ++k) flagged += HMPC_STATUS_CODE(s2[k]) != HMPC_S_OK;
+    CHECK(hmpc_resolve_failed(hw, &nres) == HMPC_OK && nres == flagged && hmpc_download(hw, f2, s2) == HMPC_OK);
+    for (int k = 0; k < N2; ++k) {
+      CHECK(HMPC_STATUS_CODE(s2[k]) != HMPC_S_WORKSET && HMPC_STATUS_CODE(s2[k]) != HMPC_S_TOO_LARGE);
+      left += HMPC_STATUS_CODE(s2[k]) != HMPC_S_OK && HMPC_STATUS_CODE(s2[k]) != HMPC_S_OK_RELAXED;
+    }
+    printf("wide variant, hard inputs: %d of %d flagged by the fast pass, %d left after the safe pass\n", flagged, N2, left);
+    CHECK(hmpc_destroy(hw) == HMPC_OK);
+    free(r2), free(f2), free(s2);
+  }
+
+  /* round 4: a group of three-contact handles (BASELINE config 5's split): 18 step-0 values + status per instance */
+  {
+    hmpc_group *g3 = NULL;
+    int d2[2] = {0, 0};
+    CHECK(hmpc_group_create_ex(&g3, &ps, d2, 2, N, HMPC_GROUP_P2P, 4) == HMPC_E_ARG);
+    CHECK(hmpc_group_create_ex(&g3, &ps, d2, 2, N, HMPC_GROUP_P2P, 3) == HMPC_OK && hmpc_group_contacts(g3) == 3);
+    const size_t s3 = hmpc_record_stride_ex(H, 3);
+    unsigned char *r3 = (unsigned char *)calloc(N, s3);
+    double Q[12] = {100, 100, 250, 200, 200, 300, 1, 1, 1, 1, 1, 1}, Rh[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double A3[18] = {1e-4, 1e-4, 5e-4, 1e-4, 1e-4, 5e-4, 1e-4, 1e-4, 5e-4, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2, 1e-2};
+    for (int k = 0; k < N; ++k) {
+      double vx = -0.5 + k * (1.0 / (N - 1)), p[3] = {0, 0, 0.55}, v[3] = {vx, 0, 0}, q[4] = {1, 0, 0, 0}, w[3] = {0, 0, 0};
+      double r9[9] = {0, 0, 0.25, 0.06, -0.06, -0.15, -0.55, -0.55, 0.10}, ja[10] = {0}, traj[12 * H] = {0};
+      int gait3[3 * H];
+      for (int i = 0; i < H; ++i) traj[12 * i + 5] = 0.55, traj[12 * i + 9] = vx, gait3[3 * i] = gait3[3 * i + 1] = 1, gait3[3 * i + 2] = (i + k) % H < 6;
+      CHECK(hmpc_pack_record_ex(r3 + k * s3, H, 3, p, v, q, w, r9, ja, 0.0, Q, traj, A3, gait3, Rh, 100.0) == HMPC_OK);
+    }
+    float *w3 = (float *)calloc((size_t)18 * N, sizeof(float)), *f3 = (float *)calloc((size_t)N * 18 * H, sizeof(float));
+    CHECK(hmpc_group_upload_records(g3, r3, N) == HMPC_OK && hmpc_group_solve(g3) == HMPC_OK);
+    CHECK(hmpc_group_gather_wrench(g3, w3, st) == HMPC_OK && hmpc_group_download(g3, f3, NULL) == HMPC_OK);
+    for (int k = 0; k < N; ++k) CHECK(HMPC_STATUS_CODE(st[k]) == HMPC_S_OK && memcmp(w3 + 18 * k, f3 + (size_t)18 * H * k, 72) == 0);
+    CHECK(hmpc_group_destroy(g3) == HMPC_OK);
+    free(r3), free(w3), free(f3);
+  }
+
   free(recs), free(forces), free(forces2), free(st), free(x64), free(obj), free(ticks), free(wpd), free(rb), free(lq), free(fff), free(tau), free(wrench);
   printf("host API sweep ok\n");
+  fflush(stdout); /* (so that the line survives a tool that aborts the process during runtime teardown, e.g. a sanitizer) */
   return 0;
 }
