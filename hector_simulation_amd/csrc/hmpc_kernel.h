@@ -165,6 +165,11 @@ struct Smem {
   double sc7[NG];        // ... and the unit scale of that row: 1/ub7 where ub7 > 1 (read where used: not a live register pair)
   unsigned char vstep[NMAX], vcomp[NMAX];  // reference-order reduced variable -> horizon step, component (0..11)
   unsigned char o2s[NMAX], s2o[NMAX];      // reference order <-> sweep order (leg-step major)
+  unsigned short sinfo[NMAX];              // sweep-order variable -> horizon step | component << 8 (loader of the matrix-core sweeps)
+  // matrix-core sweeps: power-of-two diagonal scaling, H~ = 2^k H 2^k with k_i = -floor(log2(H_ii) / 2) -- exact in binary
+  // floating point in both directions (H_ii spans 2e-4 .. 500; the 4 x 4 pivot blocks of the scaled matrix are far better
+  // conditioned than the raw ones, which is what the explicitly inverted pivot block needs)
+  signed char kexp[(NMAX == 120 && NT == 256 && BPT == 1 && NC == 2) ? NMAX + 8 : 1];
   unsigned char rmap[U * HMAX];            // original variable U*step+comp -> sweep index (255 = eliminated)
   unsigned char ls_leg[NG], ls_step[NG];
   int n, m, nls, pad0;
@@ -319,6 +324,9 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #ifndef HMPC_EPT_3C
 #define HMPC_EPT_3C 7            // three-contact variant on 256 threads: packed-triangle entries per thread in the block start
 #endif
+#ifndef HMPC_MFMA_SWEEP
+#define HMPC_MFMA_SWEEP 1  // 120-variable / 256-thread variants: stage S as 4 x 4 block pivots on v_mfma_f64_16x16x4_f64 (0: scalar sweeps)
+#endif
 #ifndef HMPC_BLOCK_FRICTION
 #define HMPC_BLOCK_FRICTION 1  // block start also takes friction rows violated at the unconstrained minimiser
 #endif
@@ -344,6 +352,304 @@ struct LazyInt {
 template <bool LAZY, class F>
 __device__ __forceinline__ LazyInt<LAZY, F> lazy_int(F f) {
   return LazyInt<LAZY, F>{LAZY ? 0 : f((int)threadIdx.x), f};
+}
+
+// ================================================================================================================
+// Stage S on the binary64 matrix cores (round 4; the 120-variable / 256-thread variants).
+//
+// M = H^-1 by symmetric Gauss-Jordan sweeps with 4 x 4 BLOCK pivots: for the pivot set K (four consecutive variables),
+//     D = A_KK;   A_KK <- -D^-1;   A_Kj <- D^-1 A_Kj;   A_iK <- A_iK D^-1;   A_ij <- A_ij - A_iK D^-1 A_Kj      (after n/4 steps A = -H^-1)
+// so that the update of the whole matrix is ONE rank-4 product per step -- v_mfma_f64_16x16x4_f64 on 16 x 16 tiles.  The
+// symmetric matrix lives in the accumulator registers as its 36 upper-triangle tiles (128 x 128 with identity padding), nine
+// tiles = 72 VGPRs per lane, exactly the footprint of the scalar sweeps' 6 x 6 block.  As in the scalar sweeps the rows and
+// columns of K take the same fused update with substituted multipliers: the published pivot panel P = A_K,: carries D - I in
+// the columns of K, then  A_Kj - (I - D^-1) A_Kj = D^-1 A_Kj,  A_iK - A_iK D^-1 (D - I) = A_iK D^-1,  and the pivot block comes
+// out as 2I - D^-1: its diagonal is patched by -2.
+// Per step: the wave that owns the pivot's diagonal tile publishes the panel rows AND the inverse of the 4 x 4 pivot block
+// (rows of D^-1 by LDL' in pivot order: backward stable for the positive definite block); after the barrier every lane forms its A operand
+// -(D^-1 P)[g][16 I + c] (four multiply-adds per tile row), reads its B operand P[g][16 J + c] and issues nine matrix
+// instructions; tiles that hold the next panel publish it.  One barrier per step, 30 steps for 120 variables instead of 120.
+// The code is specialised per wave (WV is a template parameter): tile coordinates are compile-time constants, LDS addresses
+// immediate offsets, and the pivot's tile row is dispatched by ONE computed jump per step -- conditional tests per tile cost
+// more than the arithmetic (scripts/micro/sweep_mfma64.hip has the stand-alone measurements: 78 k cycles per workgroup at three
+// per CU against 122 k for the scalar sweeps, once the workgroups are out of lockstep as they are in this kernel).
+// In the product kernel (profiles/r04/phase_cycles.txt): stage S -- tile load, sweeps, hand-over -- 108 k against 123 k + 3.5 k of
+// block loading, but the workgroups sharing the SIMDs slow down by ~15 % in their latency-bound phases (a binary64 matrix
+// instruction holds the double-precision pipe for 64 cycles at a time; wave priorities do not change that): +1.3 % end to
+// end on the 2-contact h = 10 workload, +5 % at h = 20.
+// Precision: an explicitly inverted 4 x 4 pivot block carries cond(D) into the update, which sequential scalar pivots do not --
+// unscaled, forces came out up to 6e-5 from qpOASES at 10x the nominal input ranges (7e-8 with scalar pivots).  H_ii spans
+// 2e-4 .. 500, so the matrix is scaled first: H~ = 2^k H 2^k, k_i = -floor(log2 H_ii / 2) -- powers of two, exact in both
+// directions -- which brings the 10x case back to 1.5e-7 and leaves nominal inputs where they were (5.7e-8).  The pivot block
+// itself is factorised by LDL' in pivot order (closed-form 2 x 2 determinants lost another two digits) from its raw entries
+// (not recovered from the panel's D - I).
+// Afterwards M is handed to the rest of the kernel in the layout everything downstream is built on -- one 6 x 6 leg-step
+// block per thread -- through three passes over an LDS staging area (rows of M in chunks of 42).
+typedef double hmpc_d4 __attribute__((ext_vector_type(4)));
+
+constexpr int mfs_tile_i(int t) {  // tile t (0..35, block-row-major over I <= J of the 8 x 8 tile grid) -> I
+  int i = 0, base = 0;
+  while (t >= base + (8 - i)) base += 8 - i, ++i;
+  return i;
+}
+constexpr int mfs_tile_j(int t) {
+  int i = 0, base = 0;
+  while (t >= base + (8 - i)) base += 8 - i, ++i;
+  return i + (t - base);
+}
+template <int WV>
+struct MfsTiles {  // wave WV owns tiles 9 WV .. 9 WV + 8: at most four distinct tile rows
+  int i[9], j[9];
+  constexpr MfsTiles() : i{}, j{} {
+    for (int t = 0; t < 9; ++t) i[t] = mfs_tile_i(9 * WV + t), j[t] = mfs_tile_j(9 * WV + t);
+  }
+};
+constexpr int MFS_PST = 144;  // panel row stride in doubles (= 128 mod 256 bytes: the four rows of a read hit different banks)
+struct MfsPanel {
+  double P[2][4][MFS_PST];  // pivot panel rows, double buffered; the K columns carry D - I
+  double Dinv[2][4][4];     // inverse of the pivot block
+  double Draw[4][4];        // the pivot block itself, as it is (recovering D from the panel's D - I would cost the small pivots --
+                            // down to 1e-4 -- three digits; the scalar sweeps pass d beside the row for the same reason)
+};
+
+// hinfo(i): what the staging needs to know about sweep-order variable i (one LDS read); hval(hinfo(i), hinfo(j)): H(i, j) from
+// the binary32 staging, symmetric in its arguments.  stage: LDS area of stage_doubles doubles that
+// nothing else uses until the function returns (the solver state that will live there is initialised afterwards).
+template <int WV, int NT, class HInfo, class HVal>
+__device__ __forceinline__ void mfma_sweeps(MfsPanel &PN, double *stage, const int stage_doubles, const int n, HInfo hinfo, HVal hval,
+                                            signed char *kexp, const int e0, const int e1, const bool live, double (&a)[GS][GS]) {
+  constexpr MfsTiles<WV> T;
+  constexpr int TPW = 9, PST = MFS_PST;
+  const int tid = threadIdx.x, ln = tid & 63, g = ln >> 4, c = ln & 15;
+  // power-of-two Jacobi scaling: k_i from the exponent of H_ii (the staging holds binary32 values: exponent field bits 23-30)
+  if (tid < 128) {
+    int k = 0;
+    if (tid < n) {
+      const int inf = hinfo(tid);
+      const int ex = (int)((__float_as_uint(hval(inf, inf)) >> 23) & 255u) - 127;  // floor(log2(H_ii)), H_ii > 0
+      k = -(ex >> 1);
+    }
+    kexp[tid] = (signed char)k;
+  }
+  __syncthreads();
+  hmpc_d4 acc[TPW];
+  {
+    // Tiles from the binary32 staging of H.  Two rounds of LDS reads, each issued back to back: first what the lane's four
+    // rows per tile row and its one column per tile ARE (horizon step and component, or the reference-order index), then the
+    // 36 entries themselves; the address arithmetic in between is branch-free.
+    int cinf[TPW], rinf[TPW][4];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int j = 16 * T.j[t] + c;
+      cinf[t] = hinfo(j < n ? j : 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (t == 0 || T.i[t] != T.i[t - 1]) {  // compile time
+          const int i = 16 * T.i[t] + g + 4 * r;
+          rinf[t][r] = hinfo(i < n ? i : 0);
+        } else {
+          rinf[t][r] = rinf[t - 1][r];
+        }
+      }
+    }
+    float hv[TPW][4];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#ifdef HMPC_MFS_NO_LOAD  // developer switch (timing)
+        hv[t][r] = 0.0f;
+#else
+        hv[t][r] = hval(rinf[t][r], cinf[t]);  // (symmetric in its arguments: the lower half of a diagonal tile reads the mirror)
+#endif
+      }
+    // scaled while still binary32: two multiplications by powers of two (exact; |H| <= 1e3 and |k| <= 12 keep clear of the
+    // binary32 range on both sides), the row factors shared by the tiles of a tile row
+    float srow[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int j = 16 * T.j[t] + c;
+      const float scol = __uint_as_float((unsigned)(127 + (int)kexp[j]) << 23);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * T.i[t] + g + 4 * r;
+        if (t == 0 || T.i[t] != T.i[t - 1]) srow[r] = __uint_as_float((unsigned)(127 + (int)kexp[i]) << 23);  // compile time
+        acc[t][r] = (i < n && j < n) ? (double)((hv[t][r] * srow[r]) * scol) : ((i == j) ? 1.0 : 0.0);  // identity padding
+      }
+    }
+  }
+  __syncthreads();  // every tile is loaded before the panel (which aliases the staging of H) is written
+  auto pick = [&](const hmpc_d4 &v, int rr) __attribute__((always_inline)) -> double {  // rr uniform
+    const double lo = (rr & 1) ? v[1] : v[0], hi = (rr & 1) ? v[3] : v[2];
+    return (rr & 2) ? hi : lo;
+  };
+  auto rcp1 = [](double d) __attribute__((always_inline)) -> double {  // v_rcp_f64 (2^-24) + two Newton steps: last bit
+    double r = __builtin_amdgcn_rcp(d);
+    r = dfma(dfma(-d, r, 1.0), r, r);
+    return dfma(dfma(-d, r, 1.0), r, r);
+  };
+  // row g of D^-1 for the pivot block just published
+  auto publish_dinv = [&](const int s) __attribute__((always_inline)) {
+    // x = D^-1 e_g by LDL' with the four pivots taken in order -- for a positive definite block that is backward stable, where
+    // closed-form 2 x 2 determinants lose cond(D) eps to cancellation (seen at 10x the nominal input ranges: forces 1e-4 off)
+    const double(*D)[4] = PN.Draw;
+    const double d00 = D[0][0], d10 = D[1][0], d20 = D[2][0], d30 = D[3][0];
+    const double d11 = D[1][1], d21 = D[2][1], d31 = D[3][1], d22 = D[2][2], d32 = D[3][2], d33 = D[3][3];
+    const double i0 = rcp1(d00);
+    const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+    const double e1 = dfma(-l10, d10, d11), i1 = rcp1(e1);
+    const double m21 = dfma(-l20, d10, d21), m31 = dfma(-l30, d10, d31);
+    const double l21 = m21 * i1, l31 = m31 * i1;
+    const double e2 = dfma(-l21, m21, dfma(-l20, d20, d22)), i2 = rcp1(e2);
+    const double m32 = dfma(-l31, m21, dfma(-l30, d20, d32));
+    const double l32 = m32 * i2;
+    const double e3 = dfma(-l32, m32, dfma(-l31, m31, dfma(-l30, d30, d33))), i3 = rcp1(e3);
+    double y0 = (g == 0) ? 1.0 : 0.0, y1 = (g == 1) ? 1.0 : 0.0, y2 = (g == 2) ? 1.0 : 0.0, y3 = (g == 3) ? 1.0 : 0.0;
+    y1 = dfma(-l10, y0, y1);
+    y2 = dfma(-l21, y1, dfma(-l20, y0, y2));
+    y3 = dfma(-l32, y2, dfma(-l31, y1, dfma(-l30, y0, y3)));
+    const double x3 = y3 * i3;
+    const double x2 = dfma(-l32, x3, y2 * i2);
+    const double x1 = dfma(-l31, x3, dfma(-l21, x2, y1 * i1));
+    const double x0 = dfma(-l30, x3, dfma(-l20, x2, dfma(-l10, x1, y0 * i0)));
+    if (c == 0) {
+      double *dst = PN.Dinv[s & 1][g];
+      dst[0] = x0, dst[1] = x1, dst[2] = x2, dst[3] = x3;
+    }
+  };
+  // panel of step s from the accumulators (rr = s % 4):
+  //   row tiles (Ik, J):      lane (g, c) holds A[16 Ik + 4 rr + g][16 J + c] in register rr
+  //   column tiles (I < Ik):  lanes with c in [4 rr, 4 rr + 4) hold A[16 I + g + 4 r][16 Ik + c], r = 0..3
+  auto publish_ik = [&](auto ikc, const int s, const int rr) __attribute__((always_inline)) {
+    constexpr int IK = decltype(ikc)::value;
+    const int c0 = 4 * rr;
+    double(*P)[PST] = PN.P[s & 1];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      if (T.i[t] == IK) {  // compile time
+        double v = pick(acc[t], rr);
+        if (T.j[t] == IK) {
+          if (c >= c0 && c < c0 + 4) PN.Draw[g][c - c0] = v;
+          v -= (c == c0 + g) ? 1.0 : 0.0;
+        }
+        P[g][16 * T.j[t] + c] = v;
+        if (T.j[t] == IK) {  // this wave owns the pivot block: its own LDS writes are visible to it after a wait
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          publish_dinv(s);
+        }
+      } else if (T.j[t] == IK) {
+        if (c >= c0 && c < c0 + 4) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) P[c - c0][16 * T.i[t] + g + 4 * r] = acc[t][r];
+        }
+      }
+    }
+  };
+  auto publish = [&](const int s) __attribute__((always_inline)) {
+    const int rr = s & 3;
+    switch (s >> 2) {  // uniform: one computed jump
+      case 0: publish_ik(std::integral_constant<int, 0>(), s, rr); break;
+      case 1: publish_ik(std::integral_constant<int, 1>(), s, rr); break;
+      case 2: publish_ik(std::integral_constant<int, 2>(), s, rr); break;
+      case 3: publish_ik(std::integral_constant<int, 3>(), s, rr); break;
+      case 4: publish_ik(std::integral_constant<int, 4>(), s, rr); break;
+      case 5: publish_ik(std::integral_constant<int, 5>(), s, rr); break;
+      case 6: publish_ik(std::integral_constant<int, 6>(), s, rr); break;
+      default: publish_ik(std::integral_constant<int, 7>(), s, rr); break;
+    }
+  };
+  publish(0);
+  __syncthreads();
+#ifdef HMPC_MFS_NO_STEPS  // developer switch: tile load + re-layout only (timing)
+  const int nsteps = 0;
+#else
+  const int nsteps = (n + 3) >> 2;
+#endif
+#pragma unroll 1
+  for (int s = 0; s < nsteps; ++s) {
+    const int rr = s & 3, Ik = s >> 2;
+    const double(*P)[PST] = PN.P[s & 1];
+    const double x0 = PN.Dinv[s & 1][g][0], x1 = PN.Dinv[s & 1][g][1], x2 = PN.Dinv[s & 1][g][2], x3 = PN.Dinv[s & 1][g][3];
+    // tile(I,J) -= Q_I' P_J, Q = D^-1 P: A operand -Q[g][16 I + c], B operand P[g][16 J + c]; groups of three tiles, the
+    // operands of group k+1 read while the matrix instructions of group k run
+    constexpr int GT = 3, NGRP = TPW / GT;
+    double aop[2][GT], bop[2][GT];
+    double alast = 0.0;
+    auto fetch = [&](const int grp, double (&ao)[GT], double (&bo)[GT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < GT; ++u) {
+        const int t = grp * GT + u;
+        bo[u] = P[g][16 * T.j[t] + c];
+        if (t == 0 || T.i[t] != T.i[t - 1]) {  // compile time; the wave's tiles are sorted by I
+          const int m = 16 * T.i[t] + c;
+          alast = -dfma(x3, P[3][m], dfma(x2, P[2][m], dfma(x1, P[1][m], x0 * P[0][m])));
+        }
+        ao[u] = alast;
+      }
+    };
+    fetch(0, aop[0], bop[0]);
+#pragma unroll
+    for (int grp = 0; grp < NGRP; ++grp) {
+      if (grp + 1 < NGRP) fetch(grp + 1, aop[(grp + 1) & 1], bop[(grp + 1) & 1]);
+#pragma unroll
+      for (int u = 0; u < GT; ++u) {
+        const int t = grp * GT + u;
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[grp & 1][u], bop[grp & 1][u], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+      if (T.i[t] == T.j[t] && T.i[t] == Ik) {  // (first test compile time, second uniform): the pivot block's diagonal
+        asm volatile("");
+        const double two = (c == 4 * rr + g) ? 2.0 : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] -= (r == rr) ? two : 0.0;
+      }
+    if (s + 1 < nsteps) publish(s + 1);
+    __syncthreads();
+  }
+  // ---- M = -A into the 6 x 6 leg-step blocks: rows of M staged in chunks of 48 -- three tile rows = eight leg-steps, so that
+  // which tiles store in a pass is known at compile time and no block straddles a chunk -- with an odd row stride
+  constexpr int RC = 48, SST = 121;
+  // (callers guarantee stage_doubles >= RC * SST; columns >= 120 are padding and are not staged)
+#pragma unroll
+  for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < GS; ++jj) a[ii][jj] = 0.0;
+#ifndef HMPC_MFS_NO_RELAYOUT
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    if (RC * p < n) {  // uniform
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+        if (T.i[t] / 3 == p) {  // compile time
+          const int j = 16 * T.j[t] + c;
+          if (T.j[t] < 7 || c < 8) {  // (first test compile time)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[(16 * (T.i[t] - 3 * p) + g + 4 * r) * SST + j] = -acc[t][r];
+          }
+        }
+      __syncthreads();
+      if (live && (e0 >> 3) == p) {  // this thread's block lies in the chunk: rows 6 e0 .., columns 6 e1 ..
+        const double *rowp = stage + (GS * e0 - RC * p) * SST + GS * e1;
+        const bool dg = (e0 == e1);
+        int kr[GS], kc[GS];
+#pragma unroll
+        for (int k = 0; k < GS; ++k) kr[k] = (int)kexp[GS * e0 + k], kc[k] = (int)kexp[GS * e1 + k];
+#pragma unroll
+        for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < GS; ++jj) {
+            // off-diagonal blocks lie above the diagonal of M: staged as they are; a diagonal block takes its lower
+            // triangle from the mirror of the upper one (bit-identical halves, as the scalar path leaves them)
+            const int off = (ii > jj) ? (dg ? jj * SST + ii : ii * SST + jj) : ii * SST + jj;
+            a[ii][jj] = rowp[off] * __hiloint2double((1023 + kr[ii] + kc[jj]) << 20, 0);  // M = 2^k M~ 2^k (exact)
+          }
+      }
+      __syncthreads();
+    }
+  }
+#endif
 }
 
 // three waves per SIMD = 3 (256 threads) or 6 (128 threads) workgroups per CU: their LDS must fit the CU's 160 KB
@@ -634,6 +940,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
           S.vstep[oM] = (unsigned char)i, S.vcomp[oM] = (unsigned char)(3 * NC + 3 * leg + k);
           S.o2s[oF] = (unsigned char)(GS * e + k), S.s2o[GS * e + k] = (unsigned char)oF;
           S.o2s[oM] = (unsigned char)(GS * e + 3 + k), S.s2o[GS * e + 3 + k] = (unsigned char)oM;
+          S.sinfo[GS * e + k] = (unsigned short)(i | ((3 * leg + k) << 8));
+          S.sinfo[GS * e + 3 + k] = (unsigned short)(i | ((3 * NC + 3 * leg + k) << 8));
           S.rmap[U * i + 3 * leg + k] = (unsigned char)(GS * e + k);
           S.rmap[U * i + 3 * NC + 3 * leg + k] = (unsigned char)(GS * e + 3 + k);
           if (k == 0) {
@@ -751,6 +1059,12 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // ---- register blocks of the sweeps (stage S): thread t owns the 6x6 blocks number t, t + NT, ... (< NG(NG+1)/2) of the
   // symmetric matrix in sweep order, block-row-major: (e0, e1), e0 <= e1.  Declared here because the blocks are filled
   // straight from the staging area of H, pass by pass where that area holds only part of the block-diagonals at a time.
+  // Matrix-core sweeps: the FAST 120-variable variants only.  The safe-pass variants (working set = variable count) keep the
+  // scalar sweeps: 4 x 4 block pivots apply an explicitly inverted pivot block, whose forward error carries cond(D) -- at 10x
+  // the nominal input ranges that showed as forces up to 9e-5 from qpOASES in the safe pass (7e-8 with scalar pivots), while
+  // nominal inputs are unaffected (5.8e-8 either way) and whatever the fast variants get wrong beyond 2e-6 is caught by
+  // their KKT check and handed to the safe pass anyway.
+  constexpr bool MFMA_SWEEP = HMPC_MFMA_SWEEP && NMAX == 120 && NT == 256 && BPT == 1 && NC == 2 && !ASM_ONLY && QCAP != 0 && QCAP < NMAX;
   constexpr int NTILE = NG * (NG + 1) / 2;
   static_assert(NTILE <= BPT * NT && SM::MMAX <= NT && NMAX <= NT, "threads per block / constraint row / variable");
   // BPT == 1: plain registers.  BPT == 2 (256 VGPRs, 144 of them the two blocks): the coordinates of a slot travel PACKED in
@@ -960,7 +1274,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         }
       } else {
         if (hp == 0) own_blocks();
-        load_blocks(dlo, dhi);
+        if constexpr (!MFMA_SWEEP) load_blocks(dlo, dhi);  // (matrix-core sweeps: the staging is read into 16 x 16 tiles in stage S)
       }
       if (hp + 1 < SM::HSP) __syncthreads();  // the next pass overwrites the staging area
     }
@@ -1054,6 +1368,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     if constexpr (!ASM_ONLY) {
     own_blocks();
     // register blocks from the folded upper triangle over the reduced variables (reference order)
+    if constexpr (!MFMA_SWEEP)
 #pragma unroll
     for (int s = 0; s < BPT; ++s)
 #pragma unroll
@@ -1119,6 +1434,37 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // sweeps of a leg-step are statically unrolled (static register indices).
   const bool is_v = tid < n, is_c = tid < m;
   // (the register blocks were loaded from the staging area of H at the end of stage A5)
+  if constexpr (MFMA_SWEEP) {
+    // ---- matrix-core sweeps (mfma_sweeps above): tiles from the staging of H, 4 x 4 block pivots, M back in the 6 x 6 blocks
+    auto hinfo = [&](const int i) __attribute__((always_inline)) -> int {  // i < n, sweep order
+      if constexpr (SM::FULLBLK) return (int)S.sinfo[i];  // horizon step | component << 8
+      else return (int)S.s2o[i];                          // reference-order index
+    };
+    auto hval = [&](const int vi, const int vj) __attribute__((always_inline)) -> float {  // H(i, j) from hinfo(i), hinfo(j)
+      if constexpr (SM::FULLBLK) {
+        // staged: every U x U block (a <= b) of the unreduced matrix, block (a, a + d) at hs_off(d) + a; a same-step block holds
+        // its upper triangle in reference (component) order
+        const int si = vi & 255, sj = vj & 255, ri = vi >> 8, rj = vj >> 8;
+        const bool sw = (si > sj) || (si == sj && ri > rj);
+        const int sa = sw ? sj : si, sb = sw ? si : sj, r = sw ? rj : ri, c = sw ? ri : rj, d = sb - sa;
+        return A.Hs[(SM::hs_off(d, h) + sa) * (U * U) + r * U + c];
+      } else {
+        return A.Hs[hs_index<NMAX>(vi < vj ? vi : vj, vi < vj ? vj : vi)];
+      }
+    };
+    MfsPanel &PN = *reinterpret_cast<MfsPanel *>(&Q.ST[0][0]);
+    static_assert(sizeof(MfsPanel) <= sizeof(Q.ST), "the pivot panels live in the (not yet used) mat-vec staging");
+    double *stage = reinterpret_cast<double *>(&S.u);
+    constexpr int stage_doubles = (int)(sizeof(S.u) / sizeof(double));
+    static_assert(stage_doubles >= 48 * 121, "re-layout staging of the matrix-core sweeps: 48 rows of M at stride 121");
+    const bool live0 = owner_r[0] && e1_r[0] < ng;
+    switch (wv) {  // uniform: per-wave specialised code
+      case 0: mfma_sweeps<0, NT>(PN, stage, stage_doubles, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a[0]); break;
+      case 1: mfma_sweeps<1, NT>(PN, stage, stage_doubles, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a[0]); break;
+      case 2: mfma_sweeps<2, NT>(PN, stage, stage_doubles, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a[0]); break;
+      default: mfma_sweeps<3, NT>(PN, stage, stage_doubles, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a[0]); break;
+    }
+  } else {
   __syncthreads();  // every block is loaded before the solver state (which aliases the staging area) is written
   if (tid < NMAX) Q.piv[0][tid] = 0.0, Q.piv[1][tid] = 0.0;
   __syncthreads();
@@ -1235,6 +1581,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
 #pragma unroll
       for (int jj = 0; jj < ii; ++jj) a[s][ii][jj] = diag_s ? a[s][jj][ii] : a[s][ii][jj];
   }
+  }  // scalar sweeps
   PROF_MARK(P_SWEEP);
 
   // ---- products with the register blocks --------------------------------------------------------------------------

@@ -3,6 +3,10 @@
 // (36 upper-triangle 16x16 tiles over 4 waves = 9 tiles = 72 VGPRs per lane -- the footprint of the scalar sweeps' 6x6 block).
 // Measures cycles per workgroup with three workgroups per CU (the headline variant's occupancy) and the accuracy of the
 // inverse; the scalar sweeps of hmpc_kernel.h cost ~122 k cycles per workgroup in the same setting (profiles/r03).
+// This is the stand-alone prototype of mfma_sweeps() in hmpc_kernel.h (which adds the power-of-two scaling and the hand-over
+// to the 6 x 6 blocks).  -DDESYNC staggers the workgroups (identical workgroups started together run in lockstep and never
+// overlap their matrix instructions with each other's latency chains: 101 k; staggered as in the product: 78 k);
+// -DNO_MFMA leaves the matrix instructions out (what the rest costs).
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off scripts/micro/sweep_mfma64.hip -o /tmp/sweep_mfma64 && /tmp/sweep_mfma64
 #include <hip/hip_runtime.h>
 
@@ -10,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -31,6 +36,8 @@ __device__ __forceinline__ double rcp1(double d) {  // v_rcp_f64 (2^-24) + one N
 
 struct Smem {
   double P[2][4][PST];  // published pivot panel rows (double buffered); the K columns carry D - I
+  double Dinv[2][4][4]; // inverse of the step's 4x4 pivot block, published with the panel by the wave that owns the diagonal tile
+  double Draw[4][4];    // the pivot block as it is (D recovered from the panel's D - I would cost small pivots three digits)
   double pad[5200];     // brings the footprint to the headline variant's (three workgroups per CU by LDS as well)
 };
 
@@ -69,6 +76,13 @@ __device__ __forceinline__ void sweep_wave(Smem &S, const double *H, double *M, 
       acc[t][r] = (i < n && j < n) ? H[i * N + j] : ((i == j) ? 1.0 : 0.0);  // identity padding
     }
   }
+#ifdef DESYNC
+  // identical workgroups started together run in lockstep (all in their matrix instructions at once, then all in their
+  // latency chains at once) -- unlike the product kernel, whose workgroups sit at unrelated phases.  A start-up delay that
+  // differs per workgroup breaks the lockstep.
+  for (int d = 0; d < (int)((blockIdx.x * 37u) % 61u) * 64; ++d) __builtin_amdgcn_s_sleep(1);
+  __syncthreads();
+#endif
   const long long t0 = clock64();
   // panel of step s from the accumulators: rows K = 4 s .. 4 s + 3 of the symmetric matrix, the pivot block as D - I.
   //   row tiles (Ik, J):      lane (g, c) holds A[16 Ik + 4 rr + g][16 J + c] in register rr         (rr = s % 4)
@@ -77,18 +91,57 @@ __device__ __forceinline__ void sweep_wave(Smem &S, const double *H, double *M, 
     const double lo = (rr & 1) ? v[1] : v[0], hi = (rr & 1) ? v[3] : v[2];
     return (rr & 2) ? hi : lo;
   };
-  auto publish = [&](const int s, const int rr) __attribute__((always_inline)) {
-    const int Ik = s >> 2, c0 = 4 * rr;
+  // x = row g of D^-1 (D = [A B; B' C] in 2x2 blocks; the panel carries D - I), every lane for its own g:
+  //   S = C - B' A^-1 B,  x_lo = S^-1 (v - B' A^-1 u),  x_hi = A^-1 u - (A^-1 B) x_lo      for e_g = [u; v]
+  // Computed ONCE per step, by the wave that owns the diagonal tile, right after it has published the panel (its own LDS
+  // writes are visible to it after a wait): lanes c == 0 publish the four rows.
+  auto publish_dinv = [&](const int s) __attribute__((always_inline)) {
+    // LDL' in pivot order: backward stable for the positive definite block (closed-form 2 x 2 determinants lose cond(D) eps)
+    const double(*D)[4] = S.Draw;
+    const double d00 = D[0][0], d10 = D[1][0], d20 = D[2][0], d30 = D[3][0];
+    const double d11 = D[1][1], d21 = D[2][1], d31 = D[3][1], d22 = D[2][2], d32 = D[3][2], d33 = D[3][3];
+    const double i0 = rcp_nr(d00);
+    const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+    const double e1 = dfma(-l10, d10, d11), i1 = rcp_nr(e1);
+    const double m21 = dfma(-l20, d10, d21), m31 = dfma(-l30, d10, d31);
+    const double l21 = m21 * i1, l31 = m31 * i1;
+    const double e2 = dfma(-l21, m21, dfma(-l20, d20, d22)), i2 = rcp_nr(e2);
+    const double m32 = dfma(-l31, m21, dfma(-l30, d20, d32));
+    const double l32 = m32 * i2;
+    const double e3 = dfma(-l32, m32, dfma(-l31, m31, dfma(-l30, d30, d33))), i3 = rcp_nr(e3);
+    double y0 = (g == 0) ? 1.0 : 0.0, y1 = (g == 1) ? 1.0 : 0.0, y2 = (g == 2) ? 1.0 : 0.0, y3 = (g == 3) ? 1.0 : 0.0;
+    y1 = dfma(-l10, y0, y1);
+    y2 = dfma(-l21, y1, dfma(-l20, y0, y2));
+    y3 = dfma(-l32, y2, dfma(-l31, y1, dfma(-l30, y0, y3)));
+    const double x3 = y3 * i3;
+    const double x2 = dfma(-l32, x3, y2 * i2);
+    const double x1 = dfma(-l31, x3, dfma(-l21, x2, y1 * i1));
+    const double x0 = dfma(-l30, x3, dfma(-l20, x2, dfma(-l10, x1, y0 * i0)));
+    if (c == 0) {
+      double *dst = S.Dinv[s & 1][g];
+      dst[0] = x0, dst[1] = x1, dst[2] = x2, dst[3] = x3;
+    }
+  };
+  // One computed jump on the tile row of the pivot instead of two tests per tile: inside a case the tile coordinates AND the
+  // pivot's tile row are compile-time constants, so only the tiles that really hold panel entries leave code behind.
+  auto publish_ik = [&](auto ikc, const int s, const int rr) __attribute__((always_inline)) {
+    constexpr int IK = decltype(ikc)::value;
+    const int c0 = 4 * rr;
     double(*P)[PST] = S.P[s & 1];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      if (tI[t] == Ik) {  // uniform
-        asm volatile("");  // (a real branch: keeps the selects below from being speculated for every tile)
+      if (tI[t] == IK) {  // compile time
         double v = pick(acc[t], rr);
-        if (tJ[t] == Ik) v -= (c == c0 + g) ? 1.0 : 0.0;
+        if (tJ[t] == IK) {
+          if (c >= c0 && c < c0 + 4) S.Draw[g][c - c0] = v;
+          v -= (c == c0 + g) ? 1.0 : 0.0;
+        }
         P[g][16 * tJ[t] + c] = v;
-      } else if (tJ[t] == Ik) {  // uniform
-        asm volatile("");
+        if (tJ[t] == IK) {  // this wave owns the diagonal tile = the pivot block
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes have landed
+          publish_dinv(s);
+        }
+      } else if (tJ[t] == IK) {
         if (c >= c0 && c < c0 + 4) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) P[c - c0][16 * tI[t] + g + 4 * r] = acc[t][r];
@@ -96,27 +149,22 @@ __device__ __forceinline__ void sweep_wave(Smem &S, const double *H, double *M, 
       }
     }
   };
-  auto step = [&](const int s, const int rr) __attribute__((always_inline)) {  // rr = s % 4, static
-    const int k0 = 4 * s, Ik = s >> 2;
+  auto publish = [&](const int s, const int rr) __attribute__((always_inline)) {
+    switch (s >> 2) {  // uniform
+      case 0: publish_ik(std::integral_constant<int, 0>(), s, rr); break;
+      case 1: publish_ik(std::integral_constant<int, 1>(), s, rr); break;
+      case 2: publish_ik(std::integral_constant<int, 2>(), s, rr); break;
+      case 3: publish_ik(std::integral_constant<int, 3>(), s, rr); break;
+      case 4: publish_ik(std::integral_constant<int, 4>(), s, rr); break;
+      case 5: publish_ik(std::integral_constant<int, 5>(), s, rr); break;
+      case 6: publish_ik(std::integral_constant<int, 6>(), s, rr); break;
+      default: publish_ik(std::integral_constant<int, 7>(), s, rr); break;
+    }
+  };
+  auto step = [&](const int s, const int rr) __attribute__((always_inline)) {  // rr = s % 4
+    const int Ik = s >> 2;
     const double(*P)[PST] = S.P[s & 1];
-    // x = row g of D^-1 (D = [A B; B' C] in 2x2 blocks; the panel carries D - I), every lane for its own g:
-    //   S = C - B' A^-1 B,  x_lo = S^-1 (v - B' A^-1 u),  x_hi = A^-1 u - (A^-1 B) x_lo      for e_g = [u; v]
-    const double a00 = P[0][k0] + 1.0, a10 = P[1][k0], a11 = P[1][k0 + 1] + 1.0;
-    const double b00 = P[2][k0], b01 = P[3][k0], b10 = P[2][k0 + 1], b11 = P[3][k0 + 1];  // B[i][j] = D[i][2 + j] = P[2 + j][k0 + i]
-    const double c00 = P[2][k0 + 2] + 1.0, c10 = P[3][k0 + 2], c11 = P[3][k0 + 3] + 1.0;
-    const double ia = rcp1(dfma(a00, a11, -(a10 * a10)));
-    const double p00 = a11 * ia, p01 = -a10 * ia, p11 = a00 * ia;              // A^-1
-    const double w00 = dfma(p00, b00, p01 * b10), w01 = dfma(p00, b01, p01 * b11);  // W = A^-1 B
-    const double w10 = dfma(p01, b00, p11 * b10), w11 = dfma(p01, b01, p11 * b11);
-    const double s00 = c00 - dfma(b00, w00, b10 * w10), s10 = c10 - dfma(b01, w00, b11 * w10);
-    const double s11 = c11 - dfma(b01, w01, b11 * w11);
-    const double is = rcp1(dfma(s00, s11, -(s10 * s10)));
-    const double q00 = s11 * is, q01 = -s10 * is, q11 = s00 * is;              // S^-1
-    const double u0 = (g == 0) ? 1.0 : 0.0, u1 = (g == 1) ? 1.0 : 0.0, v0 = (g == 2) ? 1.0 : 0.0, v1 = (g == 3) ? 1.0 : 0.0;
-    const double t0v = dfma(p00, u0, p01 * u1), t1v = dfma(p01, u0, p11 * u1);  // A^-1 u
-    const double r0 = v0 - dfma(b00, t0v, b10 * t1v), r1 = v1 - dfma(b01, t0v, b11 * t1v);
-    const double x2 = dfma(q00, r0, q01 * r1), x3 = dfma(q01, r0, q11 * r1);
-    const double x0 = t0v - dfma(w00, x2, w01 * x3), x1 = t1v - dfma(w10, x2, w11 * x3);
+    const double x0 = S.Dinv[s & 1][g][0], x1 = S.Dinv[s & 1][g][1], x2 = S.Dinv[s & 1][g][2], x3 = S.Dinv[s & 1][g][3];
     // rank-4 updates: tile(I,J) -= Q_I' P_J,  Q = D^-1 P;  A operand: lane (g, c) supplies -Q[g][16 I + c], B: P[g][16 J + c].
     // Operands first (every LDS read in flight before the first use), then the matrix instructions back to back.
     // Groups of three tiles, software pipelined: the operands of group k+1 are read while the matrix instructions of group k run.
@@ -152,7 +200,7 @@ __device__ __forceinline__ void sweep_wave(Smem &S, const double *H, double *M, 
     // the pivot block came out as 2 I - D^-1 (substituted multipliers on both sides): its diagonal is 2 too high
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
-      if (tI[t] == Ik && tJ[t] == Ik) {  // uniform branch
+      if (tI[t] == tJ[t] && tI[t] == Ik) {  // (first test compile time, second uniform)
         asm volatile("");
         const double two = (c == 4 * rr + g) ? 2.0 : 0.0;
 #pragma unroll
