@@ -169,7 +169,9 @@ struct Smem {
   // matrix-core sweeps: power-of-two diagonal scaling, H~ = 2^k H 2^k with k_i = -floor(log2(H_ii) / 2) -- exact in binary
   // floating point in both directions (H_ii spans 2e-4 .. 500; the 4 x 4 pivot blocks of the scaled matrix are far better
   // conditioned than the raw ones, which is what the explicitly inverted pivot block needs)
-  signed char kexp[(NMAX == 120 && NT == 256 && BPT == 1 && NC == 2) ? NMAX + 8 : 1];
+  static constexpr bool MFS2 = (NMAX == 120 && NT == 256 && BPT == 1 && NC == 2);  // shapes whose fast variants sweep on the matrix cores
+  static constexpr bool MFS3 = (NMAX == 180 && NT == 256 && BPT == 2 && NC == 3);
+  signed char kexp[(MFS2 || MFS3) ? 16 * ((NMAX + 15) / 16) : 1];
   unsigned char rmap[U * HMAX];            // original variable U*step+comp -> sweep index (255 = eliminated)
   unsigned char ls_leg[NG], ls_step[NG];
   int n, m, nls, pad0;
@@ -327,6 +329,12 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #ifndef HMPC_MFMA_SWEEP
 #define HMPC_MFMA_SWEEP 1  // 120-variable / 256-thread variants: stage S as 4 x 4 block pivots on v_mfma_f64_16x16x4_f64 (0: scalar sweeps)
 #endif
+#ifndef HMPC_MFS_GT
+#define HMPC_MFS_GT 4  // matrix-core sweeps, 20 tiles per wave: tiles per group of operand reads (two groups in flight)
+#endif
+#ifndef HMPC_MFMA_SWEEP3
+#define HMPC_MFMA_SWEEP3 1  // the same for the fast three-contact variant (180 variables, 256 threads, two blocks per thread)
+#endif
 #ifndef HMPC_BLOCK_FRICTION
 #define HMPC_BLOCK_FRICTION 1  // block start also takes friction rows violated at the unconstrained minimiser
 #endif
@@ -387,98 +395,245 @@ __device__ __forceinline__ LazyInt<LAZY, F> lazy_int(F f) {
 // block per thread -- through three passes over an LDS staging area (rows of M in chunks of 42).
 typedef double hmpc_d4 __attribute__((ext_vector_type(4)));
 
-constexpr int mfs_tile_i(int t) {  // tile t (0..35, block-row-major over I <= J of the 8 x 8 tile grid) -> I
+// tile t (block-row-major over I <= J of the NTG x NTG grid of 16 x 16 tiles) -> I, J
+constexpr int mfs_tile_i(int t, int ntg) {
   int i = 0, base = 0;
-  while (t >= base + (8 - i)) base += 8 - i, ++i;
+  while (t >= base + (ntg - i)) base += ntg - i, ++i;
   return i;
 }
-constexpr int mfs_tile_j(int t) {
+constexpr int mfs_tile_j(int t, int ntg) {
   int i = 0, base = 0;
-  while (t >= base + (8 - i)) base += 8 - i, ++i;
+  while (t >= base + (ntg - i)) base += ntg - i, ++i;
   return i + (t - base);
 }
-template <int WV>
-struct MfsTiles {  // wave WV owns tiles 9 WV .. 9 WV + 8: at most four distinct tile rows
-  int i[9], j[9];
-  constexpr MfsTiles() : i{}, j{} {
-    for (int t = 0; t < 9; ++t) i[t] = mfs_tile_i(9 * WV + t), j[t] = mfs_tile_j(9 * WV + t);
+// Which wave holds tile (I, J).  By default the NTG (NTG + 1) / 2 tiles are dealt in contiguous runs of the block-row-major
+// order (a wave then needs few distinct A operands: one per tile row it touches).  The 12 x 12 grid on four waves (180
+// variables, two leg-step blocks per thread) is dealt by hand instead: there the 160 accumulator registers and the 144
+// registers of the two blocks have to pass each other in the register file when M is handed over chunk by chunk
+// (mfs_relayout), and what bounds the peak is how many of a wave's tiles are still unstored when its blocks are born -- a
+// thread's slot-0 block lies in row chunk 0 (wave 3: 0-1), its slot-1 block in chunk 1 / 1-2 / 2-3 / 3 for waves 0..3.  With
+// tiles per row chunk (9, 7, 4, 0), (8, 8, 4, 0), (8, 5, 3, 3), (8, 4, 4, 3) for waves 0..3 no wave holds more than 176 registers
+// of matrix at any time (contiguous runs: 232, and the allocator spills); every wave owns three diagonal tiles.
+constexpr int mfs_owner(int ntg, int nwv, int I, int J) {
+  if (ntg == 12 && nwv == 4) {
+    switch (I) {
+      case 0: return J <= 8 ? 0 : 1;
+      case 1: return J <= 5 ? 1 : 2;
+      case 2: return J <= 3 ? 2 : 3;
+      case 3: return J <= 9 ? 0 : 1;
+      case 4: return J <= 9 ? 1 : 2;
+      case 5: return J <= 7 ? 2 : 3;
+      case 6: return J <= 9 ? 0 : 1;
+      case 7: return J <= 8 ? 1 : 2;
+      case 8: return 3;
+      case 9: return 2;
+      default: return 3;
+    }
+  }
+  const int ntiles = ntg * (ntg + 1) / 2, base = ntiles / nwv, rem = ntiles % nwv;
+  int t = 0;  // index of (I, J) in block-row-major order
+  for (int i = 0; i < I; ++i) t += ntg - i;
+  t += J - I;
+  int w = 0, first = 0;
+  while (w < nwv - 1 && t >= first + base + (w < rem ? 1 : 0)) first += base + (w < rem ? 1 : 0), ++w;
+  return w;
+}
+constexpr int mfs_count(int ntg, int nwv, int wv) {
+  int c = 0;
+  for (int i = 0; i < ntg; ++i)
+    for (int j = i; j < ntg; ++j) c += (mfs_owner(ntg, nwv, i, j) == wv) ? 1 : 0;
+  return c;
+}
+template <int NTG, int NWV>
+struct MfsGrid {
+  static constexpr int NTILES = NTG * (NTG + 1) / 2;
+  static constexpr int TPW = (NTILES + NWV - 1) / NWV;  // accumulator tiles per wave (some waves may hold one less)
+  static constexpr int PST = 16 * NTG + 16;             // panel row stride in doubles (= 128 mod 256 bytes: the four rows of a read hit different banks)
+};
+template <int NTG, int NWV>
+using MfsAcc = hmpc_d4[MfsGrid<NTG, NWV>::TPW];  // a wave's accumulator tiles
+template <int NTG, int NWV, int WV>
+struct MfsTiles {  // the wave's tiles, sorted by (I, J)
+  static constexpr int TPW = MfsGrid<NTG, NWV>::TPW;
+  int cnt;
+  int i[TPW], j[TPW];
+  constexpr MfsTiles() : cnt(0), i{}, j{} {
+    for (int ii = 0; ii < NTG; ++ii)
+      for (int jj = ii; jj < NTG; ++jj)
+        if (mfs_owner(NTG, NWV, ii, jj) == WV) i[cnt] = ii, j[cnt] = jj, ++cnt;
+    for (int t = cnt; t < TPW; ++t) i[t] = i[cnt - 1], j[t] = j[cnt - 1];  // (a slot beyond the wave's count is never used)
   }
 };
-constexpr int MFS_PST = 144;  // panel row stride in doubles (= 128 mod 256 bytes: the four rows of a read hit different banks)
+static_assert(mfs_count(12, 4, 0) == 20 && mfs_count(12, 4, 1) == 20 && mfs_count(12, 4, 2) == 19 && mfs_count(12, 4, 3) == 19, "12 x 12 deal");
+static_assert(mfs_count(8, 4, 0) == 9 && mfs_count(8, 4, 3) == 9, "8 x 8 deal");
+template <int NTG>
 struct MfsPanel {
-  double P[2][4][MFS_PST];  // pivot panel rows, double buffered; the K columns carry D - I
-  double Dinv[2][4][4];     // inverse of the pivot block
-  double Draw[4][4];        // the pivot block itself, as it is (recovering D from the panel's D - I would cost the small pivots --
-                            // down to 1e-4 -- three digits; the scalar sweeps pass d beside the row for the same reason)
+  static constexpr int PST = 16 * NTG + 16;
+  double P[2][4][PST];   // pivot panel rows, double buffered; the K columns carry D - I
+  double Dinv[2][4][4];  // inverse of the pivot block
+  double Draw[4][4];     // the pivot block itself, as it is (recovering D from the panel's D - I would cost the small pivots --
+                         // down to 1e-4 -- three digits; the scalar sweeps pass d beside the row for the same reason)
 };
+// leg-step block t (block-row-major over e0 <= e1 of the NG x NG grid of 6 x 6 blocks) -> e0
+constexpr int mfs_block_row(int t, int ng) {
+  int e = 0, base = 0;
+  while (e < ng - 1 && t >= base + (ng - e)) base += ng - e, ++e;
+  return e;
+}
 
-// hinfo(i): what the staging needs to know about sweep-order variable i (one LDS read); hval(hinfo(i), hinfo(j)): H(i, j) from
-// the binary32 staging, symmetric in its arguments.  stage: LDS area of stage_doubles doubles that
-// nothing else uses until the function returns (the solver state that will live there is initialised afterwards).
-template <int WV, int NT, class HInfo, class HVal>
-__device__ __forceinline__ void mfma_sweeps(MfsPanel &PN, double *stage, const int stage_doubles, const int n, HInfo hinfo, HVal hval,
-                                            signed char *kexp, const int e0, const int e1, const bool live, double (&a)[GS][GS]) {
-  constexpr MfsTiles<WV> T;
-  constexpr int TPW = 9, PST = MFS_PST;
-  const int tid = threadIdx.x, ln = tid & 63, g = ln >> 4, c = ln & 15;
-  // power-of-two Jacobi scaling: k_i from the exponent of H_ii (the staging holds binary32 values: exponent field bits 23-30)
-  if (tid < 128) {
+// power-of-two Jacobi scaling: k_i from the exponent of H_ii (the staging holds binary32 values: exponent field bits 23-30).
+// hdiag(i): H_ii of sweep-order variable i < n.  (The caller's barrier follows.)
+template <int NTG, class HDiag>
+__device__ __forceinline__ void mfs_scale_exponents(const int n, HDiag hdiag, signed char *kexp) {
+  const int tid = threadIdx.x;
+  if (tid < 16 * NTG) {
     int k = 0;
     if (tid < n) {
-      const int inf = hinfo(tid);
-      const int ex = (int)((__float_as_uint(hval(inf, inf)) >> 23) & 255u) - 127;  // floor(log2(H_ii)), H_ii > 0
+      const int ex = (int)((__float_as_uint(hdiag(tid)) >> 23) & 255u) - 127;  // floor(log2(H_ii)), H_ii > 0
       k = -(ex >> 1);
     }
     kexp[tid] = (signed char)k;
   }
-  __syncthreads();
-  hmpc_d4 acc[TPW];
-  {
-    // Tiles from the binary32 staging of H.  Two rounds of LDS reads, each issued back to back: first what the lane's four
-    // rows per tile row and its one column per tile ARE (horizon step and component, or the reference-order index), then the
-    // 36 entries themselves; the address arithmetic in between is branch-free.
-    int cinf[TPW], rinf[TPW][4];
+}
+
+// Tiles from the binary32 staging of H, code specialised per wave (the 120-variable variants: the whole matrix is staged at
+// once).  hinfo(i): what the staging needs to know about sweep-order variable i (one LDS read); hval(hinfo(i), hinfo(j)):
+// H(i, j) from the staging, symmetric in its arguments.
+template <int NTG, int NWV, int WV, class HInfo, class HVal>
+__device__ __forceinline__ void mfs_load(MfsAcc<NTG, NWV> &acc, const int n, HInfo hinfo, HVal hval, const signed char *kexp) {
+  constexpr MfsTiles<NTG, NWV, WV> T;
+  constexpr int TPW = MfsGrid<NTG, NWV>::TPW;
+  const int ln = threadIdx.x & 63, g = ln >> 4, c = ln & 15;
+  // Two rounds of LDS reads, each issued back to back: first what the lane's four rows per tile row and its one column per
+  // tile ARE (horizon step and component, or the reference-order index), then the entries themselves; the address
+  // arithmetic in between is branch-free.
+  int cinf[TPW], rinf[TPW][4];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int j = 16 * T.j[t] + c;
-      cinf[t] = hinfo(j < n ? j : 0);
+  for (int t = 0; t < TPW; ++t) {
+    const int j = 16 * T.j[t] + c;
+    cinf[t] = hinfo(j < n ? j : 0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (t == 0 || T.i[t] != T.i[t - 1]) {  // compile time
-          const int i = 16 * T.i[t] + g + 4 * r;
-          rinf[t][r] = hinfo(i < n ? i : 0);
-        } else {
-          rinf[t][r] = rinf[t - 1][r];
-        }
-      }
-    }
-    float hv[TPW][4];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#ifdef HMPC_MFS_NO_LOAD  // developer switch (timing)
-        hv[t][r] = 0.0f;
-#else
-        hv[t][r] = hval(rinf[t][r], cinf[t]);  // (symmetric in its arguments: the lower half of a diagonal tile reads the mirror)
-#endif
-      }
-    // scaled while still binary32: two multiplications by powers of two (exact; |H| <= 1e3 and |k| <= 12 keep clear of the
-    // binary32 range on both sides), the row factors shared by the tiles of a tile row
-    float srow[4] = {1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int j = 16 * T.j[t] + c;
-      const float scol = __uint_as_float((unsigned)(127 + (int)kexp[j]) << 23);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 4; ++r) {
+      if (t == 0 || T.i[t] != T.i[t - 1]) {  // compile time
         const int i = 16 * T.i[t] + g + 4 * r;
-        if (t == 0 || T.i[t] != T.i[t - 1]) srow[r] = __uint_as_float((unsigned)(127 + (int)kexp[i]) << 23);  // compile time
-        acc[t][r] = (i < n && j < n) ? (double)((hv[t][r] * srow[r]) * scol) : ((i == j) ? 1.0 : 0.0);  // identity padding
+        rinf[t][r] = hinfo(i < n ? i : 0);
+      } else {
+        rinf[t][r] = rinf[t - 1][r];
       }
     }
   }
-  __syncthreads();  // every tile is loaded before the panel (which aliases the staging of H) is written
+  float hv[TPW][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#ifdef HMPC_MFS_NO_LOAD  // developer switch (timing)
+      hv[t][r] = 0.0f;
+#else
+      hv[t][r] = hval(rinf[t][r], cinf[t]);  // (symmetric in its arguments: the lower half of a diagonal tile reads the mirror)
+#endif
+    }
+  // scaled while still binary32: two multiplications by powers of two (exact; |H| <= 1e3 and |k| <= 12 keep clear of the
+  // binary32 range on both sides), the row factors shared by the tiles of a tile row
+  float srow[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int j = 16 * T.j[t] + c;
+    const float scol = __uint_as_float((unsigned)(127 + (int)kexp[j]) << 23);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * T.i[t] + g + 4 * r;
+      if (t == 0 || T.i[t] != T.i[t - 1]) srow[r] = __uint_as_float((unsigned)(127 + (int)kexp[i]) << 23);  // compile time
+      acc[t][r] = (i < n && j < n) ? (double)((hv[t][r] * srow[r]) * scol) : ((i == j) ? 1.0 : 0.0);  // identity padding
+    }
+  }
+}
+
+// Tiles for the variants whose staging of H holds only part of the matrix at a time (three contacts: two passes over the
+// block-diagonals): the 6 x 6 leg-step register blocks are filled pass by pass exactly as for the scalar sweeps, then -- H is
+// binary32 data -- parked as floats in LDS, block t of the block-row-major order at 36 t (mfs_park_blocks: common code, the
+// blocks die there and never meet the accumulators in the register file), and read into tiles from there (mfs_load_parked:
+// per-wave code).  The scaling exponents come from the diagonal blocks.
+template <int NV, int BPT, int NTHR, int NTG>
+__device__ __forceinline__ void mfs_park_blocks(float *hb, const int n, signed char *kexp, const bool (&own)[BPT], const int (&e0)[BPT],
+                                                const int (&e1)[BPT], const bool (&live)[BPT], const double (&a)[BPT][GS][GS]) {
+  const int tid = threadIdx.x;
+  if (tid >= n && tid < 16 * NTG) kexp[tid] = 0;  // padding
+#pragma unroll
+  for (int s = 0; s < BPT; ++s) {
+    if (own[s]) {
+      float *dst = hb + (tid + NTHR * s) * (GS * GS);
+#pragma unroll
+      for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < GS; jj += 2) {
+          float2 v2;
+          v2.x = (float)a[s][ii][jj], v2.y = (float)a[s][ii][jj + 1];  // (exact: the blocks were loaded from binary32 values)
+          *reinterpret_cast<float2 *>(dst + ii * GS + jj) = v2;
+        }
+    }
+    if (live[s] && e0[s] == e1[s]) {
+      // k_i = -floor(log2(H_ii) / 2) from the exponent field of the diagonal entries (H_ii > 0)
+#pragma unroll
+      for (int k = 0; k < GS; ++k) {
+        const int ex = ((__double2hiint(a[s][k][k]) >> 20) & 2047) - 1023;
+        kexp[GS * e0[s] + k] = (signed char)(-(ex >> 1));
+      }
+    }
+  }
+}
+template <int NTG, int NWV, int WV, int NV>
+__device__ __forceinline__ void mfs_load_parked(MfsAcc<NTG, NWV> &acc, const int n, const float *hb, const signed char *kexp) {
+  constexpr MfsTiles<NTG, NWV, WV> T;
+  constexpr int CNT = mfs_count(NTG, NWV, WV), NGB = NV / GS;
+  const int ln = threadIdx.x & 63, g = ln >> 4, c = ln & 15;
+  // entry (i, j), i <= j, lies in block (e0, e1) = (i / 6, j / 6) at 36 (e0 NGB - e0 (e0 - 1) / 2 + e1 - e0) + 6 (i % 6) + j % 6: a row
+  // part and a column part, each computed once per tile row / tile column
+  auto rowpart = [&](const int i) __attribute__((always_inline)) -> int {
+    const int e = (i * 171) >> 10, ii = i - GS * e;  // i / 6 for i < 256
+    return (e * NGB - ((e * (e - 1)) >> 1) - e) * (GS * GS) + ii * GS;
+  };
+  auto colpart = [&](const int j) __attribute__((always_inline)) -> int {
+    const int e = (j * 171) >> 10, jj = j - GS * e;
+    return e * (GS * GS) + jj;
+  };
+  int rp[4] = {0, 0, 0, 0}, rcp[4] = {0, 0, 0, 0};
+  float srow[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+  for (int t = 0; t < CNT; ++t) {
+    const int j = 16 * T.j[t] + c;
+    const bool jv = j < n;
+    const int cp = colpart(jv ? j : 0);
+    const float scol = __uint_as_float((unsigned)(127 + (int)kexp[j]) << 23);
+    if (t == 0 || T.i[t] != T.i[t - 1]) {  // compile time
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * T.i[t] + g + 4 * r;
+        rp[r] = rowpart(i < n ? i : 0), rcp[r] = colpart(i < n ? i : 0);
+        srow[r] = __uint_as_float((unsigned)(127 + (int)kexp[i]) << 23);
+      }
+    }
+    const int crp = (T.i[t] == T.j[t]) ? rowpart(jv ? j : 0) : 0;  // diagonal tiles: the lower half reads the mirror
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * T.i[t] + g + 4 * r;
+      const bool valid = i < n && jv;
+      const int off = (T.i[t] == T.j[t] && i > j) ? crp + rcp[r] : rp[r] + cp;
+      const float hv = hb[valid ? off : 0];
+      // scaled while still binary32: two multiplications by powers of two (exact)
+      acc[t][r] = valid ? (double)((hv * srow[r]) * scol) : ((i == j) ? 1.0 : 0.0);  // identity padding
+    }
+  }
+}
+
+// The NTG * 4 block-pivot steps on the tiles in acc (code specialised per wave).  Callers: a barrier between the last read
+// of whatever PN aliases and this call.
+template <int NTG, int NWV, int WV>
+__device__ __forceinline__ void mfs_steps(MfsPanel<NTG> &PN, MfsAcc<NTG, NWV> &acc, const int n) {
+  constexpr MfsTiles<NTG, NWV, WV> T;
+  constexpr int TPW = MfsGrid<NTG, NWV>::TPW, PST = MfsPanel<NTG>::PST, CNT = mfs_count(NTG, NWV, WV);
+  static_assert(NTG <= 16, "publish(): one case per tile row");
+  const int ln = threadIdx.x & 63, g = ln >> 4, c = ln & 15;
   auto pick = [&](const hmpc_d4 &v, int rr) __attribute__((always_inline)) -> double {  // rr uniform
     const double lo = (rr & 1) ? v[1] : v[0], hi = (rr & 1) ? v[3] : v[2];
     return (rr & 2) ? hi : lo;
@@ -522,25 +677,29 @@ __device__ __forceinline__ void mfma_sweeps(MfsPanel &PN, double *stage, const i
   //   column tiles (I < Ik):  lanes with c in [4 rr, 4 rr + 4) hold A[16 I + g + 4 r][16 Ik + c], r = 0..3
   auto publish_ik = [&](auto ikc, const int s, const int rr) __attribute__((always_inline)) {
     constexpr int IK = decltype(ikc)::value;
-    const int c0 = 4 * rr;
-    double(*P)[PST] = PN.P[s & 1];
+    if constexpr (IK < NTG) {
+      const int c0 = 4 * rr;
+      double(*P)[PST] = PN.P[s & 1];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      if (T.i[t] == IK) {  // compile time
-        double v = pick(acc[t], rr);
-        if (T.j[t] == IK) {
-          if (c >= c0 && c < c0 + 4) PN.Draw[g][c - c0] = v;
-          v -= (c == c0 + g) ? 1.0 : 0.0;
-        }
-        P[g][16 * T.j[t] + c] = v;
-        if (T.j[t] == IK) {  // this wave owns the pivot block: its own LDS writes are visible to it after a wait
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          publish_dinv(s);
-        }
-      } else if (T.j[t] == IK) {
-        if (c >= c0 && c < c0 + 4) {
+      for (int t = 0; t < CNT; ++t) {
+        if (T.i[t] == IK) {  // compile time
+          double v = pick(acc[t], rr);
+          if (T.j[t] == IK) {
+            if (c >= c0 && c < c0 + 4) PN.Draw[g][c - c0] = v;
+            v -= (c == c0 + g) ? 1.0 : 0.0;
+          }
+          P[g][16 * T.j[t] + c] = v;
+          if (T.j[t] == IK) {  // this wave owns the pivot block: its own LDS writes are visible to it after a wait
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+#ifndef HMPC_MFS_NO_LDL  // developer switch (register pressure)
+            publish_dinv(s);
+#endif
+          }
+        } else if (T.j[t] == IK) {
+          if (c >= c0 && c < c0 + 4) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) P[c - c0][16 * T.i[t] + g + 4 * r] = acc[t][r];
+            for (int r = 0; r < 4; ++r) P[c - c0][16 * T.i[t] + g + 4 * r] = acc[t][r];
+          }
         }
       }
     }
@@ -548,14 +707,11 @@ __device__ __forceinline__ void mfma_sweeps(MfsPanel &PN, double *stage, const i
   auto publish = [&](const int s) __attribute__((always_inline)) {
     const int rr = s & 3;
     switch (s >> 2) {  // uniform: one computed jump
-      case 0: publish_ik(std::integral_constant<int, 0>(), s, rr); break;
-      case 1: publish_ik(std::integral_constant<int, 1>(), s, rr); break;
-      case 2: publish_ik(std::integral_constant<int, 2>(), s, rr); break;
-      case 3: publish_ik(std::integral_constant<int, 3>(), s, rr); break;
-      case 4: publish_ik(std::integral_constant<int, 4>(), s, rr); break;
-      case 5: publish_ik(std::integral_constant<int, 5>(), s, rr); break;
-      case 6: publish_ik(std::integral_constant<int, 6>(), s, rr); break;
-      default: publish_ik(std::integral_constant<int, 7>(), s, rr); break;
+#define HMPC_MFS_CASE(K) case K: publish_ik(std::integral_constant<int, K>(), s, rr); break;
+      HMPC_MFS_CASE(0) HMPC_MFS_CASE(1) HMPC_MFS_CASE(2) HMPC_MFS_CASE(3) HMPC_MFS_CASE(4) HMPC_MFS_CASE(5) HMPC_MFS_CASE(6) HMPC_MFS_CASE(7)
+      HMPC_MFS_CASE(8) HMPC_MFS_CASE(9) HMPC_MFS_CASE(10) HMPC_MFS_CASE(11) HMPC_MFS_CASE(12) HMPC_MFS_CASE(13) HMPC_MFS_CASE(14)
+#undef HMPC_MFS_CASE
+      default: publish_ik(std::integral_constant<int, 15>(), s, rr); break;
     }
   };
   publish(0);
@@ -570,21 +726,23 @@ __device__ __forceinline__ void mfma_sweeps(MfsPanel &PN, double *stage, const i
     const int rr = s & 3, Ik = s >> 2;
     const double(*P)[PST] = PN.P[s & 1];
     const double x0 = PN.Dinv[s & 1][g][0], x1 = PN.Dinv[s & 1][g][1], x2 = PN.Dinv[s & 1][g][2], x3 = PN.Dinv[s & 1][g][3];
-    // tile(I,J) -= Q_I' P_J, Q = D^-1 P: A operand -Q[g][16 I + c], B operand P[g][16 J + c]; groups of three tiles, the
-    // operands of group k+1 read while the matrix instructions of group k run
-    constexpr int GT = 3, NGRP = TPW / GT;
+    // tile(I,J) -= Q_I' P_J, Q = D^-1 P: A operand -Q[g][16 I + c], B operand P[g][16 J + c].
+    // groups of GT tiles, the operands of group k+1 read while the matrix instructions of group k run
+    constexpr int GT = (TPW % 3 == 0) ? 3 : HMPC_MFS_GT, NGRP = (CNT + GT - 1) / GT;
     double aop[2][GT], bop[2][GT];
     double alast = 0.0;
     auto fetch = [&](const int grp, double (&ao)[GT], double (&bo)[GT]) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < GT; ++u) {
         const int t = grp * GT + u;
-        bo[u] = P[g][16 * T.j[t] + c];
-        if (t == 0 || T.i[t] != T.i[t - 1]) {  // compile time; the wave's tiles are sorted by I
-          const int m = 16 * T.i[t] + c;
-          alast = -dfma(x3, P[3][m], dfma(x2, P[2][m], dfma(x1, P[1][m], x0 * P[0][m])));
+        if (t < CNT) {  // compile time
+          bo[u] = P[g][16 * T.j[t] + c];
+          if (t == 0 || T.i[t] != T.i[t - 1]) {  // compile time; the wave's tiles are sorted by I
+            const int m = 16 * T.i[t] + c;
+            alast = -dfma(x3, P[3][m], dfma(x2, P[2][m], dfma(x1, P[1][m], x0 * P[0][m])));
+          }
+          ao[u] = alast;
         }
-        ao[u] = alast;
       }
     };
     fetch(0, aop[0], bop[0]);
@@ -594,11 +752,11 @@ __device__ __forceinline__ void mfma_sweeps(MfsPanel &PN, double *stage, const i
 #pragma unroll
       for (int u = 0; u < GT; ++u) {
         const int t = grp * GT + u;
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[grp & 1][u], bop[grp & 1][u], acc[t], 0, 0, 0);
+        if (t < CNT) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[grp & 1][u], bop[grp & 1][u], acc[t], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
+    for (int t = 0; t < CNT; ++t)
       if (T.i[t] == T.j[t] && T.i[t] == Ik) {  // (first test compile time, second uniform): the pivot block's diagonal
         asm volatile("");
         const double two = (c == 4 * rr + g) ? 2.0 : 0.0;
@@ -608,48 +766,110 @@ __device__ __forceinline__ void mfma_sweeps(MfsPanel &PN, double *stage, const i
     if (s + 1 < nsteps) publish(s + 1);
     __syncthreads();
   }
-  // ---- M = -A into the 6 x 6 leg-step blocks: rows of M staged in chunks of 48 -- three tile rows = eight leg-steps, so that
-  // which tiles store in a pass is known at compile time and no block straddles a chunk -- with an odd row stride
-  constexpr int RC = 48, SST = 121;
-  // (callers guarantee stage_doubles >= RC * SST; columns >= 120 are padding and are not staged)
+}
+
+// M = -A (scaling undone) into the 6 x 6 leg-step blocks, BPT per thread: rows of M staged in chunks of 48 -- three tile rows
+// = eight leg-steps, so that which tiles store in a pass is known at compile time and no block straddles a chunk -- with an
+// odd row stride.  stage: 48 * (NV + 1) doubles of LDS that nothing else uses until the function returns.
+// With two blocks per thread the accumulators and the blocks do not fit the register file together (160 + 144): a slot's block
+// is only born at the first chunk it can lie in (known per wave at compile time: thread t's slot s holds block t + NTHR s of the
+// block-row-major order), by which time the tiles of the earlier chunks are stored and dead.
+template <int NTG, int NWV, int WV, int NV, int BPT, int NTHR>
+__device__ __forceinline__ void mfs_relayout(double *stage, MfsAcc<NTG, NWV> &acc, const int n, const signed char *kexp,
+                                             const int (&e0)[BPT], const int (&e1)[BPT], const bool (&live)[BPT], double (&a)[BPT][GS][GS]) {
+  constexpr MfsTiles<NTG, NWV, WV> T;
+  constexpr int CNT = mfs_count(NTG, NWV, WV);
+  constexpr int RC = 48, SST = NV + 1, NCH = (NTG + 2) / 3, NGB = NV / GS, NBLK = NGB * (NGB + 1) / 2;
+  const int ln = threadIdx.x & 63, g = ln >> 4, c = ln & 15;
 #pragma unroll
-  for (int ii = 0; ii < GS; ++ii)
+  for (int p = 0; p < NCH; ++p) {
+    // a slot's block is born (zero) at the first chunk it can lie in -- after that chunk's tiles are stored and dead
+    auto birth = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int jj = 0; jj < GS; ++jj) a[ii][jj] = 0.0;
+      for (int s = 0; s < BPT; ++s) {
+        const int b_lo = NTHR * s + 64 * WV;  // compile time: first block a thread of this wave can hold in slot s
+        const int pf = (b_lo < NBLK) ? mfs_block_row(b_lo, NGB) / 8 : 0;
+        if (p == pf) {
+#pragma unroll
+          for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < GS; ++jj) a[s][ii][jj] = 0.0;
+        }
+      }
+    };
 #ifndef HMPC_MFS_NO_RELAYOUT
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
     if (RC * p < n) {  // uniform
 #pragma unroll
-      for (int t = 0; t < TPW; ++t)
+      for (int t = 0; t < CNT; ++t)
         if (T.i[t] / 3 == p) {  // compile time
           const int j = 16 * T.j[t] + c;
-          if (T.j[t] < 7 || c < 8) {  // (first test compile time)
+          if (T.j[t] < NTG - 1 || c < NV - 16 * (NTG - 1)) {  // (first test compile time; columns >= NV are padding and are not staged)
 #pragma unroll
             for (int r = 0; r < 4; ++r) stage[(16 * (T.i[t] - 3 * p) + g + 4 * r) * SST + j] = -acc[t][r];
           }
         }
       __syncthreads();
-      if (live && (e0 >> 3) == p) {  // this thread's block lies in the chunk: rows 6 e0 .., columns 6 e1 ..
-        const double *rowp = stage + (GS * e0 - RC * p) * SST + GS * e1;
-        const bool dg = (e0 == e1);
-        int kr[GS], kc[GS];
+      birth();
 #pragma unroll
-        for (int k = 0; k < GS; ++k) kr[k] = (int)kexp[GS * e0 + k], kc[k] = (int)kexp[GS * e1 + k];
+      for (int s = 0; s < BPT; ++s) {
+        const int b_lo = NTHR * s + 64 * WV, b_hi = (b_lo + 63 < NBLK - 1) ? b_lo + 63 : NBLK - 1;
+        const bool can = b_lo < NBLK && p >= mfs_block_row(b_lo < NBLK ? b_lo : 0, NGB) / 8 && p <= mfs_block_row(b_hi, NGB) / 8;  // compile time
+        if (can && live[s] && (e0[s] >> 3) == p) {  // this slot's block lies in the chunk: rows 6 e0 .., columns 6 e1 ..
+          const double *rowp = stage + (GS * e0[s] - RC * p) * SST + GS * e1[s];
+          const bool dg = (e0[s] == e1[s]);
+          int kr[GS], kc[GS];
 #pragma unroll
-        for (int ii = 0; ii < GS; ++ii)
+          for (int k = 0; k < GS; ++k) kr[k] = (int)kexp[GS * e0[s] + k], kc[k] = (int)kexp[GS * e1[s] + k];
 #pragma unroll
-          for (int jj = 0; jj < GS; ++jj) {
-            // off-diagonal blocks lie above the diagonal of M: staged as they are; a diagonal block takes its lower
-            // triangle from the mirror of the upper one (bit-identical halves, as the scalar path leaves them)
-            const int off = (ii > jj) ? (dg ? jj * SST + ii : ii * SST + jj) : ii * SST + jj;
-            a[ii][jj] = rowp[off] * __hiloint2double((1023 + kr[ii] + kc[jj]) << 20, 0);  // M = 2^k M~ 2^k (exact)
+          for (int ii = 0; ii < GS; ++ii) {
+#pragma unroll
+            for (int jj = 0; jj < GS; ++jj) {
+              // off-diagonal blocks lie above the diagonal of M: staged as they are; a diagonal block takes its lower
+              // triangle from the mirror of the upper one (bit-identical halves, as the scalar path leaves them)
+              const int off = (ii > jj) ? (dg ? jj * SST + ii : ii * SST + jj) : ii * SST + jj;
+              a[s][ii][jj] = rowp[off] * __hiloint2double((1023 + kr[ii] + kc[jj]) << 20, 0);  // M = 2^k M~ 2^k (exact)
+            }
+            // (two blocks per thread: keep the scheduler from forming all 36 scale factors ahead of the reads -- 72 registers
+            // that the dying tiles and the blocks do not leave)
+            if constexpr (BPT > 1) __builtin_amdgcn_sched_barrier(0);
           }
+        }
       }
       __syncthreads();
+    } else
+#endif
+    {
+      birth();
     }
   }
-#endif
+}
+
+// The blocks leave a wave's arm of the switch through real register moves: without them the allocator ties the blocks of the
+// four arms (and of the code behind the switch) to the same registers, and the arms -- whose tiles die in different orders --
+// cannot all be coloured around that choice (it spilled a tile inside the step loop of one arm).
+template <int BPT>
+__device__ __forceinline__ void mfs_move_blocks(double (&dst)[BPT][GS][GS], const double (&src)[BPT][GS][GS]) {
+#pragma unroll
+  for (int s = 0; s < BPT; ++s)
+#pragma unroll
+    for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < GS; ++jj) asm volatile("v_mov_b64 %0, %1" : "=v"(dst[s][ii][jj]) : "v"(src[s][ii][jj]));
+}
+
+// Stage S of the 120-variable variants in one call (the whole of H is staged at once): scaling, tiles, steps, hand-over.
+template <int WV, int NT, class HInfo, class HVal>
+__device__ __forceinline__ void mfma_sweeps(MfsPanel<8> &PN, double *stage, const int n, HInfo hinfo, HVal hval, signed char *kexp, const int e0,
+                                            const int e1, const bool live, double (&a)[1][GS][GS]) {
+  mfs_scale_exponents<8>(n, [&](const int i) __attribute__((always_inline)) { const int inf = hinfo(i); return hval(inf, inf); }, kexp);
+  __syncthreads();
+  hmpc_d4 acc[MfsGrid<8, 4>::TPW];
+  mfs_load<8, 4, WV>(acc, n, hinfo, hval, kexp);
+  __syncthreads();  // every tile is loaded before the panel (which aliases the staging of H) is written
+  mfs_steps<8, 4, WV>(PN, acc, n);
+  const int e0a[1] = {e0}, e1a[1] = {e1};
+  const bool la[1] = {live};
+  mfs_relayout<8, 4, WV, 120, 1, NT>(stage, acc, n, kexp, e0a, e1a, la, a);
 }
 
 // three waves per SIMD = 3 (256 threads) or 6 (128 threads) workgroups per CU: their LDS must fit the CU's 160 KB
@@ -1064,7 +1284,11 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // the nominal input ranges that showed as forces up to 9e-5 from qpOASES in the safe pass (7e-8 with scalar pivots), while
   // nominal inputs are unaffected (5.8e-8 either way) and whatever the fast variants get wrong beyond 2e-6 is caught by
   // their KKT check and handed to the safe pass anyway.
-  constexpr bool MFMA_SWEEP = HMPC_MFMA_SWEEP && NMAX == 120 && NT == 256 && BPT == 1 && NC == 2 && !ASM_ONLY && QCAP != 0 && QCAP < NMAX;
+  constexpr bool MFMA_SWEEP = HMPC_MFMA_SWEEP && SM::MFS2 && !ASM_ONLY && QCAP != 0 && QCAP < NMAX;
+  // ... and the fast three-contact variant (180 variables, two blocks per thread): 78 tiles, 20 per wave.  Its staging of H holds
+  // the block-diagonals in two passes, so the register blocks are filled as for the scalar sweeps and turned into tiles in stage S.
+  constexpr bool MFMA_SWEEP3 = HMPC_MFMA_SWEEP3 && SM::MFS3 && !ASM_ONLY && QCAP != 0 && QCAP < NMAX;
+  constexpr int MFS3_NTG = (NMAX + 15) / 16;
   constexpr int NTILE = NG * (NG + 1) / 2;
   static_assert(NTILE <= BPT * NT && SM::MMAX <= NT && NMAX <= NT, "threads per block / constraint row / variable");
   // BPT == 1: plain registers.  BPT == 2 (256 VGPRs, 144 of them the two blocks): the coordinates of a slot travel PACKED in
@@ -1274,7 +1498,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         }
       } else {
         if (hp == 0) own_blocks();
-        if constexpr (!MFMA_SWEEP) load_blocks(dlo, dhi);  // (matrix-core sweeps: the staging is read into 16 x 16 tiles in stage S)
+        if constexpr (!MFMA_SWEEP) load_blocks(dlo, dhi);  // (matrix-core sweeps of the 120-variable variants: the staging is read into 16 x 16 tiles in stage S)
       }
       if (hp + 1 < SM::HSP) __syncthreads();  // the next pass overwrites the staging area
     }
@@ -1452,18 +1676,53 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         return A.Hs[hs_index<NMAX>(vi < vj ? vi : vj, vi < vj ? vj : vi)];
       }
     };
-    MfsPanel &PN = *reinterpret_cast<MfsPanel *>(&Q.ST[0][0]);
-    static_assert(sizeof(MfsPanel) <= sizeof(Q.ST), "the pivot panels live in the (not yet used) mat-vec staging");
+    MfsPanel<8> &PN = *reinterpret_cast<MfsPanel<8> *>(&Q.ST[0][0]);
+    static_assert(sizeof(MfsPanel<8>) <= sizeof(Q.ST), "the pivot panels live in the (not yet used) mat-vec staging");
     double *stage = reinterpret_cast<double *>(&S.u);
-    constexpr int stage_doubles = (int)(sizeof(S.u) / sizeof(double));
-    static_assert(stage_doubles >= 48 * 121, "re-layout staging of the matrix-core sweeps: 48 rows of M at stride 121");
+    static_assert(sizeof(S.u) / sizeof(double) >= 48 * 121, "re-layout staging of the matrix-core sweeps: 48 rows of M at stride 121");
     const bool live0 = owner_r[0] && e1_r[0] < ng;
     switch (wv) {  // uniform: per-wave specialised code
-      case 0: mfma_sweeps<0, NT>(PN, stage, stage_doubles, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a[0]); break;
-      case 1: mfma_sweeps<1, NT>(PN, stage, stage_doubles, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a[0]); break;
-      case 2: mfma_sweeps<2, NT>(PN, stage, stage_doubles, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a[0]); break;
-      default: mfma_sweeps<3, NT>(PN, stage, stage_doubles, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a[0]); break;
+      case 0: mfma_sweeps<0, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
+      case 1: mfma_sweeps<1, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
+      case 2: mfma_sweeps<2, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
+      default: mfma_sweeps<3, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
     }
+  } else if constexpr (MFMA_SWEEP3) {
+    // ---- the same on the tiles filled in stage A5
+    MfsPanel<MFS3_NTG> &PN = *reinterpret_cast<MfsPanel<MFS3_NTG> *>(&Q.ST[0][0]);
+    static_assert(sizeof(MfsPanel<MFS3_NTG>) <= sizeof(Q.ST), "the pivot panels live in the (not yet used) mat-vec staging");
+    double *stage = reinterpret_cast<double *>(&S.u);
+    static_assert(sizeof(S.u) / sizeof(double) >= 48 * (NMAX + 1), "re-layout staging of the matrix-core sweeps: 48 rows of M");
+    __syncthreads();  // every block is loaded before the staging area of H is written over
+    pk_fence();
+    int e0a[BPT], e1a[BPT];
+    bool lva[BPT], owa[BPT];
+#pragma unroll
+    for (int s = 0; s < BPT; ++s) e0a[s] = E0(s), e1a[s] = E1(s), owa[s] = OWN(s), lva[s] = OWN(s) && E1(s) < ng;
+    float *hb = reinterpret_cast<float *>(&S.u);
+    static_assert(sizeof(S.u) >= (size_t)NTILE * GS * GS * sizeof(float), "the parked blocks fit the staging area");
+    mfs_park_blocks<NMAX, BPT, NT, MFS3_NTG>(hb, n, S.kexp, owa, e0a, e1a, lva, a);
+    __syncthreads();
+    switch (wv) {  // uniform: per-wave specialised code
+#define HMPC_MFS3_WAVE(W)                                                                  \
+  MfsAcc<MFS3_NTG, 4> acc;                                                                 \
+  mfs_load_parked<MFS3_NTG, 4, W, NMAX>(acc, n, hb, S.kexp);                               \
+  __syncthreads(); /* every tile is loaded before the panel (which aliases the parked blocks) is written */ \
+  mfs_steps<MFS3_NTG, 4, W>(PN, acc, n);                                                   \
+  double aw[BPT][GS][GS];                                                                  \
+  mfs_relayout<MFS3_NTG, 4, W, NMAX, BPT, NT>(stage, acc, n, S.kexp, e0a, e1a, lva, aw);   \
+  mfs_move_blocks<BPT>(a, aw);
+#ifdef HMPC_MFS_ONLY_WAVE  // developer switch (register pressure of one wave's code)
+      default: { HMPC_MFS3_WAVE(HMPC_MFS_ONLY_WAVE) } break;
+#else
+      case 0: { HMPC_MFS3_WAVE(0) } break;
+      case 1: { HMPC_MFS3_WAVE(1) } break;
+      case 2: { HMPC_MFS3_WAVE(2) } break;
+      default: { HMPC_MFS3_WAVE(3) } break;
+#endif
+#undef HMPC_MFS3_WAVE
+    }
+    pk_fence();
   } else {
   __syncthreads();  // every block is loaded before the solver state (which aliases the staging area) is written
   if (tid < NMAX) Q.piv[0][tid] = 0.0, Q.piv[1][tid] = 0.0;
