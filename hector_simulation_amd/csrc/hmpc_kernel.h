@@ -127,6 +127,15 @@ enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT =
 
 constexpr int GS = 6;  // variables per stance leg-step: force (3) then moment (3)
 
+#ifndef HMPC_MFMA_SWEEP1
+// Stage S on the binary64 matrix cores (mfma_sweeps below; HMPC_MFMA_SWEEP, HMPC_MFMA_SWEEP3) for the 60-variable / 128-thread
+// variants as well (4 x 4 tiles on two waves): built, parity-green, and OFF -- stage S + block
+// load cost one workgroup 65 k cycles instead of 81 k, but with six workgroups per CU the kernel as a whole got 1.4 % SLOWER
+// (walking b8192 0.4755 ms against 0.4691): a binary64 matrix instruction holds the SIMD's double-precision pipe for 64 cycles,
+// and the five neighbours' latency-bound phases wait behind it (profiles/r04/mfma_sweep_experiments.txt).
+#define HMPC_MFMA_SWEEP1 0
+#endif
+
 // BPT = register blocks per thread (1: one 6x6 block each, NT >= NG(NG+1)/2; 2: the three-contact variant on 256 threads,
 // 465 blocks, two workgroups per CU -- which also needs its LDS under 80 KB: the staging of H is filled and drained in two
 // passes over the block-diagonals and the staged mat-vec partials in two halves of the source leg-steps).
@@ -169,9 +178,10 @@ struct Smem {
   // matrix-core sweeps: power-of-two diagonal scaling, H~ = 2^k H 2^k with k_i = -floor(log2(H_ii) / 2) -- exact in binary
   // floating point in both directions (H_ii spans 2e-4 .. 500; the 4 x 4 pivot blocks of the scaled matrix are far better
   // conditioned than the raw ones, which is what the explicitly inverted pivot block needs)
-  static constexpr bool MFS2 = (NMAX == 120 && NT == 256 && BPT == 1 && NC == 2);  // shapes whose fast variants sweep on the matrix cores
+  static constexpr bool MFS1 = (NMAX == 60 && NT == 128 && BPT == 1 && NC == 2);   // shapes whose fast variants sweep on the matrix cores
+  static constexpr bool MFS2 = (NMAX == 120 && NT == 256 && BPT == 1 && NC == 2);
   static constexpr bool MFS3 = (NMAX == 180 && NT == 256 && BPT == 2 && NC == 3);
-  signed char kexp[(MFS2 || MFS3) ? 16 * ((NMAX + 15) / 16) : 1];
+  signed char kexp[((MFS1 && HMPC_MFMA_SWEEP1) || MFS2 || MFS3) ? 16 * ((NMAX + 15) / 16) : 1];
   unsigned char rmap[U * HMAX];            // original variable U*step+comp -> sweep index (255 = eliminated)
   unsigned char ls_leg[NG], ls_step[NG];
   int n, m, nls, pad0;
@@ -363,7 +373,7 @@ __device__ __forceinline__ LazyInt<LAZY, F> lazy_int(F f) {
 }
 
 // ================================================================================================================
-// Stage S on the binary64 matrix cores (round 4; the 120-variable / 256-thread variants).
+// Stage S on the binary64 matrix cores (round 4; the fast 120-variable / 256-thread variants and the fast three-contact variant).
 //
 // M = H^-1 by symmetric Gauss-Jordan sweeps with 4 x 4 BLOCK pivots: for the pivot set K (four consecutive variables),
 //     D = A_KK;   A_KK <- -D^-1;   A_Kj <- D^-1 A_Kj;   A_iK <- A_iK D^-1;   A_ij <- A_ij - A_iK D^-1 A_Kj      (after n/4 steps A = -H^-1)
@@ -391,8 +401,11 @@ __device__ __forceinline__ LazyInt<LAZY, F> lazy_int(F f) {
 // directions -- which brings the 10x case back to 1.5e-7 and leaves nominal inputs where they were (5.7e-8).  The pivot block
 // itself is factorised by LDL' in pivot order (closed-form 2 x 2 determinants lost another two digits) from its raw entries
 // (not recovered from the panel's D - I).
-// Afterwards M is handed to the rest of the kernel in the layout everything downstream is built on -- one 6 x 6 leg-step
-// block per thread -- through three passes over an LDS staging area (rows of M in chunks of 42).
+// Afterwards M is handed to the rest of the kernel in the layout everything downstream is built on -- 6 x 6 leg-step
+// blocks, one or two per thread -- through passes over an LDS staging area (rows of M in chunks of 48).
+// Three contacts (180 variables, 12 x 12 tiles, 20 per wave = 160 VGPRs next to two blocks = 144 VGPRs per thread): tiles and
+// blocks do not fit the register file together, which shapes both hand-overs -- see mfs_park_blocks, mfs_owner, mfs_move_blocks.
+// 203 k cycles against 265 k for the scalar sweeps there.
 typedef double hmpc_d4 __attribute__((ext_vector_type(4)));
 
 // tile t (block-row-major over I <= J of the NTG x NTG grid of 16 x 16 tiles) -> I, J
@@ -857,19 +870,21 @@ __device__ __forceinline__ void mfs_move_blocks(double (&dst)[BPT][GS][GS], cons
       for (int jj = 0; jj < GS; ++jj) asm volatile("v_mov_b64 %0, %1" : "=v"(dst[s][ii][jj]) : "v"(src[s][ii][jj]));
 }
 
-// Stage S of the 120-variable variants in one call (the whole of H is staged at once): scaling, tiles, steps, hand-over.
-template <int WV, int NT, class HInfo, class HVal>
-__device__ __forceinline__ void mfma_sweeps(MfsPanel<8> &PN, double *stage, const int n, HInfo hinfo, HVal hval, signed char *kexp, const int e0,
+// Stage S in one call for the variants whose staging holds the whole of H at once and whose threads hold one block each (120
+// variables on 256 threads: 8 x 8 tiles on four waves; 60 variables on 128 threads: 4 x 4 tiles on two waves): scaling, tiles,
+// steps, hand-over.
+template <int NTG, int NWV, int WV, int NV, int NT, class HInfo, class HVal>
+__device__ __forceinline__ void mfma_sweeps(MfsPanel<NTG> &PN, double *stage, const int n, HInfo hinfo, HVal hval, signed char *kexp, const int e0,
                                             const int e1, const bool live, double (&a)[1][GS][GS]) {
-  mfs_scale_exponents<8>(n, [&](const int i) __attribute__((always_inline)) { const int inf = hinfo(i); return hval(inf, inf); }, kexp);
+  mfs_scale_exponents<NTG>(n, [&](const int i) __attribute__((always_inline)) { const int inf = hinfo(i); return hval(inf, inf); }, kexp);
   __syncthreads();
-  hmpc_d4 acc[MfsGrid<8, 4>::TPW];
-  mfs_load<8, 4, WV>(acc, n, hinfo, hval, kexp);
+  MfsAcc<NTG, NWV> acc;
+  mfs_load<NTG, NWV, WV>(acc, n, hinfo, hval, kexp);
   __syncthreads();  // every tile is loaded before the panel (which aliases the staging of H) is written
-  mfs_steps<8, 4, WV>(PN, acc, n);
+  mfs_steps<NTG, NWV, WV>(PN, acc, n);
   const int e0a[1] = {e0}, e1a[1] = {e1};
   const bool la[1] = {live};
-  mfs_relayout<8, 4, WV, 120, 1, NT>(stage, acc, n, kexp, e0a, e1a, la, a);
+  mfs_relayout<NTG, NWV, WV, NV, 1, NT>(stage, acc, n, kexp, e0a, e1a, la, a);
 }
 
 // three waves per SIMD = 3 (256 threads) or 6 (128 threads) workgroups per CU: their LDS must fit the CU's 160 KB
@@ -1284,7 +1299,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // the nominal input ranges that showed as forces up to 9e-5 from qpOASES in the safe pass (7e-8 with scalar pivots), while
   // nominal inputs are unaffected (5.8e-8 either way) and whatever the fast variants get wrong beyond 2e-6 is caught by
   // their KKT check and handed to the safe pass anyway.
-  constexpr bool MFMA_SWEEP = HMPC_MFMA_SWEEP && SM::MFS2 && !ASM_ONLY && QCAP != 0 && QCAP < NMAX;
+  constexpr bool MFMA_SWEEP = !ASM_ONLY && QCAP != 0 && ((HMPC_MFMA_SWEEP && SM::MFS2 && QCAP < NMAX) || (HMPC_MFMA_SWEEP1 && SM::MFS1));
+  // (the 60-variable variants are fast-pass only: the safe pass of two-contact batches runs on the 120-variable safe variants)
   // ... and the fast three-contact variant (180 variables, two blocks per thread): 78 tiles, 20 per wave.  Its staging of H holds
   // the block-diagonals in two passes, so the register blocks are filled as for the scalar sweeps and turned into tiles in stage S.
   constexpr bool MFMA_SWEEP3 = HMPC_MFMA_SWEEP3 && SM::MFS3 && !ASM_ONLY && QCAP != 0 && QCAP < NMAX;
@@ -1676,16 +1692,29 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         return A.Hs[hs_index<NMAX>(vi < vj ? vi : vj, vi < vj ? vj : vi)];
       }
     };
-    MfsPanel<8> &PN = *reinterpret_cast<MfsPanel<8> *>(&Q.ST[0][0]);
-    static_assert(sizeof(MfsPanel<8>) <= sizeof(Q.ST), "the pivot panels live in the (not yet used) mat-vec staging");
+    constexpr int NTG1 = (NMAX + 15) / 16;
+    // the pivot panels live in LDS that the solver does not use yet: the mat-vec staging, or (60 variables: that is too small)
+    // the area of the Schur inverse
+    constexpr bool PN_IN_ST = sizeof(MfsPanel<NTG1>) <= sizeof(Q.ST);
+    static_assert(PN_IN_ST || (!SM::EGLOBAL && sizeof(MfsPanel<NTG1>) <= sizeof(Q.Ep)), "room for the pivot panels");
+    void *pnp = nullptr;
+    if constexpr (PN_IN_ST) pnp = &Q.ST[0][0];
+    else pnp = &Q.Ep[0];
+    MfsPanel<NTG1> &PN = *reinterpret_cast<MfsPanel<NTG1> *>(pnp);
     double *stage = reinterpret_cast<double *>(&S.u);
-    static_assert(sizeof(S.u) / sizeof(double) >= 48 * 121, "re-layout staging of the matrix-core sweeps: 48 rows of M at stride 121");
+    static_assert(sizeof(S.u) / sizeof(double) >= 48 * (NMAX + 1), "re-layout staging of the matrix-core sweeps: 48 rows of M at stride NMAX + 1");
     const bool live0 = owner_r[0] && e1_r[0] < ng;
-    switch (wv) {  // uniform: per-wave specialised code
-      case 0: mfma_sweeps<0, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
-      case 1: mfma_sweeps<1, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
-      case 2: mfma_sweeps<2, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
-      default: mfma_sweeps<3, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
+    if constexpr (NW == 4) {
+      switch (wv) {  // uniform: per-wave specialised code
+        case 0: mfma_sweeps<NTG1, 4, 0, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
+        case 1: mfma_sweeps<NTG1, 4, 1, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
+        case 2: mfma_sweeps<NTG1, 4, 2, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
+        default: mfma_sweeps<NTG1, 4, 3, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
+      }
+    } else {
+      static_assert(NW == 2 || NW == 4, "per-wave code of the matrix-core sweeps");
+      if (wv == 0) mfma_sweeps<NTG1, 2, 0, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a);
+      else mfma_sweeps<NTG1, 2, 1, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a);
     }
   } else if constexpr (MFMA_SWEEP3) {
     // ---- the same on the tiles filled in stage A5
