@@ -2,16 +2,13 @@
 # rocprofv3 passes for profiles/<round>/ (one gpurun call).  Passes are kept separate: kernel trace + stats, then one
 # --pmc pass per counter group (TCC slots do not fit both FETCH and WRITE; counters are never combined with other trace
 # domains).  scripts/summarize_rocprof.py turns the output into the tracked summaries.
-#  (1) bench lines: headline (default two launch streams, with the CPU baseline), walking, h=20 single support
+#  (1) bench lines: headline (default two launch streams, with the CPU baseline), walking, h=20 single support (run last, see below)
 #  (2) headline workload, --streams 1: kernel trace + stats, PMC passes (HBM traffic, SQ counters, fp64 instruction mix)
 #  (3) headline workload, DEFAULT two streams: kernel trace (start/end of consecutive dispatches: the overlap the value uses)
 #  (4) every other kernel variant (walking 60 variables, h=20 single support, three contacts, wide double support):
 #      kernel trace + stats and one SQ counter pass each
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/rocprof; rm -rf gpurun_out/rocprof/*; export TMPDIR=/tmp
 O=gpurun_out/rocprof
-python bench.py --steps 20 --warmup 3 > $O/bench_standing.json 2> $O/bench.err
-python bench.py --steps 20 --warmup 3 --gait walking --no-cpu-baseline > $O/bench_walking.json 2>> $O/bench.err
-python bench.py --steps 10 --warmup 2 --horizon 20 --gait single --batch 4096 --no-cpu-baseline > $O/bench_h20_single.json 2>> $O/bench.err
 CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side-configs --check 0 --streams 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $CMD > $O/kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- $CMD > $O/pmc_fetch.log 2>&1
@@ -32,6 +29,13 @@ python scripts/phase_profile.py single 20 4096 >> $O/phase_cycles.txt 2>/dev/nul
 python scripts/phase_profile.py standing 10 2048 3 >> $O/phase_cycles.txt 2>/dev/null
 python scripts/dev/latency_vs_batch.py 2>/dev/null | grep -v amdgpu > $O/latency_vs_batch.txt
 python scripts/soak.py > $O/soak.txt 2>&1
+# (1) last: the bench lines read profiles/hbm_traffic.json, which only counts for the build it was taken on -- refresh it
+# from the PMC passes above first (on this box's copy of the tree; the caller runs the summary again on its own copy)
+ROUND=${1:-r04}
+python scripts/summarize_rocprof.py $ROUND > /dev/null 2>&1
+python bench.py --steps 20 --warmup 3 > $O/bench_standing.json 2> $O/bench.err
+python bench.py --steps 20 --warmup 3 --gait walking --no-cpu-baseline > $O/bench_walking.json 2>> $O/bench.err
+python bench.py --steps 10 --warmup 2 --horizon 20 --gait single --batch 4096 --no-cpu-baseline > $O/bench_h20_single.json 2>> $O/bench.err
 find $O -name '*.db' -delete
 find $O -name '*_agent_info.csv' -delete
 cat $O/bench_standing.json | cut -c1-600
