@@ -426,6 +426,12 @@ def main() -> None:
 
     dev = torch.device("cuda", local_rank)
     d_rec = torch.from_numpy(rec).to(dev)                      # inputs resident in HBM before the timed region
+    # ... and the SAME instances one 5 ms MPC tick later (synthetic.advance_tick: body moved, velocities drifted, feet stayed):
+    # every handle alternates between the two tick batches, so that whatever the library carries from one solve to the next --
+    # by default the dispatch order, hmpc_set_dispatch_order: longest previous solve first -- is one tick old, as in an MPC
+    # loop, and never the exact answer to the same data
+    rec_next = records.pack_records(synthetic.advance_tick(fields, h, seed=7 + 1000 * rank), h, nc)
+    d_rec_next = torch.from_numpy(rec_next).to(dev)
     # Two handles on two streams, each with its own output block, used alternately: the tail of one step's launch (the last,
     # partly filled round of workgroups) and the launch gap overlap the head of the next step's.  Every step still is one
     # complete pass of the hot path over the whole batch; --streams 1 times strictly back-to-back launches on one stream.
@@ -451,11 +457,18 @@ def main() -> None:
     xch = sharding.WrenchExchange(B, W, dev, always_collective=args.force_exchange) \
         if ((world > 1 or args.force_exchange) and args.exchange == "wrench") else None
     nstep = [0]
+    uses = [0] * nstream
+
+    def solve_on(k):  # handle k's next solve: the other tick batch than its last one
+        d_in = d_rec_next if uses[k] % 2 else d_rec
+        uses[k] += 1
+        mpcs[k].set_device_records(d_in.data_ptr(), B, max_reduced_vars=n_red, keepalive=(d_rec, d_rec_next))
+        mpcs[k].solve(streams[k].cuda_stream)
 
     def step():
         k = nstep[0] % nstream
         with torch.cuda.stream(streams[k]):
-            mpcs[k].solve(streams[k].cuda_stream)
+            solve_on(k)
             if xch is not None:
                 xch.post(k, d_forces_l[k], d_status_l[k])  # slot = launch stream: never reused while that stream's step owns it
             elif world > 1:
@@ -501,13 +514,36 @@ def main() -> None:
     # reported beside the headline value
     torch.cuda.synchronize()
     ts0 = time.perf_counter()
-    for _ in range(args.steps):
-        mpcs[0].solve(stream)
+    with torch.cuda.stream(streams[0]):
+        for _ in range(args.steps):
+            solve_on(0)
     torch.cuda.synchronize()
     single_stream_s = time.perf_counter() - ts0
 
-    # dominant kernel's own duration: HIP events on the launch stream, kernel launches only (no collective)
-    kernel_ms = mpc.time_solve(max(5, args.steps), stream)
+    # the headline loop once more in natural dispatch order (hmpc_set_dispatch_order(0)): what the ordering is worth
+    natural_s = None
+    if xch is None and world == 1:
+        for m in mpcs:
+            m.set_dispatch_order(False)
+        for _ in range(max(2, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        tn0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        natural_s = time.perf_counter() - tn0
+        for m in mpcs:
+            m.set_dispatch_order(True)
+
+    # dominant kernel's own duration: HIP events on the launch stream, kernel launches only (no collective); tick batch `rec`
+    # ordered by the solve of the other tick batch before it, as in the timed loop
+    mpc.set_device_records(d_rec_next.data_ptr(), B, max_reduced_vars=n_red, keepalive=(d_rec, d_rec_next))
+    mpc.solve(stream)
+    mpc.set_device_records(d_rec.data_ptr(), B, max_reduced_vars=n_red, keepalive=(d_rec, d_rec_next))
+    mpc.solve(stream)
+    torch.cuda.synchronize()
+    kernel_ms = mpc.time_solve(max(5, args.steps), stream)   # (leaves handle 0's outputs = the solution of `rec`: checked below)
 
     status = d_status.cpu().numpy().astype(np.uint32)
     n_fail = int((interface.status_code(status) != 0).sum())
@@ -572,7 +608,8 @@ def main() -> None:
             "dtype": "f32 assembly / f64 solve", "data": "synthetic",
             "config": {"workload": (f"{'2-contact standing' if args.gait == 'standing' else args.gait} randomized MPC ticks, " if nc == 2 else
                                     f"3-contact (two feet + hand, BASELINE config 5 extension) randomized MPC ticks, feet {args.gait}, ") +
-                                   f"horizon {h}, reduced QP up to {n_red}x{n_red // 6 * 8}; records and forces device-resident in/out",
+                                   f"horizon {h}, reduced QP up to {n_red}x{n_red // 6 * 8}; records and forces device-resident in/out; "
+                                   "two batches of the same instances one 5 ms tick apart, solved alternately",
                        "batch_per_gpu": B, "global_batch": world * B, "horizon": h, "contacts": nc,
                        "exchange_backend": (args.backend + (" (TEST transport: host-staged, ranks may share a GPU)" if args.backend == "gloo" else " (RCCL)"))
                        if (world > 1 or args.force_exchange) else None,
@@ -594,6 +631,13 @@ def main() -> None:
                               "note": "this rank's K passes launched back to back on one stream, no exchange; the headline value "
                                       "alternates two streams (config.launch_streams) so that the partly filled last round of "
                                       "workgroups of one launch overlaps the next launch"},
+            "dispatch_order": {
+                "mode": "longest previous solve first (hmpc_set_dispatch_order, the library's default for 512 < batch <= 32768)",
+                "hint": "each handle's solve is ordered on the device by the iteration counts of ITS previous solve, which was of "
+                        "the same instances one tick apart (the other of the two tick batches) -- never of the same data; the sort "
+                        "(one small launch) is inside the timed region; results do not depend on the order",
+                "natural_order": None if natural_s is None else {"value": world * B * args.steps / natural_s,
+                                                                 "ms_per_step": 1e3 * natural_s / args.steps}},
             "fp64_valu_frac": fp64_tf / FP64_VALU_PEAK_TF,
             "fp64_valu": {"achieved": fp64_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                           "useful_flop_per_solve": fp64_flop,
@@ -623,19 +667,40 @@ def main() -> None:
                 _, st2 = m2.download()
                 extra[name] = {"solves_per_s": bb / (ms2 * 1e-3), "kernel_ms": ms2,
                                "failed": int((interface.status_code(st2) != 0).sum())}
+                m2.set_dispatch_order(False)
+                ms2n = m2.time_solve(10, stream)
+                extra[name]["natural_order"] = {"solves_per_s": bb / (ms2n * 1e-3), "kernel_ms": ms2n}
                 m2.close()
             # BASELINE configs[4]: two feet + hand, 180 variables x 240 rows (the three-contact extension)
             for name, bb in (("cfg5_3contact_180x240_b2048_per_gpu", 2048), ("cfg5_3contact_180x240_b8192", 8192)):
                 f3 = synthetic.make_batch3(bb, 10, "standing", seed=5, hand="contact")
                 m3 = interface.BatchedMPC(synthetic.DT_MPC, 10, synthetic.F_MAX, bb, device=local_rank, contacts=3)
-                m3.upload(records.pack_records(f3, 10, 3))
+                rec3 = records.pack_records(f3, 10, 3)
+                m3.upload(rec3)
                 m3.solve(stream)
                 torch.cuda.synchronize()
                 ms3 = m3.time_solve(5, stream)
                 _, st3 = m3.download()
                 extra[name] = {"solves_per_s": bb / (ms3 * 1e-3), "kernel_ms": ms3,
                                "failed": int((interface.status_code(st3) != 0).sum())}
+                m3.set_dispatch_order(False)
+                ms3n = m3.time_solve(5, stream)
+                extra[name]["natural_order"] = {"solves_per_s": bb / (ms3n * 1e-3), "kernel_ms": ms3n}
+                # the hint one tick old instead of exact: solve tick k, time ONE solve of tick k+1
+                m3.set_dispatch_order(True)
+                rec3n = records.pack_records(synthetic.advance_tick(f3, 10, seed=9), 10, 3)
+                t3 = []
+                for _ in range(4):
+                    m3.upload(rec3)
+                    m3.solve(stream)
+                    torch.cuda.synchronize()
+                    m3.upload(rec3n)
+                    t3.append(m3.time_solve(1, stream))
+                extra[name]["next_tick"] = {"solves_per_s": bb / (min(t3) * 1e-3), "kernel_ms": min(t3)}
                 m3.close()
+            extra["dispatch_order_note"] = ("side configs re-solve ONE batch: their dispatch order (longest previous solve first, the "
+                                            "default) comes from the previous solve of the same data; `natural_order` = "
+                                            "hmpc_set_dispatch_order(0), `next_tick` = ordered by the solve of the batch one tick earlier")
             # rows f1+f2 -> solve -> f3 as ONE device-resident entry (hmpc_tick_solve_device): tick structs in HBM in, joint
             # torques in HBM out, no host call between the launches; every instance routed on the device to the smallest
             # kernel variant that holds it (walking ticks run on the 60-variable kernel without any host hint)

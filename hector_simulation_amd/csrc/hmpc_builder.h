@@ -146,6 +146,33 @@ __global__ __launch_bounds__(256) void classify_records_kernel(const unsigned ch
   cls[inst] = (unsigned char)(cnt > 255 ? 255 : cnt);
 }
 
+// Longest-first dispatch (hmpc_set_dispatch_order): the instances of the batch ordered by the active-set iterations their
+// PREVIOUS solve took (status word bits 8-19), most first -- a counting sort by one workgroup (64 buckets, iterations >= 63
+// share the first).  The solve kernels then take instance order[blockIdx.x]: the hardware starts workgroups in index
+// order, so the long solves start first and the short ones fill the last, partly occupied round of workgroup slots.  The
+// position inside a bucket is decided by atomics and may differ from run to run -- that only changes which slot an
+// instance runs in, never its result.
+__global__ __launch_bounds__(1024) void dispatch_order_kernel(const uint32_t *status, int batch, int *order) {
+  __shared__ int cnt[64], start[64];
+  const int tid = threadIdx.x;
+  if (tid < 64) cnt[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < batch; i += 1024) {
+    const int it = (int)((status[i] >> 8) & 0xFFFu);
+    atomicAdd(&cnt[it > 63 ? 63 : it], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int b = 63; b >= 0; --b) start[b] = run, run += cnt[b];
+  }
+  __syncthreads();
+  for (int i = tid; i < batch; i += 1024) {
+    const int it = (int)((status[i] >> 8) & 0xFFFu);
+    order[atomicAdd(&start[it > 63 ? 63 : it], 1)] = i;
+  }
+}
+
 // thread g -> (instance g/12, leg (g%12)/6, row (g%6)): f_ff = -rBody * [GRF; GRM]
 __global__ __launch_bounds__(256) void body_wrench_kernel(const float *forces, int batch, int h, const double *rBody,
                                                           double *f_ff) {

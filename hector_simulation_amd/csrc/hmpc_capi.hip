@@ -132,6 +132,11 @@ struct hmpc_handle {
   const float *d_ext_H, *d_ext_g, *d_ext_Fc;
   int ext_ld;
   int iter_cap;  // hmpc_set_max_iterations: cap on the active-set iterations of every solve (0 = the variant's own bound)
+  // hmpc_set_dispatch_order: 1 = workgroups take the instances longest-previous-solve first (d_order, rebuilt at the head of
+  // every solve from the status words the previous solve of a batch of the same size left; order_batch = that size, 0 = none)
+  int dispatch_order, order_batch;
+  bool order_valid;
+  int *d_order;
   // size classes of a device-resident batch whose widest reduced QP the host was not told (hmpc_set_max_reduced_vars < 0):
   // stance leg-steps per instance, written on the device by the record builder (cls_valid) or, for records handed in by
   // pointer, by classify_records_kernel at the head of every solve
@@ -141,6 +146,9 @@ struct hmpc_handle {
   double *d_escratch;
   size_t e_bytes;
 };
+// longest-first dispatch (hmpc_set_dispatch_order, on by default): only where a launch has a tail to shorten -- more instances
+// than the ~512-1536 workgroup slots of the chip -- and not beyond what the one-workgroup sort handles in a few microseconds
+constexpr int DISPATCH_ORDER_MIN_BATCH = 512, DISPATCH_ORDER_MAX_BATCH = 32768;
 constexpr int REPAIR_GRID_CAP = 2048;  // workgroups of the device-side safe launch = most instances it can repair per solve
 constexpr int REPAIR_GRID_CAP_WIDE = 256;  // ... of the wide variant's, whose safe pass keeps 231 KB per workgroup in global memory
 
@@ -205,6 +213,7 @@ struct LaunchOpt {
   bool carry_wset = true;  // false keeps a repeated launch of the same batch from consuming/advancing the tick-to-tick working sets
   const unsigned int *d_list_count = nullptr;
   bool record_flagged = false;
+  bool longest_first = false;  // workgroup b takes instance h->d_order[b] (enqueue_solve, hmpc_set_dispatch_order)
   int variant = -1;        // -1 = pick_variant; else this entry of variants() (the size-class launches)
   bool ultimate = false;   // safe pass, second level (three contacts): the variant whose working set cannot overflow
   int cls_lo = 0, cls_hi = -1;  // cls_hi >= 0: only instances whose size class lies in [cls_lo, cls_hi] (h->d_cls)
@@ -258,6 +267,7 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   a.prof = h->d_prof;
   a.warm = (o.warm < 0) ? h->warm : o.warm;
   a.index_list = o.d_index_list;
+  if (!o.d_index_list && !o.assemble_only && o.longest_first) a.index_list = h->d_order;
   a.wset = (h->tick_warm && !o.assemble_only && o.carry_wset) ? h->d_wset : nullptr;
   a.flagged = h->d_flagged;
   a.wset_shift = h->tick_shift;
@@ -289,9 +299,20 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
 static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
   const bool repair = h->device_repair != 0;
   if (repair) HIP_TRY(hipMemsetAsync(h->d_flag_count, 0, sizeof(unsigned int), stream));
+  // longest-first dispatch: only where the tail of a launch matters (small and medium batches) and the previous solve was of
+  // a batch of this size (the caller's contract: instance i of this tick is instance i of the last one)
+  h->order_valid = false;
+  if (h->dispatch_order == 1 && h->d_order && h->order_batch == h->batch && h->batch > DISPATCH_ORDER_MIN_BATCH &&
+      h->batch <= DISPATCH_ORDER_MAX_BATCH) {
+    hipLaunchKernelGGL(hmpc::dispatch_order_kernel, dim3(1), dim3(1024), 0, stream, h->d_status, h->batch, h->d_order);
+    HIP_TRY(hipGetLastError());
+    h->order_valid = true;
+  }
+  h->order_batch = h->batch;
   LaunchOpt o;
   o.carry_wset = carry_wset;
   o.record_flagged = repair;
+  o.longest_first = h->order_valid;
   int rc = HMPC_OK;
   if (h->nc == 2 && h->max_stance < 0 && h->d_cls) {
     if (!h->cls_valid) {
@@ -428,6 +449,12 @@ int hmpc_create_ex(hmpc_handle **out, const struct problem_setup *setup, int max
     hmpc_destroy(h);
     return HMPC_E_HIP;
   }
+  h->dispatch_order = 1;
+  if (max_batch > DISPATCH_ORDER_MIN_BATCH && hipMalloc(&h->d_order, (size_t)max_batch * sizeof(int)) != hipSuccess) {
+    g_hip_err = "hipMalloc failed in hmpc_create";
+    hmpc_destroy(h);
+    return HMPC_E_HIP;
+  }
   h->d_records = h->d_records_own;
   h->d_forces = h->d_forces_own;
   h->d_status = h->d_status_own;
@@ -452,6 +479,7 @@ int hmpc_destroy(hmpc_handle *h) {
   if (h->d_flag_list) hipFree(h->d_flag_list);
   if (h->d_flag_count) hipFree(h->d_flag_count);
   if (h->d_cls) hipFree(h->d_cls);
+  if (h->d_order) hipFree(h->d_order);
   if (h->d_escratch) hipFree(h->d_escratch);
   delete h;
   return HMPC_OK;
@@ -521,6 +549,18 @@ int hmpc_set_device_records(hmpc_handle *h, const void *device_records, int batc
 int hmpc_set_max_reduced_vars(hmpc_handle *h, int n_reduced) {
   if (!h) return HMPC_E_ARG;
   h->max_stance = n_reduced;
+  return HMPC_OK;
+}
+
+int hmpc_set_dispatch_order(hmpc_handle *h, int mode) {
+  if (!h || (mode != 0 && mode != 1)) return HMPC_E_ARG;
+  if (mode == 1 && !h->d_order && h->max_batch > DISPATCH_ORDER_MIN_BATCH) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMalloc(&h->d_order, (size_t)h->max_batch * sizeof(int)));
+  }
+  h->dispatch_order = mode;
+  h->order_batch = 0;  // the next solve runs in natural order and leaves the iteration counts the one after it sorts by
+  h->order_valid = false;
   return HMPC_OK;
 }
 

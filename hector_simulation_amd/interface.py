@@ -141,6 +141,11 @@ class BatchedMPC:
         """Cap on the active-set iterations (0 = none); the nWSR analogue (include/hector_mpc.h hmpc_set_max_iterations)."""
         _check(self.L.hmpc_set_max_iterations(self.h, int(max_iter)), "hmpc_set_max_iterations")
 
+    def set_dispatch_order(self, longest_first: bool) -> None:
+        """Start the instances whose previous solve took most iterations first (include/hector_mpc.h
+        hmpc_set_dispatch_order); results do not depend on it."""
+        _check(self.L.hmpc_set_dispatch_order(self.h, 1 if longest_first else 0), "hmpc_set_dispatch_order")
+
     def tick_solve_device(self, ticks_ptr: int, batch: int, dt_mpc: float, tau_ptr: int, f_ff_ptr: int = 0, wpd_ptr: int = 0,
                           stream: int = 0) -> None:
         """f1+f2 -> solve -> f3 on one stream, everything device-resident (include/hector_mpc.h hmpc_tick_solve_device)."""

@@ -176,6 +176,19 @@ int hmpc_reset_tick_warm_start(hmpc_handle *h);
  * profiles/r04/stress.txt): every instance qpOASES solves ends HMPC_S_OK.  *n_resolved (may be NULL) = how many were
  * re-solved.  hmpc_download does this automatically unless hmpc_set_auto_resolve(h, 0). */
 int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved);
+/* Dispatch order of the workgroups of a solve.  mode 1 (default), longest first: the instances are started in the order of
+ * the active-set iterations their PREVIOUS solve took (most first; read on the device from the status words the previous
+ * solve of this handle left, one small sorting launch at the head of each solve).  An MPC tick resembles the tick before it,
+ * so the solves that will run longest start first and the short ones fill the last, partly occupied round of workgroup
+ * slots -- what bounds small and medium batches is that tail (2 048 three-contact instances are four rounds of 512 resident
+ * workgroups and one 87-iteration straggler: 1.18 M solves/s in natural order, 1.66 M with a hint one tick old).  mode 0:
+ * instance b runs in workgroup b.  Results do not depend on the mode, nor on whether the assumption holds (instance i of
+ * this solve = instance i of the previous one, as for hmpc_set_tick_warm_start): any status words give a valid order, a
+ * stale one merely stops helping.  The first solve of a handle, the first after a change of the batch size, batches of at
+ * most 512 instances (they fit the chip's workgroup slots at once) and of more than 32 768 run in natural order.
+ * The reference has no counterpart (one QP per call). */
+int hmpc_set_dispatch_order(hmpc_handle *h, int mode);
+
 /* Cap on the active-set iterations of every later solve of the handle -- the analogue of the reference's nWSR = 500
  * (SolverMPC.cpp:706).  0 (default) = the kernel variant's own bound.  Block rounds and switch passes of the block start
  * count as one iteration each and always complete; the cap is tested before every single-row iteration after them.  An
