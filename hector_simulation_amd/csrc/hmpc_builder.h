@@ -153,23 +153,43 @@ __global__ __launch_bounds__(256) void classify_records_kernel(const unsigned ch
 // position inside a bucket is decided by atomics and may differ from run to run -- that only changes which slot an
 // instance runs in, never its result.
 __global__ __launch_bounds__(1024) void dispatch_order_kernel(const uint32_t *status, int batch, int *order) {
-  __shared__ int cnt[64], start[64];
-  const int tid = threadIdx.x;
-  if (tid < 64) cnt[tid] = 0;
+  // per-wave counters: a batch whose iteration counts all fall into two or three buckets (walking) would otherwise send every
+  // one of its atomics to the same few LDS words (measured: 15 us for 8 192 instances; ~2 us this way)
+  __shared__ int cnt[16][64];
+  __shared__ int base[64];
+  const int tid = threadIdx.x, wv = tid >> 6;
+  cnt[wv][tid & 63] = 0;
   __syncthreads();
   for (int i = tid; i < batch; i += 1024) {
     const int it = (int)((status[i] >> 8) & 0xFFFu);
-    atomicAdd(&cnt[it > 63 ? 63 : it], 1);
+    atomicAdd(&cnt[wv][it > 63 ? 63 : it], 1);
+  }
+  __syncthreads();
+  if (tid < 64) {
+    int tot = 0;
+    for (int w = 0; w < 16; ++w) tot += cnt[w][tid];
+    base[tid] = tot;
   }
   __syncthreads();
   if (tid == 0) {
     int run = 0;
-    for (int b = 63; b >= 0; --b) start[b] = run, run += cnt[b];
+    for (int b = 63; b >= 0; --b) {
+      const int t = base[b];
+      base[b] = run, run += t;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    int run = base[tid];
+    for (int w = 0; w < 16; ++w) {
+      const int t = cnt[w][tid];
+      cnt[w][tid] = run, run += t;
+    }
   }
   __syncthreads();
   for (int i = tid; i < batch; i += 1024) {
     const int it = (int)((status[i] >> 8) & 0xFFFu);
-    order[atomicAdd(&start[it > 63 ? 63 : it], 1)] = i;
+    order[atomicAdd(&cnt[wv][it > 63 ? 63 : it], 1)] = i;
   }
 }
 

@@ -302,8 +302,11 @@ static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
   // longest-first dispatch: only where the tail of a launch matters (small and medium batches) and the previous solve was of
   // a batch of this size (the caller's contract: instance i of this tick is instance i of the last one)
   h->order_valid = false;
+  // (... and not for batches known to hold single-support QPs only: those solve in one or two iterations, there is nothing to
+  //  sort and the extra launch costs a walking batch 1-4 %)
+  const bool small_qps_only = h->nc == 2 && h->max_stance >= 0 && h->max_stance <= 60;
   if (h->dispatch_order == 1 && h->d_order && h->order_batch == h->batch && h->batch > DISPATCH_ORDER_MIN_BATCH &&
-      h->batch <= DISPATCH_ORDER_MAX_BATCH) {
+      h->batch <= DISPATCH_ORDER_MAX_BATCH && !small_qps_only) {
     hipLaunchKernelGGL(hmpc::dispatch_order_kernel, dim3(1), dim3(1024), 0, stream, h->d_status, h->batch, h->d_order);
     HIP_TRY(hipGetLastError());
     h->order_valid = true;

@@ -185,7 +185,8 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved);
  * instance b runs in workgroup b.  Results do not depend on the mode, nor on whether the assumption holds (instance i of
  * this solve = instance i of the previous one, as for hmpc_set_tick_warm_start): any status words give a valid order, a
  * stale one merely stops helping.  The first solve of a handle, the first after a change of the batch size, batches of at
- * most 512 instances (they fit the chip's workgroup slots at once) and of more than 32 768 run in natural order.
+ * most 512 instances (they fit the chip's workgroup slots at once), of more than 32 768, and batches known to hold
+ * single-support QPs only (<= 60 reduced variables: one or two iterations each, nothing to sort) run in natural order.
  * The reference has no counterpart (one QP per call). */
 int hmpc_set_dispatch_order(hmpc_handle *h, int mode);
 
