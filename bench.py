@@ -5,6 +5,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Both forms run N ranks, one per GPU: started WITHOUT torchrun (no WORLD_SIZE in the environment) and N > 1, bench.py
+re-executes itself under `python -m torch.distributed.run --nproc-per-node N` (127.0.0.1, a free port) and passes the
+ranks' exit code on -- it never silently runs one GPU.  It exits non-zero, with the reason on stderr, when fewer than N
+devices are visible or when --gpus disagrees with the WORLD_SIZE it was launched with.
+The multi-GPU configurations of BASELINE.json:
+    python bench.py --gpus 8 --gait walking                  # config 3: 8 x 8 192 walking sweep
+    python bench.py --gpus 4 --contacts 3 --batch 2048       # config 5: 4 x 2 048 three-contact QPs
+(`--backend gloo` is a TEST transport that lets the N ranks share GPUs: `python bench.py --gpus 2 --backend gloo` on a
+one-GPU box runs the N = 2 code path, every rank checking its own shard.)
+
 A "step" is one pass of the hot path (assembly + QP solve, one kernel launch) over one batch of synthetic MPC
 instances whose packed records already live in HBM (consecutive steps alternate between two launch streams / two output
 blocks, --streams 1 for strictly serial launches); for N > 1 every rank owns a contiguous shard of the global batch
@@ -77,6 +87,26 @@ def cpu_worker(path: str, horizon: int, first: int, count: int, kind: str = "ref
 def _run_worker(path, horizon, first, count, kind):
     return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(horizon), str(first),
                              str(count), kind], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+
+
+def device_description(torch, local_rank: int) -> dict:
+    """Which physical device a rank ran on (the scaling line lists one per rank: two ranks on one device would show)."""
+    pr = torch.cuda.get_device_properties(local_rank)
+    d = {"local_rank_device": int(local_rank), "name": pr.name}
+    for k in ("pci_bus_id", "pci_device_id", "pci_domain_id", "uuid", "gcnArchName", "multi_processor_count"):
+        v = getattr(pr, k, None)
+        if v is not None:
+            d[k] = v if isinstance(v, (int, str)) else str(v)
+    d["visible_devices_env"] = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    return d
+
+
+def rccl_version(torch):
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as exc:  # the line must not depend on it
+        return repr(exc)
 
 
 def host_description() -> dict:
@@ -351,6 +381,35 @@ def merge_parity(per_rank: list) -> dict:
     return out
 
 
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` without torchrun: N ranks all the same.  Re-executes this file under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a free port) and returns its exit code.
+    Fewer than N visible devices is an error (exit code 2), not a one-GPU run -- unless the ranks are allowed to share
+    devices (--backend gloo, the test transport)."""
+    import socket
+
+    import torch
+
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU: the solve path has no CPU fallback", file=sys.stderr)
+        return 2
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and args.backend != "gloo":
+        print(f"[bench] ERROR: --gpus {args.gpus} but only {ndev} GPU(s) visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?): "
+              f"refusing to report an n_gpus={args.gpus} line from fewer devices.  (--backend gloo is the TEST transport that "
+              "lets ranks share a device.)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HMPC_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs across processes on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("[bench] --gpus %d without torchrun: launching %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6] if len(sys.argv) > 6 else "reference")
@@ -383,6 +442,11 @@ def main() -> None:
                     help="solve = the metric (default); builder = rows f1-f3 only (record builder + wrench kernels)")
     ap.add_argument("--check", type=int, default=256, help="instances checked against the oracle after the timed region")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started without torchrun: N ranks all the same (never a silent one-GPU run that prints n_gpus = 1)
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -394,8 +458,16 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the solve path has no CPU fallback")
+    if args.gpus != world:
+        # launched under torchrun with another rank count than --gpus asks for: a line whose n_gpus contradicts its command
+        raise SystemExit(f"[bench] ERROR: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         "(or plain `python bench.py --gpus N`, which starts the N ranks itself)")
+    ndev = torch.cuda.device_count()
     if args.backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()  # test transport: ranks may share a device
+        local_rank = local_rank % ndev  # test transport: ranks may share a device
+    elif local_rank >= ndev:
+        raise SystemExit(f"[bench] ERROR: rank {rank} (LOCAL_RANK {local_rank}) has no GPU: {ndev} device(s) visible for "
+                         f"{world} ranks -- RCCL needs one device per rank (--backend gloo is the device-sharing TEST transport)")
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -412,8 +484,6 @@ def main() -> None:
         else:
             dist.init_process_group(backend="gloo")
     n_gpus = world
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     h, B, nc = args.horizon, args.batch, args.contacts
     W = 6 * nc  # forces per horizon step = width of the step-0 wrench the exchange carries
@@ -553,7 +623,8 @@ def main() -> None:
     # every rank checks ITS OWN shard against the oracle; the line carries the worst over the ranks
     parity = None
     mine_summary = {"parity": parity_of_rank(args, rank, rec, fields, h, nc, mpc, d_forces, status) if args.check > 0 else None,
-                    "exchange_ok": exchange_check, "failed": n_fail, "kernel_ms": kernel_ms}
+                    "exchange_ok": exchange_check, "failed": n_fail, "kernel_ms": kernel_ms,
+                    "device": device_description(torch, local_rank), "iters_mean": float(iters.mean()), "iters_max": int(iters.max())}
     summaries = [mine_summary]
     if world > 1:
         summaries = [None] * world
@@ -614,6 +685,11 @@ def main() -> None:
                        "exchange_backend": (args.backend + (" (TEST transport: host-staged, ranks may share a GPU)" if args.backend == "gloo" else " (RCCL)"))
                        if (world > 1 or args.force_exchange) else None,
                        "launch_streams": nstream,
+                       "world": world, "launcher": ("bench.py re-executed itself under torch.distributed.run (--gpus N without torchrun)"
+                                                    if os.environ.get("HMPC_BENCH_SELF_LAUNCHED") else
+                                                    ("torch.distributed.run (external)" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1 else "python (single process)")),
+                       "devices_visible": ndev, "rank_devices": [sm["device"] for sm in summaries],
+                       "rccl_version": rccl_version(torch) if (world > 1 or args.force_exchange) else None,
                        "parallelism": (f"batch shards x{world}, all_gather of "
                                        f"{'step-0 wrench + status (overlapped with the next solve)' if xch is not None else 'all forces'}")
                        if world > 1 else ("single GPU" + (", exchange code path forced on (group of one)" if xch is not None else "")),
@@ -645,7 +721,8 @@ def main() -> None:
             "valu_issue_frac": valu_issue_frac,
             "iterations_per_solve": it_mean,
             "solver": {"failed": n_fail, "failed_over_all_ranks": n_fail_all,
-                       "kernel_ms_per_rank": [sm["kernel_ms"] for sm in summaries], "iters_median": float(np.median(iters)), "iters_max": int(iters.max()), "active_median": float(np.median(nact)), "active_max": int(nact.max()),
+                       "kernel_ms_per_rank": [sm["kernel_ms"] for sm in summaries],
+                       "iters_mean_per_rank": [sm["iters_mean"] for sm in summaries], "iters_max_per_rank": [sm["iters_max"] for sm in summaries], "iters_median": float(np.median(iters)), "iters_max": int(iters.max()), "active_median": float(np.median(nact)), "active_max": int(nact.max()),
                        "kernel_solves_per_s": B / (kernel_ms * 1e-3)},
         }
         # the other BASELINE.json shapes on the same kernel family, a few launches each (not the headline value)

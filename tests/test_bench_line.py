@@ -122,3 +122,54 @@ def test_bench_two_ranks_on_one_gpu(name, extra, batch):
     if name == "cfg5_three_contact":
         assert p["vs_reference_source_end_to_end"] is None  # the reference has no code for this shape
         assert "180x240" in d["config"]["workload"]
+
+
+def test_bench_gpus_n_without_gpu_is_an_error_not_a_one_gpu_run():
+    if _has_gpu():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_n_launches_n_ranks_by_itself():
+    """`python bench.py --gpus 2` WITHOUT torchrun: bench.py re-executes itself under
+    torch.distributed.run and the line says n_gpus = 2 with one parity block per rank -- on the one-GPU test box over the gloo
+    TEST transport (both ranks on device 0)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4",
+                        "--warmup", "1", "--batch", "1024", "--check", "16"], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world"] == 2 and d["config"]["global_batch"] == 2048
+    assert "re-executed itself" in d["config"]["launcher"]
+    assert len(d["config"]["rank_devices"]) == 2 and len(d["solver"]["kernel_ms_per_rank"]) == 2
+    assert d["parity"]["ranks_checked"] == 2 and d["parity"]["max_rel_force_err_vs_qpoases"] < 1e-4
+    assert d["config"]["exchange_selfcheck_ok"] is True and d["solver"]["failed_over_all_ranks"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_more_gpus_than_visible_fails_loudly():
+    """--gpus 8 on a box with fewer devices: non-zero exit and the reason on stderr, never an n_gpus line from fewer GPUs."""
+    import torch
+
+    n = torch.cuda.device_count()
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 7), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert "visible" in r.stderr and f"--gpus {n + 7}" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    # ... and --gpus that contradicts the torchrun it was launched under is an error as well
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env2)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
