@@ -44,8 +44,9 @@ MFMA_F32_PEAK_TF = 157.3
 FP64_VALU_PEAK_TF = 78.6                   # vector fp64 = half the fp32 vector rate of MI355X_MICROARCH.md (157.3 / 2)
 
 
-def cpu_worker(path: str, horizon: int, first: int, count: int, kind: str = "reference") -> None:
-    """One CPU-baseline process over instances [first, first+count) of the saved field arrays.
+def cpu_worker(path: str, horizon: int, first: int, count: int, kind: str = "reference", repeat: int = 1) -> None:
+    """One CPU-baseline process over instances [first, first+count) of the saved field arrays, `repeat` times over (the timed
+    region covers all passes: a sample of the wanted wall time from a slice of the batch).
 
     kind "reference": the reference's OWN source end to end -- setup_problem / update_problem_data / get_solution of
     oracle/_ref/libsolvempc_ref.so (ConvexMPC/SolverMPC.cpp + RobotState.cpp + convexMPC_interface.cpp compiled
@@ -64,13 +65,14 @@ def cpu_worker(path: str, horizon: int, first: int, count: int, kind: str = "ref
         log = path + f".stdout.{first}"
         ref_py.silence_forever(log)
         t0 = time.perf_counter()
-        q = ref_py.solve_fields(f, horizon, synthetic.DT_MPC, 0.25, synthetic.F_MAX, first=first, count=count)
+        for _ in range(max(1, repeat)):
+            q = ref_py.solve_fields(f, horizon, synthetic.DT_MPC, 0.25, synthetic.F_MAX, first=first, count=count)
         t1 = time.perf_counter()
         ref_py.flush_stdio()
         with open(log, "rb") as fh:
             n_failed_lines = fh.read().count(b"failed to solve!")
         os.unlink(log)
-        os.write(2, (json.dumps(dict(count=count, wall=t1 - t0,
+        os.write(2, (json.dumps(dict(count=count * max(1, repeat), wall=t1 - t0,
                                      n_bad=int(n_failed_lines + np.isnan(q).any(axis=1).sum()))) + "\n").encode())
         return
     from oracle import oracle_py
@@ -84,9 +86,9 @@ def cpu_worker(path: str, horizon: int, first: int, count: int, kind: str = "ref
                                  nwsr_hist=np.bincount(np.minimum(r["nwsr"] // 10, 9), minlength=10).tolist())) + "\n").encode())
 
 
-def _run_worker(path, horizon, first, count, kind):
+def _run_worker(path, horizon, first, count, kind, repeat=1):
     return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(horizon), str(first),
-                             str(count), kind], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+                             str(count), kind, str(repeat)], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
 
 
 def device_description(torch, local_rank: int) -> dict:
@@ -146,9 +148,14 @@ def host_description() -> dict:
     return d
 
 
-def cpu_baseline(fields: dict, horizon: int, per_core: int) -> dict:
+def cpu_baseline(fields: dict, horizon: int, per_core: int, target_s: float = 10.0, sweep_s: float = 3.0, reps: int = 3) -> dict:
     """Reference CPU path timed on the host cores as PROCESSES (qpOASES has a process-global message handler), with a
-    sweep over the process count P so that the line says where the box saturates."""
+    sweep over the process count P so that the line says where the box saturates.
+
+    Quotable: the point at P = `cores` is the MEDIAN of `reps` runs of >= `target_s` seconds of
+    wall time each (every process passes over its own slice of the batch as often as that takes; the passes are inside the
+    timed region), min and max beside it; every sweep point runs >= `sweep_s` seconds.  A 1.8-second sample swung 2x from
+    run to run."""
     from oracle import ref_py
 
     host = host_description()
@@ -160,45 +167,65 @@ def cpu_baseline(fields: dict, horizon: int, per_core: int) -> dict:
     cores = max(1, min(avail, usable, 64))
     nb = int(np.asarray(fields["p"]).shape[0])
     per_core = max(1, min(per_core, nb // cores))
-    total = per_core * cores
     kind = "reference" if ref_py.available() else "port"
     last = lambda p: json.loads(p.communicate()[1].strip().splitlines()[-1])
 
-    def run_p(path, P, per):
+    def run_p(path, P, per, repeat):
         t0 = time.perf_counter()
-        procs = [_run_worker(path, horizon, c * per, per, kind) for c in range(P)]
+        procs = [_run_worker(path, horizon, c * per, per, kind, repeat) for c in range(P)]
         res = [last(p) for p in procs]
         return res, time.perf_counter() - t0
 
+    def timed_point(path, P, per, want_s, rate_guess):
+        """one run of about want_s seconds at P processes: the repeat count comes from the current rate estimate (per process)"""
+        repeat = max(1, int(np.ceil(want_s * max(rate_guess, 1e-9) / per)))
+        res, wall = run_p(path, P, per, repeat)
+        inner = max(r["wall"] for r in res)  # slowest worker, excluding interpreter start-up
+        return dict(processes=P, solves=P * per * repeat, inner_s=inner, wall_s=wall, solves_per_s=P * per * repeat / inner,
+                    per_process=per * repeat / inner, n_bad=sum(r["n_bad"] for r in res))
+
+    t_start = time.perf_counter()
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "fields.npz")
-        per_sweep = max(8, min(per_core, 128))  # (0.3-0.4 s of solves per process: shorter samples were dominated by start-up noise)
-        n_saved = min(nb, max(total, 32 * per_sweep))
+        n_saved = min(nb, max(per_core * cores, 64 * 64))
         np.savez(path, **{k: np.asarray(v)[:n_saved] for k, v in fields.items()})
         # P = 1: one process alone on the box (the reference's own operating point: one controller, one core)
-        solo_n = min(96, total)
-        solo = last(_run_worker(path, horizon, 0, solo_n, kind))
+        solo_n = min(96, n_saved)
+        cal = last(_run_worker(path, horizon, 0, solo_n, kind))         # calibration pass (also warms the page cache)
+        solo_rate0 = solo_n / cal["wall"]
+        solo = timed_point(path, 1, solo_n, sweep_s, solo_rate0)
         solo_port = last(_run_worker(path, horizon, 0, solo_n, "port"))
-        # P-sweep on a smaller sample per process (same instances for every P: process c takes slice c)
+        solo_rate = solo["solves_per_s"]
+        # P-sweep (same instances for every P: process c takes slice c), >= sweep_s seconds per point
         sweep = []
+        guess = solo_rate
         for P in (2, 4, 8, 16, 32, 64):
             if P == cores or P > min(avail, 4 * cores):  # up to 4x oversubscription of the usable CPUs: shows the plateau
                 continue
-            per = min(per_sweep, n_saved // P)
-            r, _ = run_p(path, P, per)
-            sweep.append({"processes": P, "solves_per_s": P * per / max(x["wall"] for x in r),
-                          "per_process": per / max(x["wall"] for x in r)})
-        res, wall = run_p(path, cores, per_core)
-    inner = max(r["wall"] for r in res)  # slowest worker, excluding interpreter start-up
-    solo_rate = solo_n / solo["wall"]
-    sweep = sorted([{"processes": 1, "solves_per_s": solo_rate, "per_process": solo_rate}] + sweep +
-                   [{"processes": cores, "solves_per_s": total / inner, "per_process": per_core / inner}],
-                   key=lambda x: x["processes"])
+            per = max(8, min(per_core, 128, n_saved // P))
+            pt = timed_point(path, P, per, sweep_s, guess * (0.9 if P <= cores else 0.9 * cores / P))
+            guess = pt["per_process"] if P < cores else guess
+            sweep.append(pt)
+        # the quoted point: P = cores, `reps` runs of >= target_s seconds, median
+        runs = []
+        guess_full = min([x["per_process"] for x in sweep if x["processes"] <= cores] or [solo_rate * 0.5])
+        for _ in range(reps):
+            pt = timed_point(path, cores, per_core, target_s, guess_full)
+            guess_full = pt["per_process"]
+            runs.append(pt)
+    rates = sorted(r["solves_per_s"] for r in runs)
+    value = float(np.median(rates))
+    med = min(runs, key=lambda r: abs(r["solves_per_s"] - value))
+    sweep_pts = sorted([{"processes": 1, "solves_per_s": solo_rate, "per_process": solo_rate, "wall_s": solo["inner_s"]}] +
+                       [{"processes": x["processes"], "solves_per_s": x["solves_per_s"], "per_process": x["per_process"],
+                         "wall_s": x["inner_s"]} for x in sweep] +
+                       [{"processes": cores, "solves_per_s": value, "per_process": value / cores, "wall_s": med["inner_s"]}],
+                       key=lambda x: x["processes"])
     # saturation point: the smallest P that already delivers 90 % of the best aggregate rate of the sweep
-    best = max(x["solves_per_s"] for x in sweep)
-    sat = next(x["processes"] for x in sweep if x["solves_per_s"] >= 0.9 * best)
-    eff = (total / inner) / (cores * solo_rate)
-    why = (f"{cores} processes deliver {total / inner / solo_rate:.1f}x one process alone (parallel efficiency {eff:.2f}); the sweep "
+    best = max(x["solves_per_s"] for x in sweep_pts)
+    sat = next(x["processes"] for x in sweep_pts if x["solves_per_s"] >= 0.9 * best)
+    eff = value / (cores * solo_rate)
+    why = (f"{cores} processes deliver {value / solo_rate:.1f}x one process alone (parallel efficiency {eff:.2f}); the sweep "
            f"reaches 90 % of its best aggregate rate at P = {sat}.  ")
     pc, lc = host.get("physical_cores"), host.get("logical_cpus")
     if host.get("cgroup_cpu_max"):
@@ -215,17 +242,21 @@ def cpu_baseline(fields: dict, horizon: int, per_core: int) -> dict:
             "the reference's vendored qpOASES 3.2.0, driven through setup_problem/update_problem_data/get_solution; its "
             "three printed lines per solve go to a scratch file") if kind == "reference" else \
            "oracle C restatement of the fp32 assembly + the reference's own vendored qpOASES 3.2.0 (oracle/_ref), prints removed"
-    return dict(value=total / inner, unit="QP solves/s", cores=cores, kind=kind,
-                sample=f"{total} of the bench's 2-contact h={horizon} instances ({per_core}/process x {cores} processes); " + what,
-                host=host, process_sweep=sweep, saturation_processes=sat, parallel_efficiency_at_all_cores=eff,
+    return dict(value=value, unit="QP solves/s", cores=cores, kind=kind,
+                sample=(f"median of {reps} runs of >= {target_s:.0f} s wall each at {cores} processes: {med['solves']} solves per run "
+                        f"({per_core} of the bench's 2-contact h={horizon} instances per process, passed over "
+                        f"{med['solves'] // (per_core * cores)} times inside the timed region); ") + what,
+                runs_solves_per_s=[r["solves_per_s"] for r in runs], runs_wall_s=[r["inner_s"] for r in runs],
+                value_min=rates[0], value_max=rates[-1], spread=(rates[-1] - rates[0]) / value,
+                host=host, process_sweep=sweep_pts, saturation_processes=sat, parallel_efficiency_at_all_cores=eff,
                 scaling_note=why,
-                single_process_alone_value=solo_rate, single_process_alone_ms=1e3 * solo["wall"] / solo_n,
-                per_process_value_under_full_load=per_core / inner,
+                single_process_alone_value=solo_rate, single_process_alone_ms=1e3 / solo_rate,
+                per_process_value_under_full_load=value / cores,
                 port_single_process_alone_value=solo_n / (solo_port["t_assemble"] + solo_port["t_solve"]),
                 port_single_process_alone_ms={"assemble": 1e3 * solo_port["t_assemble"] / solo_n,
                                               "solve": 1e3 * solo_port["t_solve"] / solo_n},
                 nwsr_median=solo_port["nwsr_med"], nwsr_max=solo_port["nwsr_max"], nwsr_hist_by_10=solo_port["nwsr_hist"],
-                n_failed=sum(r["n_bad"] for r in res), wall_s=wall)
+                n_failed=sum(r["n_bad"] for r in runs), wall_s=time.perf_counter() - t_start)
 
 
 def bench_shard(rank: int, batch: int, horizon: int, gait: str, contacts: int = 2):
@@ -412,7 +443,8 @@ def self_launch(args, argv) -> int:
 
 def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
-        cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6] if len(sys.argv) > 6 else "reference")
+        cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6] if len(sys.argv) > 6 else "reference",
+                   int(sys.argv[7]) if len(sys.argv) > 7 else 1)
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -438,6 +470,9 @@ def main() -> None:
                     help="run the N>1 code path (process group, posted all_gather per solve, stream ordering) with whatever "
                          "WORLD_SIZE is -- also 1: what the one-GPU test of the torchrun path uses")
     ap.add_argument("--cpu-per-core", type=int, default=384)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0,
+                    help="wall time of each of the three CPU-baseline runs at P = cores (the quoted value is their median); the "
+                         "P-sweep points run 0.3x this")
     ap.add_argument("--path", default="solve", choices=["solve", "builder"],
                     help="solve = the metric (default); builder = rows f1-f3 only (record builder + wrench kernels)")
     ap.add_argument("--check", type=int, default=256, help="instances checked against the oracle after the timed region")
@@ -894,7 +929,7 @@ def main() -> None:
         if parity is not None:
             out["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fields, h, args.cpu_per_core)
+            out["cpu_baseline"] = cpu_baseline(fields, h, args.cpu_per_core, target_s=args.cpu_seconds, sweep_s=0.3 * args.cpu_seconds)
         print(json.dumps(out), flush=True)
     for m in mpcs:
         m.close()

@@ -1,24 +1,39 @@
 """In-tree build of libhector_mpc_hip.so (hipcc, gfx950 only; cross-compiles without a GPU).
 
+The kernel family is compiled as HMPC_VARIANT_GROUPS translation units side by side (csrc/hmpc_variants.hip with
+-DHMPC_VARIANT_GROUP=k) next to the two host-side ones, then linked: ~25 s instead of the 60 s of one serial unit.
 Staleness is decided by a content hash of the sources (kept next to the library), not by mtimes -- a snapshot copied to
 another box keeps the prebuilt library valid -- and builds are serialised by a file lock so that N ranks started by
 torchrun never compile into the same file at once."""
 from __future__ import annotations
 
+import concurrent.futures
 import fcntl
 import hashlib
 import os
 import shutil
 import subprocess
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhector_mpc_hip.so")
-SOURCES = ["hmpc_capi.hip", "hmpc_group.hip"]
-DEPS = ["hmpc_capi.hip", "hmpc_group.hip", "hmpc_kernel.h", "hmpc_math.h", "hmpc_builder.h", os.path.join("..", "..", "include", "hector_mpc.h")]
+VARIANT_GROUPS = 4  # = HMPC_VARIANT_GROUPS of csrc/hmpc_variants.h
+HOST_SOURCES = ["hmpc_capi.hip", "hmpc_group.hip"]
+DEPS = ["hmpc_capi.hip", "hmpc_group.hip", "hmpc_variants.hip", "hmpc_variants.h", "hmpc_kernel_args.h", "hmpc_kernel.h",
+        "hmpc_math.h", "hmpc_builder.h", os.path.join("..", "..", "include", "hector_mpc.h")]
 # -ffp-contract=off is part of the numerical contract (HMPC-A1): every fused multiply-add in the source is explicit
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value",
-         "-Wno-pass-failed", "-ldl"] + os.environ.get("HMPC_EXTRA_FLAGS", "").split()  # developer switches, e.g. -DHMPC_WAVES_PER_EU_256=2
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"]
+EXTRA = os.environ.get("HMPC_EXTRA_FLAGS", "").split()  # developer A/B switches, e.g. -DHMPC_MFMA_SWEEP=0 (same results, other code)
+FLAGS = CFLAGS + EXTRA
+
+
+def _check_flags() -> None:
+    """-DHMPC_DEV_TIMING unlocks switches that leave stages of the kernel out (wrong numbers, right timing): never for the
+    library the package loads, unless the developer says so explicitly (HMPC_ALLOW_DEV_TIMING=1, scripts/phase experiments)."""
+    if any(f.startswith("-DHMPC_DEV_TIMING") for f in EXTRA) and os.environ.get("HMPC_ALLOW_DEV_TIMING") != "1":
+        raise RuntimeError("HMPC_EXTRA_FLAGS contains -DHMPC_DEV_TIMING (wrong-numbers timing switches): refused for the product "
+                           "library; set HMPC_ALLOW_DEV_TIMING=1 for a throw-away timing build")
 
 
 def source_hash() -> str:
@@ -43,9 +58,22 @@ def needs_build() -> bool:
         return True
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def compile_commands(objdir: str, hipcc: str) -> list:
+    """(object path, command) of every translation unit."""
+    units = []
+    for s in HOST_SOURCES:
+        o = os.path.join(objdir, s.replace(".hip", ".o"))
+        units.append((o, [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]))
+    for g in range(VARIANT_GROUPS):
+        o = os.path.join(objdir, f"hmpc_variants_{g}.o")
+        units.append((o, [hipcc] + FLAGS + [f"-DHMPC_VARIANT_GROUP={g}", "-c", os.path.join(CSRC, "hmpc_variants.hip"), "-o", o]))
+    return units
+
+
+def build(force: bool = False, verbose: bool = False, extra_compile_flags: list | None = None) -> str:
     if not force and not needs_build():
         return LIB
+    _check_flags()
     lock_path = LIB + ".lock"
     with open(lock_path, "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
@@ -54,10 +82,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 return LIB
             hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
             tmp = LIB + f".tmp{os.getpid()}"
-            cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            with tempfile.TemporaryDirectory(prefix="hmpc_obj_") as objdir:
+                units = compile_commands(objdir, hipcc)
+                if extra_compile_flags:
+                    units = [(o, c[:1] + list(extra_compile_flags) + c[1:]) for o, c in units]
+
+                def run(unit):
+                    if verbose:
+                        print(" ".join(unit[1]), flush=True)
+                    subprocess.check_call(unit[1])
+                    return unit[0]
+
+                with concurrent.futures.ThreadPoolExecutor(max_workers=len(units)) as ex:
+                    objs = list(ex.map(run, units))
+                link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", tmp]
+                if verbose:
+                    print(" ".join(link), flush=True)
+                subprocess.check_call(link)
             os.replace(tmp, LIB)
             with open(_stamp_path(), "w") as f:
                 f.write(source_hash())

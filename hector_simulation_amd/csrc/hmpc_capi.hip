@@ -15,7 +15,8 @@
 #include <vector>
 
 #include "../../include/hector_mpc.h"
-#include "hmpc_kernel.h"
+#include "hmpc_kernel_args.h"
+#include "hmpc_variants.h"
 #include "hmpc_builder.h"
 
 namespace {
@@ -31,24 +32,7 @@ thread_local std::string g_hip_err;
     }                                                                                                    \
   } while (0)
 
-#ifndef HMPC_QCAP_FAST
-#define HMPC_QCAP_FAST 64  // working-set capacity of the fast 120-variable h <= 10 variant (49 KB LDS: three per CU)
-#endif
-#ifndef HMPC_QCAP_WIDE
-#define HMPC_QCAP_WIDE 152 // ... of the 240-variable variant (double support over h = 11 .. 20)
-#endif
-#ifndef HMPC_QCAP_3C
-#define HMPC_QCAP_3C 96    // ... of the fast three-contact variant (256 threads, two register blocks each, <= 80 KB LDS: two per CU)
-#endif
-typedef void (*kernel_fn)(hmpc::KernelArgs);
-
-struct Variant {
-  int nmax, hmax, nt, qcap, nc;
-  kernel_fn solve, assemble;
-  size_t smem;
-  int dbg_floats;
-};
-
+// The kernel family (instantiated in hmpc_variants.hip, one translation unit per group so that the build runs in parallel).
 // NMAX = reduced variables held on chip (6 per stance leg-step); 120 -> 256-thread workgroups (210 register blocks),
 // 60 (single support over h <= 10) -> 128-thread workgroups (55 blocks).  QCAP = working-set capacity: the fast variants
 // hold 64 rows (49-50 KB LDS, 168 VGPRs: three workgroups per CU, also at h = 20); the "safe"
@@ -57,22 +41,10 @@ struct Variant {
 // The extension with a third (hand) contact -- BASELINE config 5, 180 variables x 240 rows at h = 10 -- runs 256-thread
 // workgroups with two register blocks per thread (465 blocks, two workgroups per CU; round 2: 512 threads, one per CU --
 // still the shape of its safe pass).  BPT = blocks per thread, see hmpc_kernel.h.
-template <int NMAX, int HMAX, int NT, int QCAP, int NC = 2, int BPT = 1>
-Variant make_variant() {
-  static_assert(sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>) <= 160 * 1024, "LDS budget of a gfx950 CU");
-  static_assert(BPT == 1 || NT >= 512 || sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>) <= 80 * 1024, "two workgroups per CU");
-  return Variant{NMAX, HMAX, NT, QCAP, NC, hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, false, NC, BPT>,
-                 hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, true, NC, BPT>, sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>),
-                 hmpc::DbgLayout<NMAX, NC>::TOTAL};
-}
-
 const Variant *variants() {
-  static const Variant v[] = {make_variant<60, 10, 128, 60>(),   make_variant<120, 10, 256, HMPC_QCAP_FAST>(),
-                              make_variant<60, 20, 128, 60>(),   make_variant<120, 20, 256, HMPC_QCAP_FAST>(),
-                              make_variant<120, 10, 256, 120>(), make_variant<120, 20, 256, 120>(),
-                              make_variant<180, 10, 256, HMPC_QCAP_3C, 3, 2>(), make_variant<180, 10, 512, 140, 3>(),
-                              make_variant<180, 10, 512, 100, 3>(), make_variant<240, 20, 512, HMPC_QCAP_WIDE, 2, 2>(),
-                              make_variant<240, 20, 512, 0, 2, 2>(),   make_variant<180, 10, 512, 0, 3>()};
+  static const Variant v[] = {hmpc_variant_0(), hmpc_variant_1(), hmpc_variant_2(),  hmpc_variant_3(),
+                              hmpc_variant_4(), hmpc_variant_5(), hmpc_variant_6(),  hmpc_variant_7(),
+                              hmpc_variant_8(), hmpc_variant_9(), hmpc_variant_10(), hmpc_variant_11()};
   return v;
 }
 constexpr int N_FAST = 4;       // two-contact fast variants [0, N_FAST), their safe variants N_FAST + (h > 10)
@@ -150,6 +122,7 @@ struct hmpc_handle {
 // than the ~512-1536 workgroup slots of the chip -- and not beyond what the one-workgroup sort handles in a few microseconds
 constexpr int DISPATCH_ORDER_MIN_BATCH = 512, DISPATCH_ORDER_MAX_BATCH = 32768;
 constexpr int REPAIR_GRID_CAP = 2048;  // workgroups of the device-side safe launch = most instances it can repair per solve
+constexpr int EGLOBAL_CHUNK = 512;         // host-driven safe pass of the global-E variants: instances per launch (118 MB of scratch at 240 variables)
 constexpr int REPAIR_GRID_CAP_WIDE = 256;  // ... of the wide variant's, whose safe pass keeps 231 KB per workgroup in global memory
 
 // returns a device buffer of at least `bytes` owned by the handle (contents undefined)
@@ -217,6 +190,7 @@ struct LaunchOpt {
   int variant = -1;        // -1 = pick_variant; else this entry of variants() (the size-class launches)
   bool ultimate = false;   // safe pass, second level (three contacts): the variant whose working set cannot overflow
   int cls_lo = 0, cls_hi = -1;  // cls_hi >= 0: only instances whose size class lies in [cls_lo, cls_hi] (h->d_cls)
+  int safe_variant = -1;   // safe pass over an index list: this entry of variants() instead of the one derived from pick_variant
 };
 
 static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
@@ -224,16 +198,21 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   const Variant *pv = &pick_variant(h, &vi);
   if (o.variant >= 0) vi = o.variant, pv = &variants()[vi];
   if (o.d_index_list) {  // safe variant: working set as large as the variable count
-    if (vi == V2_WIDE) vi = V2_WIDE_SAFE;                  // ... which for 240 variables only global memory holds
+    if (o.safe_variant >= 0) vi = o.safe_variant;
+    else if (vi == V2_WIDE) vi = V2_WIDE_SAFE;             // ... which for 240 variables only global memory holds
     else if (h->nc == 3) vi = o.ultimate ? V3_SAFE_G : V3_SAFE;
     else vi = (h->setup.horizon <= 10) ? N_FAST : N_FAST + 1;
     pv = &variants()[vi];
   }
   const Variant &v = *pv;
-  const int grid = o.assemble_only ? 1 : (o.d_index_list ? o.n_list : h->batch);
-  if (grid < 1) return HMPC_OK;
+  const int grid_all = o.assemble_only ? 1 : (o.d_index_list ? o.n_list : h->batch);
+  if (grid_all < 1) return HMPC_OK;
+  // EGLOBAL variants keep NMAX (NMAX + 1) / 2 doubles of global scratch per WORKGROUP (231 KB for 240 variables): a host-driven
+  // safe pass over thousands of flagged instances goes through the list in chunks that reuse one bounded buffer (stream order
+  // keeps the chunks apart).  The device-driven pass (d_list_count) is one launch, capped by its caller.
+  const int chunk = (v.qcap == 0 && o.d_index_list && !o.d_list_count && grid_all > EGLOBAL_CHUNK) ? EGLOBAL_CHUNK : grid_all;
   if (v.qcap == 0) {  // EGLOBAL: one slice of packed triangle per workgroup of this launch
-    const size_t need = (size_t)grid * ((size_t)v.nmax * (v.nmax + 1) / 2) * sizeof(double);
+    const size_t need = (size_t)chunk * ((size_t)v.nmax * (v.nmax + 1) / 2) * sizeof(double);
     if (need > h->e_bytes) {
       if (h->d_escratch) {
         HIP_TRY(hipStreamSynchronize(stream));  // (an earlier launch on this stream may still be using the old buffer)
@@ -281,9 +260,31 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   a.cls = (o.cls_hi >= 0) ? h->d_cls : nullptr;
   a.cls_lo = o.cls_lo, a.cls_hi = o.cls_hi;
   a.e_scratch = h->d_escratch;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(v.nt), v.smem, stream, a);
-  HIP_TRY(hipGetLastError());
+  for (int off = 0; off < grid_all; off += chunk) {
+    const int grid = (grid_all - off < chunk) ? grid_all - off : chunk;
+    if (off > 0) a.index_list = o.d_index_list + off;  // (only list launches are ever chunked)
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(v.nt), v.smem, stream, a);
+    HIP_TRY(hipGetLastError());
+  }
   return HMPC_OK;
+}
+
+// The safe pass over a list of flagged instances.  Where the host knows the batch's widest reduced QP (or the family has one safe
+// variant) that is one launch.  A two-contact batch at h > 10 whose sizes only the DEVICE knows (records built on the device or
+// handed in by pointer: max_stance < 0) may hold both <= 120-variable instances and double-support ones with up to 240: the list
+// is then run twice, once per safe variant, each workgroup leaving at once unless its instance's size class belongs to the
+// variant -- a wide instance must never reach the 120-variable kernel (it would end as HMPC_S_TOO_LARGE with zero forces, which
+// nothing re-solves).
+static int launch_safe(hmpc_handle *h, hipStream_t stream, LaunchOpt s) {
+  if (h->nc == 2 && h->max_stance < 0 && h->setup.horizon > 10 && h->d_cls) {
+    s.safe_variant = N_FAST + 1, s.cls_lo = 0, s.cls_hi = 20;
+    int rc = launch(h, stream, s);
+    if (rc != HMPC_OK) return rc;
+    s.safe_variant = V2_WIDE_SAFE, s.cls_lo = 21, s.cls_hi = 255;
+    if (s.d_list_count && s.n_list > REPAIR_GRID_CAP_WIDE) s.n_list = REPAIR_GRID_CAP_WIDE;  // (one launch: bounded scratch)
+    return launch(h, stream, s);
+  }
+  return launch(h, stream, s);
 }
 
 // One solve of the current batch, enqueued on `stream` -- what hmpc_solve does and what hmpc_time_solve times:
@@ -350,7 +351,7 @@ static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
   s.warm = 0;
   s.carry_wset = carry_wset;
   s.d_list_count = h->d_flag_count;
-  return launch(h, stream, s);
+  return launch_safe(h, stream, s);
 }
 
 extern "C" {
@@ -672,7 +673,7 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
   // the safe pass starts cold, as the reference does (launch parameter; the handle's own setting is not touched)
   LaunchOpt so;
   so.d_index_list = d_idx, so.n_list = (int)idx.size(), so.warm = 0;
-  int rc = launch(h, h->last_stream, so);
+  int rc = launch_safe(h, h->last_stream, so);
   if (rc != HMPC_OK) return rc;
   HIP_TRY(hipStreamSynchronize(h->last_stream));
   if (n_resolved) *n_resolved = (int)idx.size();
@@ -705,7 +706,7 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
     if (still.empty()) break;
     HIP_TRY(hipMemcpy(d_idx, still.data(), still.size() * sizeof(int), hipMemcpyHostToDevice));
     so.n_list = (int)still.size(), so.relax = relax_levels[lvl];
-    rc = launch(h, h->last_stream, so);
+    rc = launch_safe(h, h->last_stream, so);
     if (rc != HMPC_OK) return rc;
     HIP_TRY(hipStreamSynchronize(h->last_stream));
   }
@@ -1062,6 +1063,7 @@ static int g_q_len = 0;
 static int g_has_solved = 0;
 static uint32_t g_last_status = 0;
 static int g_setup_error = 0;
+static int g_legacy_iter_cap = 0;  // hmpc_legacy_set_max_iterations: explicit opt-in (update_solver_settings is inert, as in the reference)
 // one tick = one pinned staging buffer [record | 12h forces | status word] and one contiguous device output block, so that
 // a blocking tick costs one asynchronous H2D copy, one launch, one asynchronous D2H copy and a single synchronisation
 static unsigned char *g_pin = nullptr;
@@ -1144,7 +1146,7 @@ static void solve_global(void) {
   const uint32_t *pst = (const uint32_t *)(forces + 12 * hz);
   const size_t out_bytes = sizeof(float) * 12 * hz + sizeof(uint32_t);
   uint32_t st = 0;
-  hmpc_set_max_iterations(g_handle, g_update.max_iterations > 0 ? g_update.max_iterations : 0);
+  hmpc_set_max_iterations(g_handle, g_legacy_iter_cap);
   int rc = hmpc_upload_records_async(g_handle, rec, 1, nullptr);  // pinned source: a true asynchronous copy
   if (rc == HMPC_OK) rc = hmpc_solve(g_handle, nullptr);
   if (rc == HMPC_OK && (hipMemcpyAsync(g_pin + g_pin_rec_bytes, g_dev_out, out_bytes, hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
@@ -1198,17 +1200,22 @@ double get_solution(int index) {
 
 void update_solver_settings(int max_iter, double rho, double sigma, double solver_alpha, double terminate,
                             double use_jcqp) {
-  // stored as the reference stores them (convexMPC_interface.cpp:112-118, where nothing reads them: the qpOASES path has no
-  // use for the JCQP/ADMM knobs).  The one with a meaning for an active-set solver is honoured here: max_iter > 0 caps the
-  // active-set iterations of every later legacy solve -- the analogue of the reference's nWSR = 500 (SolverMPC.cpp:706);
-  // a tick that would need more reports HMPC_S_MAXITER (and the "failed to solve!" line).  0 (the reference's zero-
-  // initialised global) = no cap.  rho, sigma, solver_alpha, terminate, use_jcqp have no counterpart and stay unread.
+  // Stored exactly as the reference stores them (convexMPC_interface.cpp:112-118) -- and, as in the reference, read by
+  // NOTHING: its qpOASES path runs with a fixed nWSR (SolverMPC.cpp:706) whatever max_iter says, so a caller that passes a
+  // small JCQP/ADMM-style max_iter (the knobs belong to a solver the reference does not ship) gets full solves there and
+  // must get them here.  The opt-in with a meaning for this solver is hmpc_legacy_set_max_iterations / hmpc_set_max_iterations.
   g_update.max_iterations = max_iter;
   g_update.rho = rho;
   g_update.sigma = sigma;
   g_update.solver_alpha = solver_alpha;
   g_update.terminate = terminate;
   (void)use_jcqp;
+}
+
+int hmpc_legacy_set_max_iterations(int max_iter) {
+  if (max_iter < 0) return HMPC_E_ARG;
+  g_legacy_iter_cap = max_iter;
+  return HMPC_OK;
 }
 
 void hmpc_solve_mpc(struct update_data_t *update, struct problem_setup *setup) {

@@ -37,67 +37,8 @@
 
 #include "hmpc_math.h"
 
-namespace hmpc {
+#include "hmpc_kernel_args.h"
 
-struct KernelArgs {
-  const unsigned char *records;
-  int stride, batch, horizon;
-  float dt, f_max;
-  float *forces;     // [batch][12h]
-  uint32_t *status;  // [batch]
-  double *x64;       // optional [batch][12h]
-  double *obj64;     // optional [batch]
-  // assembly-only debug dump (hmpc_debug_assemble)
-  int dbg_index;
-  float *dbg_f;
-  int *dbg_i;
-  long long *prof;  // optional [batch][NPROF] per-phase shader-clock cycles (thread 0's view), profiling builds only
-  const int *index_list;  // optional: workgroup b solves instance index_list[b] (re-solve of flagged instances)
-  int warm;         // 1: block warm start of the working set (default), 0: cold start as the reference does
-  // warm start across ticks (the reference cold-starts, SolverMPC.cpp:702): per instance the
-  // final working set of the previous solve, one signed byte per ORIGINAL constraint row (8 nc h; +1 lower side,
-  // -1 upper side, 0 inactive).  Read at the start (rows of step i are taken from saved step min(i + wset_shift, h-1)),
-  // overwritten at the end.  nullptr = off.
-  signed char *wset;
-  int wset_shift;
-  // Last-resort pass for instances stuck at a degenerate vertex (hmpc_resolve_failed): every bound is moved outward by
-  // relax * (1 + frac(0.618 row)) -- a different amount per row, which separates the coinciding vertices.  0 = exact.
-  double relax;
-  // optional device counter: +1 for every instance this launch leaves flagged for the safe pass (working set full,
-  // max-iter, infeasible, KKT); lets hmpc_download skip the status scan when nothing was flagged
-  unsigned int *flagged;
-  // Device-side safe pass (hmpc_set_device_repair): a fast launch appends the index of every instance it flags to
-  // flag_list[0 .. flag_cap) through the per-launch counter flag_count; the safe launch that follows on the same stream
-  // takes flag_list as its index_list and list_count = flag_count, so that workgroups beyond the count leave at once --
-  // no host round trip between the two launches.
-  int *flag_list;
-  unsigned int *flag_count;
-  int flag_cap;
-  const unsigned int *list_count;
-  // Parity hook (hmpc_debug_solve_external_qp): QP data handed in instead of assembled -- per instance the reduced Hessian
-  // [ext_ld][ext_ld] and gradient [ext_ld] in the reference's reduced order (binary32 values, as the reference's own H_red /
-  // g_red are widened floats; the upper triangle is read) and the per-step constraint block [8 NC][6 NC]
-  // (SolverMPC.cpp:466-548 fmat).  The record still supplies the gait table (structure) and f_max; stages S, W, Q run
-  // unchanged.  nullptr = off (the product path).
-  const float *ext_H, *ext_g, *ext_Fc;
-  int ext_ld;
-  // cap on the active-set iterations, the analogue of the reference's nWSR = 500 (SolverMPC.cpp:706): 0 = the variant's own
-  // bound.  Block rounds and switch passes count as one iteration each; the block start itself always completes (it is one
-  // inversion that stands for ~20 single-row iterations; checking the cap inside it costs the 168-VGPR variant spills),
-  // the cap is tested before every single-row iteration after it.  A solve that would need more ends as S_MAXITER.
-  int iter_cap;
-  // Size classes (device-resident batches whose widest reduced QP the host does not know): cls[inst] = stance leg-steps of
-  // the instance, written by build_records_kernel / classify_records_kernel; a workgroup leaves at once unless
-  // cls_lo <= cls[inst] <= cls_hi, so that every variant of the family is launched over the whole batch and each instance
-  // is solved by the smallest one that holds it -- no host round trip.  nullptr = every workgroup runs.
-  const unsigned char *cls;
-  int cls_lo, cls_hi;
-  // scratch for the variants that keep the packed Schur inverse in global memory (Smem::EGLOBAL): NMAX (NMAX + 1) / 2
-  // doubles per WORKGROUP of the launch (indexed by blockIdx.x)
-  double *e_scratch;
-};
-constexpr int NPROF = 32;
-enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A, P_A0, P_A1, P_A2, P_G };
 #ifdef HMPC_PROFILE
 #define PROF_DECL long long _pt = clock64(), _pt0 = _pt; long long _pacc[NPROF] = {0}
 #define PROF_MARK(ph) do { long long _n = clock64(); _pacc[ph] += _n - _pt; _pt = _n; } while (0)
@@ -108,12 +49,7 @@ enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, 
 #define PROF_FLUSH()
 #endif
 
-// offsets (in floats) of the debug dump, shared with the host
-template <int NMAX, int NC = 2>
-struct DbgLayout {
-  static constexpr int H = 0, G = NMAX * NMAX, FC = G + NMAX, LB = FC + 48 * NC * NC, UB = LB + 8 * NC * 20,
-                       X0 = UB + 8 * NC * 20, ACD = X0 + 16, BCD = ACD + 176, TOTAL = BCD + 80 * NC;
-};
+namespace hmpc {
 
 // record field offsets in floats (hector_simulation_amd/records.py).  NC = 2 is the reference's update_data_t; NC = 3 is
 // the extension record with a hand contact (its frame Rhand and force cap travel in the record).
@@ -123,18 +59,9 @@ struct RecLayout {
                        RH = AL + 6 * NC, FMH = RH + 9, NF = (NC == 2) ? RH : FMH + 1;
 };
 
-enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT = 4, S_WORKSET = 5, S_OK_RELAXED = 6 };
 
 constexpr int GS = 6;  // variables per stance leg-step: force (3) then moment (3)
 
-#ifndef HMPC_MFMA_SWEEP1
-// Stage S on the binary64 matrix cores (mfma_sweeps below; HMPC_MFMA_SWEEP, HMPC_MFMA_SWEEP3) for the 60-variable / 128-thread
-// variants as well (4 x 4 tiles on two waves): built, parity-green, and OFF -- stage S + block
-// load cost one workgroup 65 k cycles instead of 81 k, but with six workgroups per CU the kernel as a whole got 1.4 % SLOWER
-// (walking b8192 0.4755 ms against 0.4691): a binary64 matrix instruction holds the SIMD's double-precision pipe for 64 cycles,
-// and the five neighbours' latency-bound phases wait behind it (profiles/r04/mfma_sweep_experiments.txt).
-#define HMPC_MFMA_SWEEP1 0
-#endif
 
 // BPT = register blocks per thread (1: one 6x6 block each, NT >= NG(NG+1)/2; 2: the three-contact variant on 256 threads,
 // 465 blocks, two workgroups per CU -- which also needs its LDS under 80 KB: the staging of H is filled and drained in two
@@ -178,10 +105,9 @@ struct Smem {
   // matrix-core sweeps: power-of-two diagonal scaling, H~ = 2^k H 2^k with k_i = -floor(log2(H_ii) / 2) -- exact in binary
   // floating point in both directions (H_ii spans 2e-4 .. 500; the 4 x 4 pivot blocks of the scaled matrix are far better
   // conditioned than the raw ones, which is what the explicitly inverted pivot block needs)
-  static constexpr bool MFS1 = (NMAX == 60 && NT == 128 && BPT == 1 && NC == 2);   // shapes whose fast variants sweep on the matrix cores
-  static constexpr bool MFS2 = (NMAX == 120 && NT == 256 && BPT == 1 && NC == 2);
+  static constexpr bool MFS2 = (NMAX == 120 && NT == 256 && BPT == 1 && NC == 2);  // shapes whose fast variants sweep on the matrix cores
   static constexpr bool MFS3 = (NMAX == 180 && NT == 256 && BPT == 2 && NC == 3);
-  signed char kexp[((MFS1 && HMPC_MFMA_SWEEP1) || MFS2 || MFS3) ? 16 * ((NMAX + 15) / 16) : 1];
+  signed char kexp[(MFS2 || MFS3) ? 16 * ((NMAX + 15) / 16) : 1];
   unsigned char rmap[U * HMAX];            // original variable U*step+comp -> sweep index (255 = eliminated)
   unsigned char ls_leg[NG], ls_step[NG];
   int n, m, nls, pad0;
@@ -344,6 +270,13 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #endif
 #ifndef HMPC_MFMA_SWEEP3
 #define HMPC_MFMA_SWEEP3 1  // the same for the fast three-contact variant (180 variables, 256 threads, two blocks per thread)
+#endif
+// Developer switches that produce WRONG NUMBERS by design (they leave a stage of the matrix-core sweeps out to time the rest):
+// HMPC_MFS_NO_LDL, HMPC_MFS_NO_STEPS, HMPC_MFS_NO_LOAD, HMPC_MFS_NO_RELAYOUT, HMPC_MFS_ONLY_WAVE.  They compile only together
+// with -DHMPC_DEV_TIMING, which hector_simulation_amd/build.py refuses for the product library (tests/test_abi.py).
+#if (defined(HMPC_MFS_NO_LDL) || defined(HMPC_MFS_NO_STEPS) || defined(HMPC_MFS_NO_LOAD) || defined(HMPC_MFS_NO_RELAYOUT) || \
+     defined(HMPC_MFS_ONLY_WAVE)) && !defined(HMPC_DEV_TIMING)
+#error "HMPC_MFS_NO_* / HMPC_MFS_ONLY_WAVE give wrong results by design: timing builds only, add -DHMPC_DEV_TIMING"
 #endif
 #ifndef HMPC_BLOCK_FRICTION
 #define HMPC_BLOCK_FRICTION 1  // block start also takes friction rows violated at the unconstrained minimiser
@@ -871,8 +804,10 @@ __device__ __forceinline__ void mfs_move_blocks(double (&dst)[BPT][GS][GS], cons
 }
 
 // Stage S in one call for the variants whose staging holds the whole of H at once and whose threads hold one block each (120
-// variables on 256 threads: 8 x 8 tiles on four waves; 60 variables on 128 threads: 4 x 4 tiles on two waves): scaling, tiles,
-// steps, hand-over.
+// variables on 256 threads: 8 x 8 tiles on four waves): scaling, tiles, steps, hand-over.  (The same code for 60 variables on
+// 128 threads -- 4 x 4 tiles on two waves -- was built and measured in round 4: one workgroup's stage 20 % shorter, the kernel
+// 1.4 % SLOWER with six workgroups per CU behind each other's 64-cycle matrix instructions; removed in round 5,
+// profiles/r04/mfma_sweep_experiments.txt keeps the numbers.)
 template <int NTG, int NWV, int WV, int NV, int NT, class HInfo, class HVal>
 __device__ __forceinline__ void mfma_sweeps(MfsPanel<NTG> &PN, double *stage, const int n, HInfo hinfo, HVal hval, signed char *kexp, const int e0,
                                             const int e1, const bool live, double (&a)[1][GS][GS]) {
@@ -1299,7 +1234,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // the nominal input ranges that showed as forces up to 9e-5 from qpOASES in the safe pass (7e-8 with scalar pivots), while
   // nominal inputs are unaffected (5.8e-8 either way) and whatever the fast variants get wrong beyond 2e-6 is caught by
   // their KKT check and handed to the safe pass anyway.
-  constexpr bool MFMA_SWEEP = !ASM_ONLY && QCAP != 0 && ((HMPC_MFMA_SWEEP && SM::MFS2 && QCAP < NMAX) || (HMPC_MFMA_SWEEP1 && SM::MFS1));
+  constexpr bool MFMA_SWEEP = !ASM_ONLY && QCAP != 0 && (HMPC_MFMA_SWEEP && SM::MFS2 && QCAP < NMAX);
   // (the 60-variable variants are fast-pass only: the safe pass of two-contact batches runs on the 120-variable safe variants)
   // ... and the fast three-contact variant (180 variables, two blocks per thread): 78 tiles, 20 per wave.  Its staging of H holds
   // the block-diagonals in two passes, so the register blocks are filled as for the scalar sweeps and turned into tiles in stage S.
@@ -1693,28 +1628,18 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       }
     };
     constexpr int NTG1 = (NMAX + 15) / 16;
-    // the pivot panels live in LDS that the solver does not use yet: the mat-vec staging, or (60 variables: that is too small)
-    // the area of the Schur inverse
-    constexpr bool PN_IN_ST = sizeof(MfsPanel<NTG1>) <= sizeof(Q.ST);
-    static_assert(PN_IN_ST || (!SM::EGLOBAL && sizeof(MfsPanel<NTG1>) <= sizeof(Q.Ep)), "room for the pivot panels");
-    void *pnp = nullptr;
-    if constexpr (PN_IN_ST) pnp = &Q.ST[0][0];
-    else pnp = &Q.Ep[0];
-    MfsPanel<NTG1> &PN = *reinterpret_cast<MfsPanel<NTG1> *>(pnp);
+    // the pivot panels live in LDS that the solver does not use yet: the mat-vec staging
+    static_assert(sizeof(MfsPanel<NTG1>) <= sizeof(Q.ST), "room for the pivot panels");
+    MfsPanel<NTG1> &PN = *reinterpret_cast<MfsPanel<NTG1> *>(&Q.ST[0][0]);
     double *stage = reinterpret_cast<double *>(&S.u);
     static_assert(sizeof(S.u) / sizeof(double) >= 48 * (NMAX + 1), "re-layout staging of the matrix-core sweeps: 48 rows of M at stride NMAX + 1");
     const bool live0 = owner_r[0] && e1_r[0] < ng;
-    if constexpr (NW == 4) {
-      switch (wv) {  // uniform: per-wave specialised code
-        case 0: mfma_sweeps<NTG1, 4, 0, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
-        case 1: mfma_sweeps<NTG1, 4, 1, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
-        case 2: mfma_sweeps<NTG1, 4, 2, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
-        default: mfma_sweeps<NTG1, 4, 3, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
-      }
-    } else {
-      static_assert(NW == 2 || NW == 4, "per-wave code of the matrix-core sweeps");
-      if (wv == 0) mfma_sweeps<NTG1, 2, 0, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a);
-      else mfma_sweeps<NTG1, 2, 1, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a);
+    static_assert(NW == 4, "per-wave code of the matrix-core sweeps: four waves");
+    switch (wv) {  // uniform: per-wave specialised code
+      case 0: mfma_sweeps<NTG1, 4, 0, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
+      case 1: mfma_sweeps<NTG1, 4, 1, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
+      case 2: mfma_sweeps<NTG1, 4, 2, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
+      default: mfma_sweeps<NTG1, 4, 3, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
     }
   } else if constexpr (MFMA_SWEEP3) {
     // ---- the same on the tiles filled in stage A5
@@ -2829,7 +2754,10 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     // with the exact bounds.  Passed: the instance is solved exactly, HMPC_S_OK.  Not passed (the perturbed problem's
     // working set is not optimal for the exact one): the perturbed answer is kept and reported as HMPC_S_OK_RELAXED.
     __syncthreads();
+    const double relax_was = uni_d(S.relax);  // (uniform: scalar registers)
     if (is_v) Q.col[tid] = Q.x[tid];
+    if (tid < q) Q.r[tid] = Q.u[tid];  // (Q.r is free here: the multipliers of the perturbed problem, restored with x below)
+    __syncthreads();
     if (tid == 0) S.relax = 0.0;
     __syncthreads();
     if constexpr (!LAZY) {
@@ -2849,8 +2777,12 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     if (is_v) Q.x[tid] = Q.xu[tid] + Q.z[tid];
     __syncthreads();
     if (!ub(kkt_ok())) {
+      // the perturbed problem's answer is reported as it was: point, multipliers AND bounds (the objective below is formed from
+      // u and the bounds: exact-bound multipliers next to the restored x would describe neither problem)
       __syncthreads();
       if (is_v) Q.x[tid] = Q.col[tid];
+      if (tid < q) Q.u[tid] = Q.r[tid];
+      if (tid == 0) S.relax = relax_was;
       code = S_OK_RELAXED;
       __syncthreads();
     }
@@ -2877,7 +2809,10 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   }
   if (tid == 0) {
     args.status[inst] = (uint32_t)code | ((uint32_t)(iters & 0xfff) << 8) | ((uint32_t)(q & 0xfff) << 20);
-    if (code == S_WORKSET || code == S_MAXITER || code == S_INFEASIBLE || code == S_KKT) {
+    // (an instance that ran into the CALLER'S iteration cap is the caller's answer: it is neither counted nor listed for the
+    //  safe pass -- the device-side repair would otherwise re-solve it cold and overwrite its last iterate)
+    const bool capped = (code == S_MAXITER) && (args.iter_cap > 0 && args.iter_cap < itmax_v);
+    if ((code == S_WORKSET || code == S_MAXITER || code == S_INFEASIBLE || code == S_KKT) && !capped) {
       if (args.flagged) atomicAdd(args.flagged, 1u);
       if (args.flag_count) {
         const unsigned int k = atomicAdd(args.flag_count, 1u);
@@ -2891,7 +2826,13 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       for (int j = 0; j < q; ++j) {
         const int c = Q.Wrow[j], rr = c & 7;
         const double sj = (double)Q.act[c];
-        const double bnd = (sj > 0) ? 0.0 : ((rr == 4) ? (double)0.01f : (rr == 7 ? S.ub7[c >> 3] : 0.0));
+        double bnd = (sj > 0) ? 0.0 : ((rr == 4) ? (double)0.01f : (rr == 7 ? S.ub7[c >> 3] : 0.0));
+        const double rl = S.relax;  // != 0 only for an HMPC_S_OK_RELAXED answer: its bounds are the perturbed ones (row_lo / row_ub_calc)
+        if (rl != 0.0) {
+          const double fr = 0.6180339887498949 * (double)(c + 1);
+          const double dl = rl * (1.0 + (fr - __builtin_floor(fr)));
+          bnd = (sj > 0) ? -dl : bnd + dl * ((rr == 7 && bnd > 1.0) ? bnd : 1.0);
+        }
         o = dfma(0.5 * Q.u[j], sj * bnd, o);
       }
       args.obj64[inst] = o;

@@ -1,0 +1,46 @@
+// hmpc_variants.h -- the table of kernel variants, shared between the host side (hmpc_capi.hip: picks and launches) and
+// hmpc_variants.hip (instantiates; compiled once per group -DHMPC_VARIANT_GROUP=0..3 so that the groups build in parallel).
+#pragma once
+#include <stddef.h>
+
+#include "hmpc_kernel_args.h"
+
+#ifndef HMPC_QCAP_FAST
+#define HMPC_QCAP_FAST 64  // working-set capacity of the fast 120-variable h <= 10 variant (49 KB LDS: three per CU)
+#endif
+#ifndef HMPC_QCAP_WIDE
+#define HMPC_QCAP_WIDE 152 // ... of the 240-variable variant (double support over h = 11 .. 20)
+#endif
+#ifndef HMPC_QCAP_3C
+#define HMPC_QCAP_3C 96    // ... of the fast three-contact variant (256 threads, two register blocks each, <= 80 KB LDS: two per CU)
+#endif
+
+typedef void (*kernel_fn)(hmpc::KernelArgs);
+
+struct Variant {
+  int nmax, hmax, nt, qcap, nc;
+  kernel_fn solve, assemble;
+  size_t smem;
+  int dbg_floats;
+};
+
+// index = position in hmpc_capi.hip's variants(); (NMAX, HMAX, NT, QCAP, NC, BPT), group = translation unit that builds it.
+// The groups are balanced by compile time (the two-blocks-per-thread and 512-thread variants are the slow ones).
+#define HMPC_VARIANT_TABLE(X)                          \
+  X(0, 0, 60, 10, 128, 60, 2, 1)                       \
+  X(1, 0, 120, 10, 256, HMPC_QCAP_FAST, 2, 1)          \
+  X(2, 0, 60, 20, 128, 60, 2, 1)                       \
+  X(3, 1, 120, 20, 256, HMPC_QCAP_FAST, 2, 1)          \
+  X(4, 1, 120, 10, 256, 120, 2, 1)                     \
+  X(5, 1, 120, 20, 256, 120, 2, 1)                     \
+  X(6, 2, 180, 10, 256, HMPC_QCAP_3C, 3, 2)            \
+  X(7, 3, 180, 10, 512, 140, 3, 1)                     \
+  X(8, 2, 180, 10, 512, 100, 3, 1)                     \
+  X(9, 3, 240, 20, 512, HMPC_QCAP_WIDE, 2, 2)          \
+  X(10, 3, 240, 20, 512, 0, 2, 2)                      \
+  X(11, 2, 180, 10, 512, 0, 3, 1)
+constexpr int HMPC_VARIANT_GROUPS = 4;
+
+#define HMPC_DECLARE_VARIANT(IDX, GRP, NMAX, HMAX, NT, QCAP, NC, BPT) Variant hmpc_variant_##IDX();
+HMPC_VARIANT_TABLE(HMPC_DECLARE_VARIANT)
+#undef HMPC_DECLARE_VARIANT

@@ -1,0 +1,48 @@
+// hmpc_variants.hip -- instantiates the kernel family of hmpc_kernel.h.  Built once per group (-DHMPC_VARIANT_GROUP=k,
+// hector_simulation_amd/build.py) into separate objects: the 2 900-line kernel template costs 5-20 s per instantiation, and
+// the twelve variants (x solve / assemble-only) compile side by side instead of in one 60-second translation unit.
+#include <hip/hip_runtime.h>
+
+#include "hmpc_kernel.h"
+#include "hmpc_variants.h"
+
+#ifndef HMPC_VARIANT_GROUP
+#error "compile with -DHMPC_VARIANT_GROUP=0..3 (hector_simulation_amd/build.py does)"
+#endif
+
+namespace {
+template <int NMAX, int HMAX, int NT, int QCAP, int NC, int BPT>
+Variant make_variant() {
+  static_assert(sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>) <= 160 * 1024, "LDS budget of a gfx950 CU");
+  static_assert(BPT == 1 || NT >= 512 || sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>) <= 80 * 1024, "two workgroups per CU");
+  return Variant{NMAX, HMAX, NT, QCAP, NC, hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, false, NC, BPT>,
+                 hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, true, NC, BPT>, sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>),
+                 hmpc::DbgLayout<NMAX, NC>::TOTAL};
+}
+}  // namespace
+
+#define HMPC_DEFINE_VARIANT(IDX, GRP, NMAX, HMAX, NT, QCAP, NC, BPT) HMPC_DEFINE_VARIANT_##GRP(IDX, NMAX, HMAX, NT, QCAP, NC, BPT)
+#define HMPC_DEFINE_IT(IDX, NMAX, HMAX, NT, QCAP, NC, BPT) \
+  Variant hmpc_variant_##IDX() { return make_variant<NMAX, HMAX, NT, QCAP, NC, BPT>(); }
+#define HMPC_SKIP_IT(IDX, NMAX, HMAX, NT, QCAP, NC, BPT)
+#if HMPC_VARIANT_GROUP == 0
+#define HMPC_DEFINE_VARIANT_0 HMPC_DEFINE_IT
+#else
+#define HMPC_DEFINE_VARIANT_0 HMPC_SKIP_IT
+#endif
+#if HMPC_VARIANT_GROUP == 1
+#define HMPC_DEFINE_VARIANT_1 HMPC_DEFINE_IT
+#else
+#define HMPC_DEFINE_VARIANT_1 HMPC_SKIP_IT
+#endif
+#if HMPC_VARIANT_GROUP == 2
+#define HMPC_DEFINE_VARIANT_2 HMPC_DEFINE_IT
+#else
+#define HMPC_DEFINE_VARIANT_2 HMPC_SKIP_IT
+#endif
+#if HMPC_VARIANT_GROUP == 3
+#define HMPC_DEFINE_VARIANT_3 HMPC_DEFINE_IT
+#else
+#define HMPC_DEFINE_VARIANT_3 HMPC_SKIP_IT
+#endif
+HMPC_VARIANT_TABLE(HMPC_DEFINE_VARIANT)

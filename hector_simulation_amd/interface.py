@@ -48,8 +48,14 @@ def get_solution(index: int) -> float:
 
 
 def update_solver_settings(max_iter, rho, sigma, solver_alpha, terminate, use_jcqp) -> None:
+    """Stored and read by nothing, exactly as in the reference (convexMPC_interface.cpp:112-118)."""
     _lib.load().update_solver_settings(int(max_iter), float(rho), float(sigma), float(solver_alpha), float(terminate),
                                        float(use_jcqp))
+
+
+def legacy_set_max_iterations(max_iter: int) -> None:
+    """Explicit opt-in: cap on the active-set iterations of the process-global (legacy) solver; 0 = none."""
+    _check(_lib.load().hmpc_legacy_set_max_iterations(int(max_iter)), "hmpc_legacy_set_max_iterations")
 
 
 def last_status() -> int:

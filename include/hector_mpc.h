@@ -194,8 +194,13 @@ int hmpc_set_dispatch_order(hmpc_handle *h, int mode);
  * (SolverMPC.cpp:706).  0 (default) = the kernel variant's own bound.  Block rounds and switch passes of the block start
  * count as one iteration each and always complete; the cap is tested before every single-row iteration after them.  An
  * instance that would need more ends as HMPC_S_MAXITER with its last iterate in the force buffer and is NOT re-solved by
- * the safe pass.  The legacy update_solver_settings(max_iter, ...) sets the same cap for the process-global solver. */
+ * the safe pass -- neither by hmpc_download's host-driven one nor by the device-side one (hmpc_set_device_repair).
+ * hmpc_legacy_set_max_iterations sets the same cap for the process-global solver behind setup_problem / update_problem_data.
+ * The legacy update_solver_settings(max_iter, ...) does NOT: as in the reference (convexMPC_interface.cpp:112-118 stores its
+ * arguments, nothing reads them; the qpOASES path uses a fixed nWSR, SolverMPC.cpp:706) it is inert, so that a drop-in caller
+ * passing a small JCQP-style max_iter still gets full solves. */
 int hmpc_set_max_iterations(hmpc_handle *h, int max_iter);
+int hmpc_legacy_set_max_iterations(int max_iter);
 int hmpc_set_auto_resolve(hmpc_handle *h, int on);
 /* Device-side safe pass (default off for a plain handle): when on, hmpc_solve enqueues, behind the fast launch and on the
  * same stream, the safe variant over the list of instances the fast launch flagged (the list and its length stay on the

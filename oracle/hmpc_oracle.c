@@ -643,6 +643,15 @@ void orc_set_records_nc(int nc) { g_records_nc = (nc == 3) ? 3 : 2; }
 int orc_solve_records(const unsigned char *records, int stride, int first, int count, int horizon, float dt,
                       float f_max, double *q_soln, int *nwsr_out, double *obj_out, double *t_assemble,
                       double *t_solve) {
+  return orc_solve_records_ex(records, stride, first, count, horizon, dt, f_max, q_soln, nwsr_out, obj_out, t_assemble,
+                              t_solve, 0);
+}
+
+/* ... with qpOASES' return value per instance (0 = solved; SolverMPC.cpp:712-715 only prints "failed to solve!"), so that a
+ * comparison can leave out the instances the reference itself did not solve. */
+int orc_solve_records_ex(const unsigned char *records, int stride, int first, int count, int horizon, float dt,
+                         float f_max, double *q_soln, int *nwsr_out, double *obj_out, double *t_assemble,
+                         double *t_solve, int *rv_out) {
   orc_setup_t s = {dt, 0.25f, f_max, horizon};
   orc_qp_t *qp = orc_qp_alloc(horizon);
   orc_red_t *red = orc_red_alloc(horizon);
@@ -658,6 +667,7 @@ int orc_solve_records(const unsigned char *records, int stride, int first, int c
     int rv = solve_with(&u, &s, qp, red, q_soln + (size_t)k * NU * horizon, &nwsr, &obj, t_assemble, t_solve);
     if (nwsr_out) nwsr_out[k] = nwsr;
     if (obj_out) obj_out[k] = obj;
+    if (rv_out) rv_out[k] = rv;
     if (rv != 0) ++bad;
   }
   orc_qp_free(qp);

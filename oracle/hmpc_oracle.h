@@ -125,6 +125,9 @@ void orc_set_records_nc(int nc); /* record flavour orc_solve_records parses: 2 (
  * Returns the number of instances whose qpOASES status != 0.  t_assemble/t_solve (may be NULL) accumulate seconds. */
 int orc_solve_records(const unsigned char *records, int stride, int first, int count, int horizon, float dt,
                       float f_max, double *q_soln, int *nwsr_out, double *obj_out, double *t_assemble, double *t_solve);
+int orc_solve_records_ex(const unsigned char *records, int stride, int first, int count, int horizon, float dt,
+                         float f_max, double *q_soln, int *nwsr_out, double *obj_out, double *t_assemble,
+                         double *t_solve, int *rv_out /* qpOASES' return value per instance, may be NULL */);
 
 
 /* ---- the caller-side code either side of the solve ----

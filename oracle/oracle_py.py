@@ -87,6 +87,9 @@ def lib():
         L.orc_get_solution.restype = C.c_double
         L.orc_get_solution.argtypes = [C.c_int]
         L.orc_solve_records.restype = C.c_int
+        L.orc_solve_records_ex.restype = C.c_int
+        L.orc_solve_records_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_solve_records.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_unpack_record.argtypes = [C.c_void_p, C.c_int, C.POINTER(Update)]
@@ -177,7 +180,8 @@ def solve_records(records: np.ndarray, horizon: int, dt: float, f_max: float, fi
                   nc: int = 2):
     """Full reference path (assembly + elimination + qpOASES + scatter) on packed records.
 
-    Returns dict(q_soln [count,6 nc h] float64, nwsr, obj, n_bad, t_assemble, t_solve)."""
+    Returns dict(q_soln [count,6 nc h] float64, nwsr, obj, n_bad, bad [count] bool: qpOASES did not solve this instance,
+    t_assemble, t_solve)."""
     records = np.ascontiguousarray(records)
     count = records.shape[0] - first if count is None else count
     q = np.zeros((count, 6 * nc * horizon))
@@ -186,11 +190,12 @@ def solve_records(records: np.ndarray, horizon: int, dt: float, f_max: float, fi
     obj = np.zeros(count)
     ta = C.c_double(0)
     ts = C.c_double(0)
-    bad = lib().orc_solve_records(records.ctypes.data, records.shape[1], first, count, horizon, np.float32(dt),
-                                  np.float32(f_max), q.ctypes.data, nwsr.ctypes.data, obj.ctypes.data,
-                                  C.addressof(ta), C.addressof(ts))
+    rv = np.zeros(count, dtype=np.int32)
+    bad = lib().orc_solve_records_ex(records.ctypes.data, records.shape[1], first, count, horizon, np.float32(dt),
+                                     np.float32(f_max), q.ctypes.data, nwsr.ctypes.data, obj.ctypes.data,
+                                     C.addressof(ta), C.addressof(ts), rv.ctypes.data)
     lib().orc_set_records_nc(2)
-    return dict(q_soln=q, nwsr=nwsr, obj=obj, n_bad=bad, t_assemble=ta.value, t_solve=ts.value)
+    return dict(q_soln=q, nwsr=nwsr, obj=obj, n_bad=bad, bad=rv != 0, t_assemble=ta.value, t_solve=ts.value)
 
 
 def legacy_tick(fields_row: dict, horizon: int, dt: float, mu: float, f_max: float) -> np.ndarray:

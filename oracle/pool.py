@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def solve_records_parallel(rec: np.ndarray, horizon: int, dt: float, f_max: float, nc: int = 2, nproc: int | None = None):
     """``oracle_py.solve_records`` over all rows of ``rec`` with ``nproc`` worker processes (default: all host cores,
-    at most 64).  Returns dict(q_soln [n, 6 nc h], nwsr [n], obj [n], n_bad)."""
+    at most 64).  Returns dict(q_soln [n, 6 nc h], nwsr [n], obj [n], n_bad, bad [n] bool)."""
     n = rec.shape[0]
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     nproc = max(1, min(nproc or cores, 64, n))
@@ -34,7 +34,8 @@ def solve_records_parallel(rec: np.ndarray, horizon: int, dt: float, f_max: floa
                 raise RuntimeError("oracle pool worker failed")
         parts = [np.load(os.path.join(td, f"out{i}.npz")) for i in range(nproc)]
         return dict(q_soln=np.concatenate([p["q_soln"] for p in parts]), nwsr=np.concatenate([p["nwsr"] for p in parts]),
-                    obj=np.concatenate([p["obj"] for p in parts]), n_bad=int(sum(int(p["n_bad"]) for p in parts)))
+                    obj=np.concatenate([p["obj"] for p in parts]), n_bad=int(sum(int(p["n_bad"]) for p in parts)),
+                    bad=np.concatenate([p["bad"] for p in parts]))
 
 
 def _worker(argv):
@@ -43,7 +44,7 @@ def _worker(argv):
 
     rec = np.load(path)
     r = oracle_py.solve_records(rec, h, dt, fmax, first=lo, count=hi - lo, nc=nc)
-    np.savez(out, q_soln=r["q_soln"], nwsr=r["nwsr"], obj=r["obj"], n_bad=np.int64(r["n_bad"]))
+    np.savez(out, q_soln=r["q_soln"], nwsr=r["nwsr"], obj=r["obj"], n_bad=np.int64(r["n_bad"]), bad=r["bad"])
 
 
 if __name__ == "__main__":

@@ -9,10 +9,17 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c",
-       "-Wno-unused-value", "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:] + \
-      [os.path.join(ROOT, "hector_simulation_amd", "csrc", "hmpc_capi.hip"), "-o", "/dev/null"]
-out = subprocess.run(cmd, capture_output=True, text=True).stderr
+sys.path.insert(0, ROOT)
+import concurrent.futures  # noqa: E402
+
+from hector_simulation_amd import build as hip_build  # noqa: E402
+
+# the product's own translation units and flags (hector_simulation_amd/build.py), each with the resource-usage remarks on
+extra = [a for a in sys.argv[1:] if a != "--all"]
+units = hip_build.compile_commands("/tmp", "/opt/rocm/bin/hipcc")
+cmds = [c[:1] + ["-Rpass-analysis=kernel-resource-usage"] + extra + c[1:-1] + ["/dev/null"] for _, c in units]
+with concurrent.futures.ThreadPoolExecutor(max_workers=len(cmds)) as ex:
+    out = "\n".join(ex.map(lambda c: subprocess.run(c, capture_output=True, text=True).stderr, cmds))
 pats = {"vgpr": r" VGPRs: (\d+)", "agpr": r"AGPRs: (\d+)", "scratch": r"ScratchSize \[bytes/lane\]: (\d+)",
         "spill": r"VGPRs? Spill: (\d+)", "occ": r"Occupancy \[waves/SIMD\]: (\d+)", "lds": r"LDS Size \[bytes/block\]: (\d+)"}
 name, row = None, {}

@@ -107,3 +107,47 @@ def test_shard_bounds_in_c_matches_the_python_sharding():
             assert prev == batch
     with pytest.raises(ValueError):
         interface.shard_bounds(10, 2, 2)
+
+
+def test_wrong_numbers_switches_cannot_reach_the_product_library():
+    """The timing switches that leave a stage of the matrix-core sweeps out (HMPC_MFS_NO_LDL & co: wrong results by design) only
+    compile together with -DHMPC_DEV_TIMING, and build.py refuses that flag for the library the package loads."""
+    import subprocess
+
+    from hector_simulation_amd import build
+
+    src = os.path.join(ROOT, "hector_simulation_amd", "csrc", "hmpc_variants.hip")
+    base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-E", "-DHMPC_VARIANT_GROUP=0", src, "-o", "/dev/null"]
+    for sw in ("HMPC_MFS_NO_LDL", "HMPC_MFS_NO_STEPS", "HMPC_MFS_NO_LOAD", "HMPC_MFS_NO_RELAYOUT", "HMPC_MFS_ONLY_WAVE=1"):
+        r = subprocess.run(base + ["-D" + sw], capture_output=True, text=True)
+        assert r.returncode != 0 and "HMPC_DEV_TIMING" in r.stderr, sw
+    r = subprocess.run(base + ["-DHMPC_MFS_NO_LDL", "-DHMPC_DEV_TIMING"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-500:]
+    saved, saved_env = build.EXTRA[:], os.environ.pop("HMPC_ALLOW_DEV_TIMING", None)
+    try:
+        build.EXTRA[:] = ["-DHMPC_DEV_TIMING", "-DHMPC_MFS_NO_LDL"]
+        with pytest.raises(RuntimeError):
+            build._check_flags()
+        build.EXTRA[:] = ["-DHMPC_MFMA_SWEEP=0"]  # a same-results A/B switch is fine
+        build._check_flags()
+    finally:
+        build.EXTRA[:] = saved
+        if saved_env is not None:
+            os.environ["HMPC_ALLOW_DEV_TIMING"] = saved_env
+    # the removed 60-variable matrix-core path has left no plumbing behind
+    ksrc = open(os.path.join(ROOT, "hector_simulation_amd", "csrc", "hmpc_kernel.h")).read()
+    assert "HMPC_MFMA_SWEEP1" not in ksrc and "MFS1" not in ksrc
+
+
+def test_every_kernel_variant_is_built_by_exactly_one_translation_unit():
+    """csrc/hmpc_variants.h: twelve variants over HMPC_VARIANT_GROUPS groups, build.py compiles one unit per group."""
+    from hector_simulation_amd import build
+
+    hdr = open(os.path.join(ROOT, "hector_simulation_amd", "csrc", "hmpc_variants.h")).read()
+    rows = re.findall(r"X\((\d+), (\d+),", hdr)
+    assert [int(i) for i, _ in rows] == list(range(12))
+    groups = sorted({int(g) for _, g in rows})
+    assert groups == list(range(build.VARIANT_GROUPS))
+    assert f"HMPC_VARIANT_GROUPS = {build.VARIANT_GROUPS}" in hdr
+    units = build.compile_commands("/tmp/x", "hipcc")
+    assert len(units) == build.VARIANT_GROUPS + len(build.HOST_SOURCES)

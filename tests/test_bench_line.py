@@ -26,7 +26,7 @@ def test_bench_fails_loudly_without_gpu():
 @pytest.mark.gpu
 def test_bench_line_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--batch", "2048",
-                        "--no-side-configs", "--check", "16", "--cpu-per-core", "2"], capture_output=True, text=True,
+                        "--no-side-configs", "--check", "16", "--cpu-per-core", "8", "--cpu-seconds", "1.5"], capture_output=True, text=True,
                        timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -52,6 +52,9 @@ def test_bench_line_contract():
     assert e2e["checked"] == 16 and 0 < e2e["max_rel_force_err"] < 1.1e-3 and 0 <= e2e["fraction_above_1e-4"] <= 1
     assert len(cb["process_sweep"]) >= 2 and cb["process_sweep"][0]["processes"] == 1 and cb["host"]["nproc_affinity"] >= 1
     assert cb["saturation_processes"] >= 1 and "scaling_note" in cb
+    # quotable: the value is the median of three timed-to-target runs, the spread is in the line
+    assert len(cb["runs_solves_per_s"]) == 3 and cb["value_min"] <= cb["value"] <= cb["value_max"]
+    assert min(cb["runs_wall_s"]) > 0.7 * 1.5
     assert d["parity"]["max_rel_objective_gap"] < 1e-4 and d["parity"]["kkt"]["max_rel_row_violation"] < 1e-6
     assert abs(d["parity"]["kkt"]["max_rel_suboptimality"]) < 1e-6 and d["parity"]["kkt"]["max_rel_stationarity_residual"] < 1e-6
     for k in ("fp64_valu_frac", "iterations_per_solve", "single_stream"):

@@ -58,6 +58,46 @@ def test_hard_inputs(oracle, gait, h, scale, min_ok):
     assert ref["n_bad"] == 0 and err[ok].max() < 1e-4  # everything reported ok matches qpOASES
 
 
+@pytest.mark.parametrize("gait,h,nc,scale", [("standing", 10, 2, 10), ("walking", 10, 2, 10), ("mixed", 10, 2, 10), ("single", 20, 2, 10),
+                                             ("standing", 16, 2, 10), ("standing", 20, 2, 10), ("3contact", 10, 3, 10),
+                                             ("standing", 20, 2, 6)])
+def test_ok_iff_qpoases_ok_on_the_stress_rows(gait, h, nc, scale):
+    """The 10x rows of scripts/stress.py (profiles/r05/stress.txt) as assertions, 256 instances per shape against the qpOASES
+    pool: on the set where the reference has an answer at all (its failures masked out and counted separately, VERDICT round 4
+    item 7) every instance the kernel reports solved agrees with it, and "ok <=> qpOASES ok" holds -- with the one documented
+    exception, double support over h = 20 at 10x, where up to 3 % end flagged HMPC_S_KKT (never silently wrong)."""
+    from oracle import pool
+
+    nb = 256
+    if nc == 3:
+        f = synthetic.make_batch3(nb, 10, "standing", seed=19, phase="random", hand="window")
+        g = hard_batch(nb, 10, "standing", 19, scale)
+        for k in ("q", "v", "w", "joint_angles", "traj"):
+            f[k] = g[k]
+    else:
+        f = hard_batch(nb, h, gait, 17, scale)
+    rec = records.pack_records(f, h, nc)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb, contacts=nc)
+    mpc.upload(rec)
+    mpc.solve()
+    forces, status = mpc.download()  # with the safe / last-resort passes
+    mpc.close()
+    code = interface.status_code(status)
+    ok = (code == 0) | (code == 6)
+    ref = pool.solve_records_parallel(rec, h, synthetic.DT_MPC, synthetic.F_MAX, nc=nc)
+    rbad = np.asarray(ref["bad"], dtype=bool)
+    q = ref["q_soln"]
+    err = np.abs(forces - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+    both = ok & ~rbad
+    assert both.any() and err[both].max() < 1e-4, (err[both].max(), int(np.argmax(np.where(both, err, 0))))
+    assert np.isin(code[~ok], (1, 4, 5)).all()  # whatever is not solved is FLAGGED
+    n_gpu_only_fails = int((~ok & ~rbad).sum())
+    if gait == "standing" and h == 20 and scale == 10:
+        assert n_gpu_only_fails <= 0.03 * nb, n_gpu_only_fails  # (24 of 1 024 in profiles/r04/stress.txt)
+    else:
+        assert n_gpu_only_fails == 0, (n_gpu_only_fails, np.unique(code, return_counts=True))
+
+
 @pytest.mark.parametrize("gait,h,nb", [("standing", 10, 4096), ("mixed", 10, 2048), ("single", 20, 1024)])
 def test_repeated_solves_are_bitwise_identical(gait, h, nb):
     """No data race anywhere in the kernel: the same batch solved three times (other workgroups resident in different
@@ -172,3 +212,66 @@ def test_hard_inputs_wide_variant(oracle, h, scale, min_ok):
     q = ref["q_soln"]
     err = np.abs(forces - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
     assert ref["n_bad"] == 0 and err[ok].max() < 1e-4
+
+
+@pytest.mark.parametrize("device_repair", [False, True])
+def test_unsized_device_records_at_h20_route_the_safe_pass_by_size_class(oracle, device_repair):
+    """a two-contact batch at h = 20 handed in by DEVICE pointer without a size hint holds single-support
+    (<= 120 variables) and double-support (up to 240) instances side by side.  The fast launches route them by the size classes
+    counted on the device; the safe pass must do the same -- a wide instance flagged by the wide variant used to be re-solved by
+    the 120-variable safe variant, which ends as HMPC_S_TOO_LARGE with zero forces that nothing re-solves.  Hard inputs (6x the
+    nominal ranges) so that both classes do get flagged."""
+    import torch
+
+    nb, h = 96, 20
+    fa = hard_batch(nb // 2, h, "standing", 29, 6)
+    fb = hard_batch(nb // 2, h, "single", 31, 6)
+    rec = np.concatenate([records.pack_records(fa, h), records.pack_records(fb, h)])
+    perm = np.random.default_rng(3).permutation(nb)
+    rec = np.ascontiguousarray(rec[perm])
+    d_rec = torch.from_numpy(rec).cuda()
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb)
+    mpc.set_auto_resolve(False)
+    mpc.set_device_repair(device_repair)
+    mpc.set_device_records(d_rec.data_ptr(), nb, keepalive=d_rec)  # max_reduced_vars = -1: sized on the device
+    mpc.solve()
+    _, st_fast = mpc.download()
+    code_fast = interface.status_code(st_fast)
+    assert (code_fast != 3).all(), np.unique(code_fast, return_counts=True)  # never TOO_LARGE: every instance met its variant
+    if not device_repair:
+        assert np.isin(code_fast, (1, 4, 5)).sum() > 0  # the regime exercises the safe pass
+    mpc.set_auto_resolve(True)
+    forces, status = mpc.download()
+    mpc.close()
+    code = interface.status_code(status)
+    assert (code != 3).all(), np.unique(code, return_counts=True)
+    ok = (code == 0) | (code == 6)
+    assert ok.mean() >= 0.97, np.unique(code, return_counts=True)
+    ref = oracle.solve_records(rec, h, synthetic.DT_MPC, synthetic.F_MAX)
+    q = ref["q_soln"]
+    err = np.abs(forces - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+    both = ok & ~np.asarray(ref["bad"], dtype=bool)
+    assert err[both].max() < 1e-4
+    assert (np.abs(forces[ok]).max(axis=1) > 0).all()  # no "solved" instance with all-zero forces
+
+
+def test_device_repair_leaves_the_callers_iteration_cap_alone():
+    """with hmpc_set_device_repair on, an instance that ran into the CALLER'S cap (hmpc_set_max_iterations)
+    is the caller's answer -- status HMPC_S_MAXITER, last iterate in the force buffer -- and is not re-solved cold by the
+    on-stream safe launch (whose variants skip the block start: the re-solve would overwrite the forces with a worse iterate)."""
+    nb = 256
+    rec = records.pack_records(synthetic.make_batch(nb, 10, "standing", seed=77, phase="random"), 10)
+    outs = []
+    for repair in (False, True):
+        m = interface.BatchedMPC(synthetic.DT_MPC, 10, synthetic.F_MAX, nb)
+        m.set_auto_resolve(False)
+        m.set_device_repair(repair)
+        m.set_max_iterations(1)
+        m.upload(rec)
+        m.solve()
+        outs.append(m.download())
+        m.close()
+    code = interface.status_code(outs[0][1])
+    assert (code == 1).sum() > nb // 8 and set(np.unique(code)) <= {0, 1}
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))

@@ -134,10 +134,11 @@ def test_double_support_beyond_ten_steps(oracle, gait, h, nb, seed):
 
 
 def test_iteration_cap_is_honoured_batched_and_legacy(oracle):
-    """The one reference-declared knob with a meaning for an active-set solver: update_solver_settings(max_iter, ...)
-    (convexMPC_interface.h:41) / hmpc_set_max_iterations cap the active-set iterations -- the analogue of the reference's
-    nWSR = 500 (SolverMPC.cpp:706).  A cap of 1 ends every instance that needs more as HMPC_S_MAXITER (and the safe pass
-    leaves the caller's cap alone); cap 0 restores the optimum."""
+    """hmpc_set_max_iterations / hmpc_legacy_set_max_iterations cap the active-set iterations -- the analogue of the
+    reference's nWSR = 500 (SolverMPC.cpp:706).  A cap of 1 ends every instance that needs more as HMPC_S_MAXITER (and the
+    safe pass leaves the caller's cap alone); cap 0 restores the optimum.  The reference's own update_solver_settings(max_iter,
+    ...) is INERT here as it is there (convexMPC_interface.cpp:112-118 stores it, nothing reads it): a drop-in caller passing a
+    small JCQP-style max_iter gets full solves."""
     nb = 256
     f = synthetic.make_batch(nb, 10, "standing", seed=77, phase="random")
     rec = records.pack_records(f, 10)
@@ -167,10 +168,13 @@ def test_iteration_cap_is_honoured_batched_and_legacy(oracle):
     args = (row["p"], row["v"], row["q"], row["w"], row["r"], row["joint_angles"], float(row["yaw"]), row["weights"],
             row["traj"], row["Alpha_K"], row["gait"])
     interface.setup_problem(synthetic.DT_MPC, 10, 0.25, synthetic.F_MAX)
-    interface.update_solver_settings(1, 0.0, 0.0, 0.0, 0.0, 0.0)
+    interface.update_solver_settings(1, 0.0, 0.0, 0.0, 0.0, 0.0)  # the reference's entry point: stored, read by nothing
+    interface.update_problem_data(*args)
+    assert interface.last_status() & 0xFF == 0
+    interface.legacy_set_max_iterations(1)                       # the explicit opt-in
     interface.update_problem_data(*args)
     assert interface.last_status() & 0xFF == 1  # HMPC_S_MAXITER
-    interface.update_solver_settings(0, 0.0, 0.0, 0.0, 0.0, 0.0)
+    interface.legacy_set_max_iterations(0)
     interface.update_problem_data(*args)
     assert interface.last_status() & 0xFF == 0
     got = np.array([interface.get_solution(i) for i in range(120)])
