@@ -70,7 +70,25 @@ def compile_commands(objdir: str, hipcc: str) -> list:
     return units
 
 
-def build(force: bool = False, verbose: bool = False, extra_compile_flags: list | None = None) -> str:
+def build_to(out: str, extra_compile_flags: list | None = None, verbose: bool = False) -> str:
+    """A developer copy of the library (profiling / timing builds) at `out`; the product library and its stamp are not touched."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    with tempfile.TemporaryDirectory(prefix="hmpc_obj_") as objdir:
+        units = [(o, c[:1] + list(extra_compile_flags or []) + c[1:]) for o, c in compile_commands(objdir, hipcc)]
+
+        def run(unit):
+            if verbose:
+                print(" ".join(unit[1]), flush=True)
+            subprocess.check_call(unit[1])
+            return unit[0]
+
+        with concurrent.futures.ThreadPoolExecutor(max_workers=len(units)) as ex:
+            objs = list(ex.map(run, units))
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", out])
+    return out
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     _check_flags()
@@ -80,25 +98,8 @@ def build(force: bool = False, verbose: bool = False, extra_compile_flags: list 
         try:
             if not force and not needs_build():  # another process built it while we waited
                 return LIB
-            hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
             tmp = LIB + f".tmp{os.getpid()}"
-            with tempfile.TemporaryDirectory(prefix="hmpc_obj_") as objdir:
-                units = compile_commands(objdir, hipcc)
-                if extra_compile_flags:
-                    units = [(o, c[:1] + list(extra_compile_flags) + c[1:]) for o, c in units]
-
-                def run(unit):
-                    if verbose:
-                        print(" ".join(unit[1]), flush=True)
-                    subprocess.check_call(unit[1])
-                    return unit[0]
-
-                with concurrent.futures.ThreadPoolExecutor(max_workers=len(units)) as ex:
-                    objs = list(ex.map(run, units))
-                link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", tmp]
-                if verbose:
-                    print(" ".join(link), flush=True)
-                subprocess.check_call(link)
+            build_to(tmp, verbose=verbose)
             os.replace(tmp, LIB)
             with open(_stamp_path(), "w") as f:
                 f.write(source_hash())

@@ -22,7 +22,7 @@ def main():
     nc = int(sys.argv[4]) if len(sys.argv) > 4 else 2
     prof_lib = os.path.join(ROOT, "gpurun_out", "libhector_mpc_hip_prof.so")
     os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
-    subprocess.check_call(["hipcc"] + build.FLAGS + ["-DHMPC_PROFILE"] + [os.path.join(build.CSRC, s) for s in build.SOURCES] + ["-o", prof_lib])
+    build.build_to(prof_lib, ["-DHMPC_PROFILE"])
     build.LIB = prof_lib
     build.needs_build = lambda: False
     if nc == 3:

@@ -11,7 +11,9 @@ OUT=gpurun_out/sanitize; mkdir -p $OUT
 RT=$(find /opt/rocm/lib/llvm -name 'libclang_rt.asan-x86_64.so' | head -1)
 SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g"
 hipcc --offload-arch=gfx950 -O1 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -Wno-pass-failed $SAN -fno-gpu-sanitize \
-  -shared-libsan hector_simulation_amd/csrc/hmpc_capi.hip hector_simulation_amd/csrc/hmpc_group.hip -ldl -o $OUT/libhector_mpc_hip.so || exit 2
+  -shared-libsan hector_simulation_amd/csrc/hmpc_capi.hip hector_simulation_amd/csrc/hmpc_group.hip \
+  $(for g in 0 1 2 3; do hipcc --offload-arch=gfx950 -O1 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value -Wno-pass-failed -DHMPC_VARIANT_GROUP=$g -c hector_simulation_amd/csrc/hmpc_variants.hip -o $OUT/hmpc_variants_$g.o && echo $OUT/hmpc_variants_$g.o; done) \
+  -ldl -o $OUT/libhector_mpc_hip.so || exit 2
 CLANG=$(dirname $(dirname "$RT"))/../../../bin/clang
 [ -x "$CLANG" ] || CLANG=/opt/rocm/lib/llvm/bin/clang
 fail=0
