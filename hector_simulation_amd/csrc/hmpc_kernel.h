@@ -278,6 +278,9 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
      defined(HMPC_MFS_ONLY_WAVE)) && !defined(HMPC_DEV_TIMING)
 #error "HMPC_MFS_NO_* / HMPC_MFS_ONLY_WAVE give wrong results by design: timing builds only, add -DHMPC_DEV_TIMING"
 #endif
+#ifndef HMPC_SCHUR_MFMA
+#define HMPC_SCHUR_MFMA 1  // block start of the fast 256-thread two-contact variants: Schur matrix inverted by 4 x 4 block pivots on the matrix cores (0: two scalar pivots per barrier in registers)
+#endif
 #ifndef HMPC_BLOCK_FRICTION
 #define HMPC_BLOCK_FRICTION 1  // block start also takes friction rows violated at the unconstrained minimiser
 #endif
@@ -419,7 +422,9 @@ struct MfsPanel {
   double Dinv[2][4][4];  // inverse of the pivot block
   double Draw[4][4];     // the pivot block itself, as it is (recovering D from the panel's D - I would cost the small pivots --
                          // down to 1e-4 -- three digits; the scalar sweeps pass d beside the row for the same reason)
+  int bad;               // mfs_steps<.., CHECK = true>: a pivot of some block came out <= MFS_PIVOT_MIN (matrix not positive definite)
 };
+constexpr double MFS_PIVOT_MIN = 1e-9;  // on the power-of-two-equilibrated matrix (diagonal in [1, 4))
 // leg-step block t (block-row-major over e0 <= e1 of the NG x NG grid of 6 x 6 blocks) -> e0
 constexpr int mfs_block_row(int t, int ng) {
   int e = 0, base = 0;
@@ -574,7 +579,7 @@ __device__ __forceinline__ void mfs_load_parked(MfsAcc<NTG, NWV> &acc, const int
 
 // The NTG * 4 block-pivot steps on the tiles in acc (code specialised per wave).  Callers: a barrier between the last read
 // of whatever PN aliases and this call.
-template <int NTG, int NWV, int WV>
+template <int NTG, int NWV, int WV, bool CHECK = false>
 __device__ __forceinline__ void mfs_steps(MfsPanel<NTG> &PN, MfsAcc<NTG, NWV> &acc, const int n) {
   constexpr MfsTiles<NTG, NWV, WV> T;
   constexpr int TPW = MfsGrid<NTG, NWV>::TPW, PST = MfsPanel<NTG>::PST, CNT = mfs_count(NTG, NWV, WV);
@@ -605,6 +610,9 @@ __device__ __forceinline__ void mfs_steps(MfsPanel<NTG> &PN, MfsAcc<NTG, NWV> &a
     const double m32 = dfma(-l31, m21, dfma(-l30, d20, d32));
     const double l32 = m32 * i2;
     const double e3 = dfma(-l32, m32, dfma(-l31, m31, dfma(-l30, d30, d33))), i3 = rcp1(e3);
+    if constexpr (CHECK) {  // (callers whose matrix may be rank deficient: the inherited working set of the block start)
+      if (!(d00 > MFS_PIVOT_MIN && e1 > MFS_PIVOT_MIN && e2 > MFS_PIVOT_MIN && e3 > MFS_PIVOT_MIN)) PN.bad = 1;
+    }
     double y0 = (g == 0) ? 1.0 : 0.0, y1 = (g == 1) ? 1.0 : 0.0, y2 = (g == 2) ? 1.0 : 0.0, y3 = (g == 3) ? 1.0 : 0.0;
     y1 = dfma(-l10, y0, y1);
     y2 = dfma(-l21, y1, dfma(-l20, y0, y2));
@@ -674,7 +682,7 @@ __device__ __forceinline__ void mfs_steps(MfsPanel<NTG> &PN, MfsAcc<NTG, NWV> &a
     const double x0 = PN.Dinv[s & 1][g][0], x1 = PN.Dinv[s & 1][g][1], x2 = PN.Dinv[s & 1][g][2], x3 = PN.Dinv[s & 1][g][3];
     // tile(I,J) -= Q_I' P_J, Q = D^-1 P: A operand -Q[g][16 I + c], B operand P[g][16 J + c].
     // groups of GT tiles, the operands of group k+1 read while the matrix instructions of group k run
-    constexpr int GT = (TPW % 3 == 0) ? 3 : HMPC_MFS_GT, NGRP = (CNT + GT - 1) / GT;
+    constexpr int GT = (TPW % 3 == 0) ? 3 : (TPW < HMPC_MFS_GT ? TPW : HMPC_MFS_GT), NGRP = (CNT + GT - 1) / GT;
     double aop[2][GT], bop[2][GT];
     double alast = 0.0;
     auto fetch = [&](const int grp, double (&ao)[GT], double (&bo)[GT]) __attribute__((always_inline)) {
@@ -820,6 +828,76 @@ __device__ __forceinline__ void mfma_sweeps(MfsPanel<NTG> &PN, double *stage, co
   const int e0a[1] = {e0}, e1a[1] = {e1};
   const bool la[1] = {live};
   mfs_relayout<NTG, NWV, WV, NV, 1, NT>(stage, acc, n, kexp, e0a, e1a, la, a);
+}
+
+
+// ---- The Schur matrix of the block start on the same machinery (round 5) -----------------------------------------------------
+// S0 = N_W M N_W' (k0 <= 16 NTG rows, packed lower triangle in LDS) is inverted by the 4 x 4 block-pivot steps above instead of
+// two scalar pivots per barrier on a packed triangle spread over the threads' registers: (k0 + 3) / 4 barrier-separated steps
+// instead of k0 / 2, and the update is one matrix instruction per 16 x 16 tile instead of ~12 binary64 instructions per entry
+// and thread.  Same power-of-two equilibration as stage S (the diagonal of S0 spans 1/H_ii: six orders of magnitude).
+template <int NTG>
+struct SchurPanel {
+  MfsPanel<NTG> pn;
+  signed char kexp[16 * NTG];
+};
+// (the caller's barrier follows)
+template <int NTG>
+__device__ __forceinline__ void schur_scale_exponents(const int k0, const double *Ep, signed char *kexp) {
+  const int tid = threadIdx.x;
+  if (tid < 16 * NTG) {
+    int k = 0;
+    if (tid < k0) {
+      const int ex = ((__double2hiint(Ep[(unsigned)(tid * (tid + 1) / 2 + tid)]) >> 20) & 2047) - 1023;  // floor(log2 S0_ii); S0_ii > 0
+      k = -(ex >> 1);
+    }
+    kexp[tid] = (signed char)k;
+  }
+}
+template <int NTG, int NWV, int WV>
+__device__ __forceinline__ void schur_load(MfsAcc<NTG, NWV> &acc, const int k0, const double *Ep, const signed char *kexp) {
+  constexpr MfsTiles<NTG, NWV, WV> T;
+  constexpr int CNT = mfs_count(NTG, NWV, WV);
+  const int ln = threadIdx.x & 63, g = ln >> 4, c = ln & 15;
+#pragma unroll
+  for (int t = 0; t < CNT; ++t) {
+    const int j = 16 * T.j[t] + c;
+    const int kj = (int)kexp[j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * T.i[t] + g + 4 * r;
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      const bool valid = hi < k0;
+      const double v = Ep[(unsigned)(valid ? hi * (hi + 1) / 2 + lo : 0)];
+      acc[t][r] = valid ? v * __hiloint2double((1023 + (int)kexp[i] + kj) << 20, 0) : ((i == j) ? 1.0 : 0.0);  // identity padding
+    }
+  }
+}
+// E = S0^-1 = -A (scaling undone) back into the packed triangle (callers: a barrier before E is read)
+template <int NTG, int NWV, int WV>
+__device__ __forceinline__ void schur_store(const MfsAcc<NTG, NWV> &acc, const int k0, double *Ep, const signed char *kexp) {
+  constexpr MfsTiles<NTG, NWV, WV> T;
+  constexpr int CNT = mfs_count(NTG, NWV, WV);
+  const int ln = threadIdx.x & 63, g = ln >> 4, c = ln & 15;
+#pragma unroll
+  for (int t = 0; t < CNT; ++t) {
+    const int j = 16 * T.j[t] + c;
+    const int kj = (int)kexp[j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * T.i[t] + g + 4 * r;
+      if (i <= j && j < k0)  // (upper triangle of the tile grid: i <= j always holds off the diagonal tiles)
+        Ep[(unsigned)(j * (j + 1) / 2 + i)] = -acc[t][r] * __hiloint2double((1023 + (int)kexp[i] + kj) << 20, 0);
+    }
+  }
+}
+// the whole inversion, code specialised per wave; returns through SP.pn.bad whether a pivot was not positive
+template <int NTG, int NWV, int WV>
+__device__ __forceinline__ void schur_invert(SchurPanel<NTG> &SP, const int k0, double *Ep) {
+  MfsAcc<NTG, NWV> acc;
+  schur_load<NTG, NWV, WV>(acc, k0, Ep, SP.kexp);
+  mfs_steps<NTG, NWV, WV, true>(SP.pn, acc, k0);
+  schur_store<NTG, NWV, WV>(acc, k0, Ep, SP.kexp);
 }
 
 // three waves per SIMD = 3 (256 threads) or 6 (128 threads) workgroups per CU: their LDS must fit the CU's 160 KB
@@ -1903,8 +1981,11 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   const double INF = __builtin_huge_val();
   const double FEAS_TOL = 1e-9;
   constexpr bool LAZY = (BPT == 2);
-  const auto c_e = lazy_int<LAZY>([](int t) { return t >> 3; });
-  const auto c_rr = lazy_int<LAZY>([](int t) { return t & 7; });
+  // (the fast 256-thread two-contact variants sit exactly on their 168-register budget: their integer roles are recomputed at
+  //  every use as well -- one instruction each -- instead of being the allocator's first victims)
+  constexpr bool LAZY_IDX = LAZY || (NT == 256 && BPT == 1 && NC == 2 && QCAP != 0 && QCAP < NMAX);
+  const auto c_e = lazy_int<LAZY_IDX>([](int t) { return t >> 3; });
+  const auto c_rr = lazy_int<LAZY_IDX>([](int t) { return t & 7; });
   // the lower bound of a row is 0 -- except in the last-resort pass (args.relax != 0), where it is recomputed on use
   // rather than kept in a register pair for the whole solve
   // (read through LDS: a value the compiler cannot prove loop-invariant across the barriers, or it hoists the whole
@@ -1948,10 +2029,10 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   auto row_ub = [&]() __attribute__((always_inline)) -> double { if constexpr (!LAZY) return c_ub_r; else return row_ub_calc(); };
   auto row_hasl = [&]() __attribute__((always_inline)) -> bool { if constexpr (!LAZY) return c_hasl_r; else { const int rr = c_rr; return rr <= 4 || rr == 7; } };
   auto row_hasu = [&]() __attribute__((always_inline)) -> bool { if constexpr (!LAZY) return c_hasu_r; else return c_rr >= 4; };
-  const auto v_e = lazy_int<LAZY>([](int t) { return t / GS; });
-  const auto v_k = lazy_int<LAZY>([](int t) { return t % GS; });
-  const int v_leg_r = (!LAZY && is_v) ? S.ls_leg[v_e] : 0;
-  auto var_leg = [&]() __attribute__((always_inline)) -> int { if constexpr (!LAZY) return v_leg_r; else return (tid < n) ? (int)S.ls_leg[v_e] : 0; };
+  const auto v_e = lazy_int<LAZY_IDX>([](int t) { return t / GS; });
+  const auto v_k = lazy_int<LAZY_IDX>([](int t) { return t % GS; });
+  const int v_leg_r = (!LAZY_IDX && is_v) ? S.ls_leg[v_e] : 0;
+  auto var_leg = [&]() __attribute__((always_inline)) -> int { if constexpr (!LAZY_IDX) return v_leg_r; else return (tid < n) ? (int)S.ls_leg[v_e] : 0; };
   for (int t = tid; t < SM::MMAX; t += NT) {
     Q.act[t] = 0;
     Q.slot[t] = 0;
@@ -2136,8 +2217,12 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     constexpr int BLOCK_MIN_NEW = (NC == 3) ? HMPC_BLOCK_MIN_NEW_3C : HMPC_BLOCK_MIN_NEW;
     constexpr int EPT = (NC == 3 && NT < 512) ? HMPC_EPT_3C : 5;  // packed-triangle entries per thread during the Schur inversion
     constexpr int KBMAX_3C = (HMPC_EPT_3C >= 8) ? 63 : ((HMPC_EPT_3C == 7) ? 59 : 54);
-    constexpr int KBMAX = (NT >= 512) ? 71 : ((NT >= 256) ? (NC == 3 ? (KBMAX_3C < SM::QMAX ? KBMAX_3C : SM::QMAX) : 45) : 34);  // KBMAX(KBMAX+1)/2 <= EPT*NT
-    static_assert(KBMAX * (KBMAX + 1) / 2 <= EPT * NT && KBMAX <= SM::QMAX, "block start capacity");
+    // Schur matrix of the fast 256-thread two-contact variants on the matrix cores (schur_invert): 3 x 3 tiles = 48 rows
+    constexpr bool SCHUR_MFMA = HMPC_SCHUR_MFMA && !LONGRUN && NT == 256 && NC == 2 && BPT == 1 && QCAP >= 48;
+    constexpr int NTGS = 3;
+    constexpr int KBMAX = SCHUR_MFMA ? 16 * NTGS
+                                     : ((NT >= 512) ? 71 : ((NT >= 256) ? (NC == 3 ? (KBMAX_3C < SM::QMAX ? KBMAX_3C : SM::QMAX) : 45) : 34));  // KBMAX(KBMAX+1)/2 <= EPT*NT
+    static_assert((SCHUR_MFMA || KBMAX * (KBMAX + 1) / 2 <= EPT * NT) && KBMAX <= SM::QMAX, "block start capacity");
     // (one round as a lambda instantiated once per round rather than a loop: with the loop the register allocator keeps
     //  ~50 more VGPRs alive across the whole phase -- measured 185 -> 244 on the unconstrained variants)
     // refresh (safe variants only): the round is there to REBUILD E for the current working set (plus whatever is violated) --
@@ -2236,6 +2321,23 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       //     registers (<= EPT entries each); the safe variants also take sets beyond that capacity, swept in place
       //     (LDS, or global for the EGLOBAL variant), one pivot per two barriers -- slow, and only ever run for the handful of
       //     instances per thousand that need hundreds of working-set changes at many times the nominal input ranges
+      if constexpr (SCHUR_MFMA) {
+        // 4 x 4 block pivots on v_mfma_f64_16x16x4_f64: S0 as 16 x 16 tiles in the accumulators (six tiles on four waves), the
+        // pivot panels in the mat-vec staging (free here), E written back over S0 in the packed triangle
+        static_assert(sizeof(SchurPanel<NTGS>) <= sizeof(Q.ST), "the Schur panels live in the mat-vec staging");
+        SchurPanel<NTGS> &SP = *reinterpret_cast<SchurPanel<NTGS> *>(&Q.ST[0][0]);
+        schur_scale_exponents<NTGS>(k0, Ep, SP.kexp);
+        if (tid == 0) SP.pn.bad = 0;
+        __syncthreads();
+        switch (wv) {  // uniform: per-wave specialised code
+          case 0: schur_invert<NTGS, 4, 0>(SP, k0, Ep); break;
+          case 1: schur_invert<NTGS, 4, 1>(SP, k0, Ep); break;
+          case 2: schur_invert<NTGS, 4, 2>(SP, k0, Ep); break;
+          default: schur_invert<NTGS, 4, 3>(SP, k0, Ep); break;
+        }
+        __syncthreads();
+        bad_start = SP.pn.bad != 0;
+      } else
       if (LONGRUN && (SM::EGLOBAL || ub(k0 > KBMAX))) {  // (EGLOBAL: always in place -- one inversion path less to hold registers for)
         bad_start = false;
         const int ti = tid >> 4, tj = tid & 15;
