@@ -146,24 +146,50 @@ __global__ __launch_bounds__(256) void classify_records_kernel(const unsigned ch
   cls[inst] = (unsigned char)(cnt > 255 ? 255 : cnt);
 }
 
+// Cost predictor for a COLD handle (round 5): which instances will take many active-set iterations, read off the record alone --
+// no previous solve needed.  What the iteration count of this QP follows (fitted offline on the iteration counts of the bench's
+// and the stress sets' instances, scripts/dev/fit_predictor.py; correlation 0.8 with the iterations of the 2-contact and
+// 3-contact sets, 0.6-0.7 on single support / 3x ranges): the forward acceleration the tick asks for, u = (vx_cmd - vx) +
+// 2 * mean foot x -- a body slower than commanded with its feet ahead of it has to push through the heel edges of the line
+// contacts and the friction rows, many rows become active (15 iterations on average at u = 0.75 against 2 at u = 0); the other
+// direction costs a twentieth of that; tilt adds a little.  Returned as one of 64 buckets (higher = longer), the key the
+// counting sort below uses in place of the previous solve's iteration count.
+__device__ __forceinline__ int predicted_cost_bucket(const unsigned char *rec, int h, int nc) {
+  const float *f = reinterpret_cast<const float *>(rec);
+  const int nf = (nc == 3) ? 73 : 54;
+  const float vx = f[3], qw = f[6], qx = f[7], qy = f[8], qz = f[9];
+  const float mrx = 0.5f * (f[13] + f[14]);            // r_feet(axis, contact) = r[nc * axis + contact]: x of the two feet
+  const float vcmd = f[nf + 9];                        // reference trajectory, step 0, v_x (ConvexMPCLocomotion.cpp:330-406)
+  const float sr = 2.0f * (qw * qx + qy * qz), sp = 2.0f * (qw * qy - qx * qz);  // ~ roll, pitch (their sines)
+  const float u = (vcmd - vx) + 2.0f * mrx;
+  const float score = (u > 0.0f ? u : -0.05f * u) + 0.5f * (fabsf(sr) + fabsf(sp));
+  const int b = (int)(score * 48.0f);
+  return b < 0 ? 0 : (b > 63 ? 63 : b);
+}
+
 // Longest-first dispatch (hmpc_set_dispatch_order): the instances of the batch ordered by the active-set iterations their
-// PREVIOUS solve took (status word bits 8-19), most first -- a counting sort by one workgroup (64 buckets, iterations >= 63
+// PREVIOUS solve took (status word bits 8-19), most first -- or, when there is no previous solve of this batch (records !=
+// nullptr: a cold handle, a new batch size, the first tick of a device-built pipeline), by predicted_cost_bucket of their
+// records -- a counting sort by one workgroup (64 buckets, iterations >= 63
 // share the first).  The solve kernels then take instance order[blockIdx.x]: the hardware starts workgroups in index
 // order, so the long solves start first and the short ones fill the last, partly occupied round of workgroup slots.  The
 // position inside a bucket is decided by atomics and may differ from run to run -- that only changes which slot an
 // instance runs in, never its result.
-__global__ __launch_bounds__(1024) void dispatch_order_kernel(const uint32_t *status, int batch, int *order) {
+__global__ __launch_bounds__(1024) void dispatch_order_kernel(const uint32_t *status, int batch, int *order,
+                                                              const unsigned char *records, int stride, int h, int nc) {
   // per-wave counters: a batch whose iteration counts all fall into two or three buckets (walking) would otherwise send every
   // one of its atomics to the same few LDS words (measured: 15 us for 8 192 instances; ~2 us this way)
   __shared__ int cnt[16][64];
   __shared__ int base[64];
   const int tid = threadIdx.x, wv = tid >> 6;
+  auto key = [&](const int i) -> int {
+    if (records) return predicted_cost_bucket(records + (size_t)i * stride, h, nc);  // (uniform branch)
+    const int it = (int)((status[i] >> 8) & 0xFFFu);
+    return it > 63 ? 63 : it;
+  };
   cnt[wv][tid & 63] = 0;
   __syncthreads();
-  for (int i = tid; i < batch; i += 1024) {
-    const int it = (int)((status[i] >> 8) & 0xFFFu);
-    atomicAdd(&cnt[wv][it > 63 ? 63 : it], 1);
-  }
+  for (int i = tid; i < batch; i += 1024) atomicAdd(&cnt[wv][key(i)], 1);
   __syncthreads();
   if (tid < 64) {
     int tot = 0;
@@ -187,10 +213,7 @@ __global__ __launch_bounds__(1024) void dispatch_order_kernel(const uint32_t *st
     }
   }
   __syncthreads();
-  for (int i = tid; i < batch; i += 1024) {
-    const int it = (int)((status[i] >> 8) & 0xFFFu);
-    order[atomicAdd(&cnt[wv][it > 63 ? 63 : it], 1)] = i;
-  }
+  for (int i = tid; i < batch; i += 1024) order[atomicAdd(&cnt[wv][key(i)], 1)] = i;
 }
 
 // thread g -> (instance g/12, leg (g%12)/6, row (g%6)): f_ff = -rBody * [GRF; GRM]

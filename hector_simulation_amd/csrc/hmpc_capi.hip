@@ -300,15 +300,19 @@ static int launch_safe(hmpc_handle *h, hipStream_t stream, LaunchOpt s) {
 static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
   const bool repair = h->device_repair != 0;
   if (repair) HIP_TRY(hipMemsetAsync(h->d_flag_count, 0, sizeof(unsigned int), stream));
-  // longest-first dispatch: only where the tail of a launch matters (small and medium batches) and the previous solve was of
-  // a batch of this size (the caller's contract: instance i of this tick is instance i of the last one)
+  // longest-first dispatch: only where the tail of a launch matters (small and medium batches).  Keyed by the iteration counts
+  // of the previous solve when that was of a batch of this size (the caller's contract: instance i of this tick is instance i
+  // of the last one); otherwise -- a cold handle, another batch size, mode 2 -- by the cost predicted from the records themselves
+  // (predicted_cost_bucket: no previous solve needed)
   h->order_valid = false;
   // (... and not for batches known to hold single-support QPs only: those solve in one or two iterations, there is nothing to
   //  sort and the extra launch costs a walking batch 1-4 %)
   const bool small_qps_only = h->nc == 2 && h->max_stance >= 0 && h->max_stance <= 60;
-  if (h->dispatch_order == 1 && h->d_order && h->order_batch == h->batch && h->batch > DISPATCH_ORDER_MIN_BATCH &&
-      h->batch <= DISPATCH_ORDER_MAX_BATCH && !small_qps_only) {
-    hipLaunchKernelGGL(hmpc::dispatch_order_kernel, dim3(1), dim3(1024), 0, stream, h->d_status, h->batch, h->d_order);
+  if (h->dispatch_order != 0 && h->d_order && h->batch > DISPATCH_ORDER_MIN_BATCH && h->batch <= DISPATCH_ORDER_MAX_BATCH &&
+      !small_qps_only && !h->d_ext_H) {
+    const bool from_previous = h->dispatch_order == 1 && h->order_batch == h->batch;
+    hipLaunchKernelGGL(hmpc::dispatch_order_kernel, dim3(1), dim3(1024), 0, stream, h->d_status, h->batch, h->d_order,
+                       from_previous ? (const unsigned char *)nullptr : h->d_records, (int)h->stride, h->setup.horizon, h->nc);
     HIP_TRY(hipGetLastError());
     h->order_valid = true;
   }
@@ -557,13 +561,13 @@ int hmpc_set_max_reduced_vars(hmpc_handle *h, int n_reduced) {
 }
 
 int hmpc_set_dispatch_order(hmpc_handle *h, int mode) {
-  if (!h || (mode != 0 && mode != 1)) return HMPC_E_ARG;
-  if (mode == 1 && !h->d_order && h->max_batch > DISPATCH_ORDER_MIN_BATCH) {
+  if (!h || (mode != 0 && mode != 1 && mode != 2)) return HMPC_E_ARG;
+  if (mode != 0 && !h->d_order && h->max_batch > DISPATCH_ORDER_MIN_BATCH) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMalloc(&h->d_order, (size_t)h->max_batch * sizeof(int)));
   }
   h->dispatch_order = mode;
-  h->order_batch = 0;  // the next solve runs in natural order and leaves the iteration counts the one after it sorts by
+  h->order_batch = 0;  // the next solve is ordered by the predictor (mode 1, 2) and leaves the iteration counts the one after it sorts by (mode 1)
   h->order_valid = false;
   return HMPC_OK;
 }

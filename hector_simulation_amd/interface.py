@@ -147,10 +147,11 @@ class BatchedMPC:
         """Cap on the active-set iterations (0 = none); the nWSR analogue (include/hector_mpc.h hmpc_set_max_iterations)."""
         _check(self.L.hmpc_set_max_iterations(self.h, int(max_iter)), "hmpc_set_max_iterations")
 
-    def set_dispatch_order(self, longest_first: bool) -> None:
-        """Start the instances whose previous solve took most iterations first (include/hector_mpc.h
-        hmpc_set_dispatch_order); results do not depend on it."""
-        _check(self.L.hmpc_set_dispatch_order(self.h, 1 if longest_first else 0), "hmpc_set_dispatch_order")
+    def set_dispatch_order(self, mode) -> None:
+        """0 / False: natural order; 1 / True (default): longest previous solve first, a cold handle by the cost predicted
+        from the records; 2: always by the predictor (include/hector_mpc.h hmpc_set_dispatch_order).  Results do not depend
+        on it."""
+        _check(self.L.hmpc_set_dispatch_order(self.h, int(mode)), "hmpc_set_dispatch_order")
 
     def tick_solve_device(self, ticks_ptr: int, batch: int, dt_mpc: float, tau_ptr: int, f_ff_ptr: int = 0, wpd_ptr: int = 0,
                           stream: int = 0) -> None:

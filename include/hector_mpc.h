@@ -184,7 +184,11 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved);
  * workgroups and one 87-iteration straggler: 1.18 M solves/s in natural order, 1.66 M with a hint one tick old).  mode 0:
  * instance b runs in workgroup b.  Results do not depend on the mode, nor on whether the assumption holds (instance i of
  * this solve = instance i of the previous one, as for hmpc_set_tick_warm_start): any status words give a valid order, a
- * stale one merely stops helping.  The first solve of a handle, the first after a change of the batch size, batches of at
+ * stale one merely stops helping.  The first solve of a handle and the first after a change of the batch size -- no previous
+ * solve to go by -- are ordered by a COST PREDICTED FROM THE RECORDS (round 5): the forward acceleration the tick asks for,
+ * (v_x commanded - v_x) + 2 x mean foot x, and the body's tilt, which is what the iteration count of this QP follows
+ * (correlation 0.8 on the bench's sets; hmpc_builder.h predicted_cost_bucket) -- so a cold handle, and the first tick of a
+ * device-built pipeline, are ordered too.  mode 2: always by the predictor (never by a previous solve).  Batches of at
  * most 512 instances (they fit the chip's workgroup slots at once), of more than 32 768, and batches known to hold
  * single-support QPs only (<= 60 reduced variables: one or two iterations each, nothing to sort) run in natural order.
  * The reference has no counterpart (one QP per call). */

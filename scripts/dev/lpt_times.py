@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""Developer tool: kernel time of small / medium batches in natural order and with hmpc_set_dispatch_order (longest previous solve first)."""
+"""Developer tool: kernel time of small / medium batches in three dispatch orders (hmpc_set_dispatch_order):
+   natural   -- mode 0: instance b in workgroup b
+   predicted -- mode 2: ordered by the cost predicted from the records alone (what a COLD handle gets)
+   next tick -- mode 1: ordered by the iteration counts of the solve of the same instances one 5 ms tick earlier
+Every timed solve is ONE launch sequence of a batch the handle has not solved before (no order comes from the answer to the same
+data).  -> profiles/r05/dispatch_order.txt"""
 import os
 import sys
 
@@ -12,6 +17,7 @@ from hector_simulation_amd import interface, records, synthetic  # noqa: E402
 
 CASES = [("standing", 10, 1024, 2), ("standing", 10, 2048, 2), ("standing", 10, 8192, 2), ("walking", 10, 1024, 2), ("walking", 10, 8192, 2),
          ("single", 20, 4096, 2), ("standing", 10, 2048, 3), ("standing", 10, 8192, 3), ("standing", 20, 2048, 2)]
+print(f"{'case':38s} {'natural':>22s} {'predicted (cold handle)':>32s} {'previous tick':>32s}")
 for gait, h, nb, nc in CASES:
     if nc == 3:
         f = synthetic.make_batch3(nb, h, gait, seed=5, hand="contact")
@@ -19,23 +25,19 @@ for gait, h, nb, nc in CASES:
         f = synthetic.make_batch(nb, h, gait, seed=2, phase="random")
     rec = records.pack_records(f, h, nc)
     rec_next = records.pack_records(synthetic.advance_tick(f, h, seed=9), h, nc)  # the same instances one 5 ms tick later
-    row = []
-    for mode in (False, True):
+    t = {}
+    for name, mode in (("natural", 0), ("predicted", 2), ("next_tick", 1)):
         m = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb, contacts=nc)
         m.set_dispatch_order(mode)
-        m.upload(rec)
-        m.solve()
-        m.solve()
-        row.append(min(m.time_solve(10) for _ in range(3)))
-        # the hint one tick old: solve tick k, then time ONE solve of tick k+1 (ordered by tick k's iterations)
-        t = []
-        for _ in range(4):
+        ts = []
+        for _ in range(5):
             m.upload(rec)
-            m.solve()
+            m.solve()              # tick k (leaves the iteration counts mode 1 sorts by)
             m.upload(rec_next)
-            t.append(m.time_solve(1))
-        row.append(min(t))
+            ts.append(m.time_solve(1))   # ONE solve of tick k + 1
+        t[name] = min(ts)
         m.close()
-    print(f"   next tick: natural {row[1]:7.4f} ms   ordered by the previous tick {row[3]:7.4f} ms  {100 * (row[1] / row[3] - 1):+5.1f} %   ", end="")
-    row = [row[0], row[2]]
-    print(f"| same batch: {gait:9s} h={h:2d} contacts={nc} b{nb:5d}: natural {row[0]:7.4f} ms {nb / row[0] / 1e3:7.3f} M/s   longest first {row[1]:7.4f} ms {nb / row[1] / 1e3:7.3f} M/s   {100 * (row[0] / row[1] - 1):+5.1f} %")
+    n = t["natural"]
+    print(f"{gait:9s} h={h:2d} contacts={nc} b{nb:5d}      {n:7.4f} ms {nb / n / 1e3:7.3f} M/s     "
+          f"{t['predicted']:7.4f} ms {nb / t['predicted'] / 1e3:7.3f} M/s {100 * (n / t['predicted'] - 1):+5.1f} %     "
+          f"{t['next_tick']:7.4f} ms {nb / t['next_tick'] / 1e3:7.3f} M/s {100 * (n / t['next_tick'] - 1):+5.1f} %", flush=True)
