@@ -281,6 +281,12 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #ifndef HMPC_SCHUR_MFMA
 #define HMPC_SCHUR_MFMA 1  // block start of the fast 256-thread two-contact variants: Schur matrix inverted by 4 x 4 block pivots on the matrix cores (0: two scalar pivots per barrier in registers)
 #endif
+#ifndef HMPC_SCHUR_MFMA_3C
+#define HMPC_SCHUR_MFMA_3C 1    // ... the fast three-contact variant as well (4 x 4 tiles = 64 rows)
+#endif
+#ifndef HMPC_SCHUR_MFMA_WIDE
+#define HMPC_SCHUR_MFMA_WIDE 1  // ... and the wide variant (5 x 5 tiles on eight waves = 80 rows)
+#endif
 #ifndef HMPC_BLOCK_FRICTION
 #define HMPC_BLOCK_FRICTION 1  // block start also takes friction rows violated at the unconstrained minimiser
 #endif
@@ -2217,9 +2223,11 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     constexpr int BLOCK_MIN_NEW = (NC == 3) ? HMPC_BLOCK_MIN_NEW_3C : HMPC_BLOCK_MIN_NEW;
     constexpr int EPT = (NC == 3 && NT < 512) ? HMPC_EPT_3C : 5;  // packed-triangle entries per thread during the Schur inversion
     constexpr int KBMAX_3C = (HMPC_EPT_3C >= 8) ? 63 : ((HMPC_EPT_3C == 7) ? 59 : 54);
-    // Schur matrix of the fast 256-thread two-contact variants on the matrix cores (schur_invert): 3 x 3 tiles = 48 rows
-    constexpr bool SCHUR_MFMA = HMPC_SCHUR_MFMA && !LONGRUN && NT == 256 && NC == 2 && BPT == 1 && QCAP >= 48;
-    constexpr int NTGS = 3;
+    // Schur matrix of the fast variants on the matrix cores (schur_invert): 3 x 3 tiles = 48 rows for the 120-variable variants,
+    // 4 x 4 = 64 rows with three contacts, 5 x 5 = 80 rows for the wide variant (eight waves)
+    constexpr int NTGS = (NT >= 512) ? 5 : (NC == 3 ? 4 : 3);
+    constexpr bool SCHUR_MFMA = HMPC_SCHUR_MFMA && !LONGRUN && NT >= 256 && SM::QMAX >= 16 * NTGS &&
+                                (NC == 2 || HMPC_SCHUR_MFMA_3C) && (NT < 512 || HMPC_SCHUR_MFMA_WIDE);
     constexpr int KBMAX = SCHUR_MFMA ? 16 * NTGS
                                      : ((NT >= 512) ? 71 : ((NT >= 256) ? (NC == 3 ? (KBMAX_3C < SM::QMAX ? KBMAX_3C : SM::QMAX) : 45) : 34));  // KBMAX(KBMAX+1)/2 <= EPT*NT
     static_assert((SCHUR_MFMA || KBMAX * (KBMAX + 1) / 2 <= EPT * NT) && KBMAX <= SM::QMAX, "block start capacity");
@@ -2330,10 +2338,14 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         if (tid == 0) SP.pn.bad = 0;
         __syncthreads();
         switch (wv) {  // uniform: per-wave specialised code
-          case 0: schur_invert<NTGS, 4, 0>(SP, k0, Ep); break;
-          case 1: schur_invert<NTGS, 4, 1>(SP, k0, Ep); break;
-          case 2: schur_invert<NTGS, 4, 2>(SP, k0, Ep); break;
-          default: schur_invert<NTGS, 4, 3>(SP, k0, Ep); break;
+          case 0: schur_invert<NTGS, NW, 0>(SP, k0, Ep); break;
+          case 1: schur_invert<NTGS, NW, 1>(SP, k0, Ep); break;
+          case 2: schur_invert<NTGS, NW, 2>(SP, k0, Ep); break;
+          case 3: schur_invert<NTGS, NW, 3>(SP, k0, Ep); break;
+          case 4: schur_invert<NTGS, NW, (NW > 4 ? 4 : 0)>(SP, k0, Ep); break;  // (cases 4-7: eight-wave variants only)
+          case 5: schur_invert<NTGS, NW, (NW > 4 ? 5 : 0)>(SP, k0, Ep); break;
+          case 6: schur_invert<NTGS, NW, (NW > 4 ? 6 : 0)>(SP, k0, Ep); break;
+          default: schur_invert<NTGS, NW, (NW > 4 ? 7 : 0)>(SP, k0, Ep); break;
         }
         __syncthreads();
         bad_start = SP.pn.bad != 0;
