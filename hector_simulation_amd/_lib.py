@@ -22,7 +22,8 @@ EXPORTS = [
     "hmpc_group_batch", "hmpc_group_member", "hmpc_group_upload_records", "hmpc_group_set_device_records",
     "hmpc_group_solve", "hmpc_group_post_gather", "hmpc_group_wait_gather", "hmpc_group_device_gathered",
     "hmpc_group_gather_wrench", "hmpc_group_download", "hmpc_group_synchronize", "hmpc_group_last_error",
-    "hmpc_group_create_ex", "hmpc_group_contacts", "hmpc_set_max_iterations", "hmpc_legacy_set_max_iterations", "hmpc_tick_solve_device", "hmpc_set_dispatch_order",
+    "hmpc_group_create_ex", "hmpc_group_contacts", "hmpc_group_set_deal", "hmpc_group_deal", "hmpc_group_member_step",
+    "hmpc_upload_records_strided_async", "hmpc_set_max_iterations", "hmpc_legacy_set_max_iterations", "hmpc_tick_solve_device", "hmpc_set_dispatch_order",
 ]
 
 
@@ -132,6 +133,10 @@ def load():
     L.hmpc_group_create.argtypes = [C.POINTER(vp), C.POINTER(ProblemSetup), vp, ci, ci, ci]
     L.hmpc_group_create_ex.argtypes = [C.POINTER(vp), C.POINTER(ProblemSetup), vp, ci, ci, ci, ci]
     L.hmpc_group_contacts.argtypes = [vp]
+    L.hmpc_group_set_deal.argtypes = [vp, ci]
+    L.hmpc_group_deal.argtypes = [vp]
+    L.hmpc_group_member_step.argtypes = [vp, ci]
+    L.hmpc_upload_records_strided_async.argtypes = [vp, vp, ci, C.c_size_t, vp]
     L.hmpc_set_max_iterations.argtypes = [vp, ci]
     L.hmpc_legacy_set_max_iterations.argtypes = [ci]
     L.hmpc_legacy_set_max_iterations.restype = ci

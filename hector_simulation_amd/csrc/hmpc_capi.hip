@@ -493,11 +493,17 @@ int hmpc_destroy(hmpc_handle *h) {
   return HMPC_OK;
 }
 
-static int upload_common(hmpc_handle *h, const void *host_records, int batch, bool async, hipStream_t stream) {
+// pitch = bytes between consecutive records of the batch in host memory (h->stride: a packed array)
+static int upload_common(hmpc_handle *h, const void *host_records, int batch, bool async, hipStream_t stream, size_t pitch = 0) {
   if (!h || !host_records || batch < 0) return HMPC_E_ARG;
   if (batch > h->max_batch) return HMPC_E_BATCH;
+  if (pitch == 0) pitch = h->stride;
+  if (pitch < h->stride) return HMPC_E_ARG;
   HIP_TRY(hipSetDevice(h->device));
-  if (async)
+  if (pitch != h->stride) {
+    if (batch > 0)
+      HIP_TRY(hipMemcpy2DAsync(h->d_records_own, h->stride, host_records, pitch, h->stride, (size_t)batch, hipMemcpyHostToDevice, stream));
+  } else if (async)
     HIP_TRY(hipMemcpyAsync(h->d_records_own, host_records, (size_t)batch * h->stride, hipMemcpyHostToDevice, stream));
   else
     HIP_TRY(hipMemcpy(h->d_records_own, host_records, (size_t)batch * h->stride, hipMemcpyHostToDevice));
@@ -510,7 +516,7 @@ static int upload_common(hmpc_handle *h, const void *host_records, int batch, bo
   const unsigned char *rec = (const unsigned char *)host_records;
   const int nc = h->nc, nfix = fixed_floats(nc);
   for (int b = 0; b < batch; ++b) {
-    const unsigned char *rb = rec + (size_t)b * h->stride;
+    const unsigned char *rb = rec + (size_t)b * pitch;
     const unsigned char *g = rb + 4 * (nfix + 12 * hz);
     float hand_cap = 0.f;
     if (nc == 3) memcpy(&hand_cap, rb + 4 * 72, 4);
@@ -531,6 +537,10 @@ int hmpc_upload_records(hmpc_handle *h, const void *host_records, int batch) {
 
 int hmpc_upload_records_async(hmpc_handle *h, const void *host_records, int batch, void *stream) {
   return upload_common(h, host_records, batch, true, (hipStream_t)stream);
+}
+
+int hmpc_upload_records_strided_async(hmpc_handle *h, const void *host_records, int batch, size_t pitch_bytes, void *stream) {
+  return upload_common(h, host_records, batch, true, (hipStream_t)stream, pitch_bytes);
 }
 
 int hmpc_download_async(hmpc_handle *h, float *forces, uint32_t *status, void *stream) {

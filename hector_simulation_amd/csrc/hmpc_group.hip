@@ -122,8 +122,9 @@ struct Member {
   hipEvent_t packed = nullptr, gathered_ev = nullptr;
   uint32_t *d_pack = nullptr;      // [cap][pw]
   uint32_t *d_gathered = nullptr;  // [G][cap][pw]
-  int lo = 0, n = 0;               // slice of the current batch
-  int posted_lo = 0, posted_n = 0; // slice of the batch whose exchange was posted last (may differ from the current one)
+  int lo = 0, n = 0;               // slice of the current batch: instances lo, lo + step, ... (n of them)
+  int step = 1;                    // 1 = contiguous slice; G = striped deal (hmpc_group_set_deal)
+  int posted_lo = 0, posted_n = 0, posted_step = 1; // slice of the batch whose exchange was posted last (may differ from the current one)
 };
 
 }  // namespace
@@ -142,7 +143,21 @@ struct hmpc_group {
   // collected exchange posts a fresh one for the solves enqueued since
   bool gather_posted = false;
   bool exchange_repair = true; // members run the device-side safe pass inside every solve: the exchange carries repaired rows
+  int deal = HMPC_DEAL_CONTIGUOUS;  // how a batch is dealt to the members (hmpc_group_set_deal)
 };
+
+namespace {
+// member i's share of a batch: first instance, count, index step
+inline void member_share(const hmpc_group *g, int batch, int i, int *lo, int *n, int *step) {
+  if (g->deal == HMPC_DEAL_STRIPED) {
+    *lo = i, *step = g->G, *n = (batch > i) ? (batch - i + g->G - 1) / g->G : 0;
+  } else {
+    int hi;
+    hmpc_shard_bounds(batch, g->G, i, lo, &hi);
+    *n = hi - *lo, *step = 1;
+  }
+}
+}  // namespace
 
 #define GENTER() g_group_err.clear() /* a stale group-level message must not shadow a later member-level one */
 
@@ -303,6 +318,11 @@ int hmpc_group_size(const hmpc_group *g) { return g ? g->G : HMPC_E_ARG; }
 int hmpc_group_transport(const hmpc_group *g) { return g ? g->transport : HMPC_E_ARG; }
 int hmpc_group_batch(const hmpc_group *g) { return g ? g->batch : HMPC_E_ARG; }
 
+int hmpc_group_member_step(const hmpc_group *g, int member) {
+  if (!g || member < 0 || member >= g->G) return HMPC_E_ARG;
+  return g->m[member].step;
+}
+
 int hmpc_group_member(hmpc_group *g, int member, hmpc_handle **handle, int *device, int *lo, int *n, void **solve_stream) {
   if (!g || member < 0 || member >= g->G) return HMPC_E_ARG;
   const Member &mb = g->m[member];
@@ -324,16 +344,30 @@ int hmpc_group_upload_records(hmpc_group *g, const void *host_records, int batch
   if (!host_records) host_records = &empty;  // batch == 0
   for (int i = 0; i < g->G; ++i) {
     Member &mb = g->m[i];
-    int lo, hi;
-    hmpc_shard_bounds(batch, g->G, i, &lo, &hi);
-    mb.lo = lo, mb.n = hi - lo;
-    const int rc = hmpc_upload_records_async(mb.h, (const unsigned char *)host_records + (size_t)lo * stride, mb.n,
-                                             mb.solve_stream);
+    member_share(g, batch, i, &mb.lo, &mb.n, &mb.step);
+    // (striped deal: one strided copy per member -- rows lo, lo + G, ... of the host batch -- no host staging)
+    const int rc = hmpc_upload_records_strided_async(mb.h, (const unsigned char *)host_records + (size_t)mb.lo * stride, mb.n,
+                                                     (size_t)mb.step * stride, mb.solve_stream);
     if (rc != HMPC_OK) return rc;
   }
   g->batch = batch;
   return HMPC_OK;
 }
+
+// How a batch is dealt to the members.  HMPC_DEAL_CONTIGUOUS (default): member i holds the contiguous slice of
+// hmpc_shard_bounds.  HMPC_DEAL_STRIPED: member i holds instances i, i + G, i + 2 G, ... -- a parameter sweep is usually ORDERED
+// (by commanded velocity, by gait phase ...), so its hard instances sit next to each other, a contiguous slice hands them all to
+// one GPU, and the gather waits for that one; dealt round-robin every member gets the same mix (measured: tests/test_gpu_group.py
+// ::test_striped_deal_balances_a_skewed_batch).  Same member sizes either way.  Host-facing results (hmpc_group_gather_wrench,
+// hmpc_group_download) are in instance order in both modes; the device-resident gathered block keeps its [member][row] layout,
+// row r of slot s being instance s + r G in striped mode.  Takes effect with the next upload / set_device_records.
+int hmpc_group_set_deal(hmpc_group *g, int deal) {
+  GENTER();
+  if (!g || (deal != HMPC_DEAL_CONTIGUOUS && deal != HMPC_DEAL_STRIPED)) return HMPC_E_ARG;
+  g->deal = deal;
+  return HMPC_OK;
+}
+int hmpc_group_deal(const hmpc_group *g) { return g ? g->deal : HMPC_E_ARG; }
 
 // records already resident on each member's device: slice sizes are taken from the shard arithmetic, the caller supplies
 // one device pointer per member (device_records[i] points at that member's first record, on that member's device)
@@ -343,9 +377,7 @@ int hmpc_group_set_device_records(hmpc_group *g, const void *const *device_recor
   if (batch > g->max_batch) return HMPC_E_BATCH;
   for (int i = 0; i < g->G; ++i) {
     Member &mb = g->m[i];
-    int lo, hi;
-    hmpc_shard_bounds(batch, g->G, i, &lo, &hi);
-    mb.lo = lo, mb.n = hi - lo;
+    member_share(g, batch, i, &mb.lo, &mb.n, &mb.step);  // (striped deal: the caller's buffers hold instances i, i + G, ...)
     if (mb.n > 0 && !device_records[i]) return HMPC_E_ARG;
     int rc = hmpc_set_device_records(mb.h, mb.n > 0 ? device_records[i] : (const void *)mb.d_pack, mb.n);
     if (rc == HMPC_OK) rc = hmpc_set_max_reduced_vars(mb.h, max_reduced_vars);
@@ -411,7 +443,7 @@ int hmpc_group_post_gather(hmpc_group *g) {
     }
     GHIP(hipEventRecord(mb.packed, mb.solve_stream));
     GHIP(hipStreamWaitEvent(mb.comm_stream, mb.packed, 0));
-    mb.posted_lo = mb.lo, mb.posted_n = mb.n;  // hmpc_group_gather_wrench unpacks THIS batch's slices
+    mb.posted_lo = mb.lo, mb.posted_n = mb.n, mb.posted_step = mb.step;  // hmpc_group_gather_wrench unpacks THIS batch's slices
   }
   const size_t slice_words = (size_t)g->cap * PACK_WORDS;
   if (g->transport == HMPC_GROUP_RCCL) {
@@ -491,8 +523,9 @@ int hmpc_group_gather_wrench(hmpc_group *g, float *host_wrench, uint32_t *host_s
     const Member &mb = g->m[s];
     const uint32_t *rows = g->h_stage + (size_t)s * slice_words;
     for (int i = 0; i < mb.posted_n; ++i) {
-      if (host_wrench) memcpy(host_wrench + (size_t)(mb.posted_lo + i) * nw, rows + (size_t)i * PACK_WORDS, nw * sizeof(float));
-      if (host_status) host_status[mb.posted_lo + i] = rows[(size_t)i * PACK_WORDS + nw];
+      const size_t inst = (size_t)mb.posted_lo + (size_t)i * mb.posted_step;
+      if (host_wrench) memcpy(host_wrench + inst * nw, rows + (size_t)i * PACK_WORDS, nw * sizeof(float));
+      if (host_status) host_status[inst] = rows[(size_t)i * PACK_WORDS + nw];
     }
   }
   return HMPC_OK;
@@ -504,9 +537,24 @@ int hmpc_group_download(hmpc_group *g, float *forces, uint32_t *status) {
   GENTER();
   if (!g) return HMPC_E_ARG;
   const size_t width = (size_t)6 * g->nc * g->setup.horizon;
+  std::vector<float> tf;
+  std::vector<uint32_t> ts;
   for (Member &mb : g->m) {
-    const int rc = hmpc_download(mb.h, forces ? forces + (size_t)mb.lo * width : nullptr, status ? status + mb.lo : nullptr);
+    if (mb.step == 1) {
+      const int rc = hmpc_download(mb.h, forces ? forces + (size_t)mb.lo * width : nullptr, status ? status + mb.lo : nullptr);
+      if (rc != HMPC_OK) return rc;
+      continue;
+    }
+    // striped deal: the member's block comes back contiguous and is dealt out to instances lo, lo + step, ...
+    tf.resize(forces ? (size_t)mb.n * width : 0);
+    ts.resize(status ? (size_t)mb.n : 0);
+    const int rc = hmpc_download(mb.h, forces ? tf.data() : nullptr, status ? ts.data() : nullptr);
     if (rc != HMPC_OK) return rc;
+    for (int i = 0; i < mb.n; ++i) {
+      const size_t inst = (size_t)mb.lo + (size_t)i * mb.step;
+      if (forces) memcpy(forces + inst * width, tf.data() + (size_t)i * width, width * sizeof(float));
+      if (status) status[inst] = ts[i];
+    }
   }
   return HMPC_OK;
 }

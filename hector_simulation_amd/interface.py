@@ -327,6 +327,13 @@ class DeviceGroup:
     def solve(self) -> None:
         self._check(self.L.hmpc_group_solve(self.g), "hmpc_group_solve")
 
+    def set_deal(self, striped: bool) -> None:
+        """Contiguous slices (default) or round-robin: member i holds instances i, i + G, ... (hmpc_group_set_deal)."""
+        self._check(self.L.hmpc_group_set_deal(self.g, 1 if striped else 0), "hmpc_group_set_deal")
+
+    def member_step(self, i: int) -> int:
+        return int(self.L.hmpc_group_member_step(self.g, int(i)))
+
     def set_exchange_repair(self, on: bool) -> None:
         self._check(self.L.hmpc_group_set_exchange_repair(self.g, 1 if on else 0), "hmpc_group_set_exchange_repair")
 

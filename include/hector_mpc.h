@@ -220,6 +220,9 @@ int hmpc_set_device_repair(hmpc_handle *h, int on);
  * and must stay valid until the stream reaches them.  hmpc_download_async does not run the safe pass: check the status
  * words after synchronising and call hmpc_resolve_failed + hmpc_download for a batch that has flagged instances. */
 int hmpc_upload_records_async(hmpc_handle *h, const void *host_records, int batch, void *stream);
+/* ... every pitch_bytes-th record of a larger host array (pitch_bytes >= hmpc_record_stride, a multiple of 4): record k of the
+ * batch is read at host_records + k * pitch_bytes -- one strided copy, no host staging (what a striped device group uses). */
+int hmpc_upload_records_strided_async(hmpc_handle *h, const void *host_records, int batch, size_t pitch_bytes, void *stream);
 int hmpc_download_async(hmpc_handle *h, float *forces, uint32_t *status, void *stream);
 int hmpc_get_device_outputs(hmpc_handle *h, float **device_forces, uint32_t **device_status);
 int hmpc_batch(const hmpc_handle *h);
@@ -317,6 +320,10 @@ int hmpc_debug_phase_cycles(hmpc_handle *h, long long *cycles);
  * hipMemcpyPeerAsync copies), so the exchange of solve k runs under solve k+1; afterwards EVERY member holds the
  * gathered block in HBM (hmpc_group_device_gathered) and hmpc_group_gather_wrench also hands it to the host. */
 typedef struct hmpc_group hmpc_group;
+enum hmpc_group_deal {
+  HMPC_DEAL_CONTIGUOUS = 0, /* member i holds the contiguous slice of hmpc_shard_bounds (default) */
+  HMPC_DEAL_STRIPED = 1     /* member i holds instances i, i + G, i + 2 G, ...: an ORDERED sweep's hard instances are spread over all members */
+};
 enum hmpc_group_transport {
   HMPC_GROUP_AUTO = 0, /* RCCL when all listed devices are distinct, else P2P */
   HMPC_GROUP_RCCL = 1,
@@ -339,6 +346,12 @@ int hmpc_group_batch(const hmpc_group *g);
 /* member's handle (for the per-handle switches), device, slice of the current batch and solve stream; any may be NULL */
 int hmpc_group_member(hmpc_group *g, int member, hmpc_handle **handle, int *device, int *lo, int *n, void **solve_stream);
 int hmpc_group_upload_records(hmpc_group *g, const void *host_records, int batch);
+/* How the next batch is dealt to the members (enum hmpc_group_deal).  Host-facing results (hmpc_group_gather_wrench,
+ * hmpc_group_download) are in instance order either way; member sizes are the same either way; in striped mode row r of slot s
+ * of the device-resident gathered block is instance s + r G, and hmpc_group_member_step returns G (1 for contiguous slices). */
+int hmpc_group_set_deal(hmpc_group *g, int deal);
+int hmpc_group_deal(const hmpc_group *g);
+int hmpc_group_member_step(const hmpc_group *g, int member);
 /* device_records[i] = member i's first record, resident on member i's device (slice sizes from hmpc_shard_bounds) */
 int hmpc_group_set_device_records(hmpc_group *g, const void *const *device_records, int batch, int max_reduced_vars);
 int hmpc_group_solve(hmpc_group *g);       /* asynchronous on every member */

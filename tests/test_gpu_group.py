@@ -220,3 +220,81 @@ def test_group_of_three_contact_handles_cfg5_split(devices, transport, nb):
     np.testing.assert_array_equal(full_f.view(np.uint32), ref_f.view(np.uint32))
     np.testing.assert_array_equal(full_s, ref_s)
     grp.close()
+
+
+def _predicted_cost(rec, h):
+    """host restatement of the kernel-side predictor's score (hmpc_builder.h predicted_cost_bucket), two contacts"""
+    f = np.ascontiguousarray(rec[:, : 4 * (54 + 12 * h)]).view(np.float32)
+    u = (f[:, 54 + 9] - f[:, 3]) + 2.0 * 0.5 * (f[:, 13] + f[:, 14])
+    return np.where(u > 0, u, -0.05 * u)
+
+
+def test_striped_deal_balances_a_skewed_batch():
+    """group-level balance.  A parameter sweep is usually ORDERED, so its hard instances sit together; cut
+    into contiguous slices one member gets all of them and the gather waits for it.  Batch sorted hardest-first (by the record-only
+    cost predictor, i.e. the worst case for contiguous slices), four members on the box's one GPU, each member's solve timed ALONE:
+      contiguous slices: the first member's kernel takes much longer than the last one's;
+      striped deal (hmpc_group_set_deal): all members within 10 % of each other;
+    and the host-facing results are the same, in instance order, bit for bit, either way."""
+    h, nb, G = 10, 8192, 4
+    f = synthetic.make_batch(nb, h, "standing", seed=6, phase="random")
+    rec = records.pack_records(f, h)
+    rec = np.ascontiguousarray(rec[np.argsort(-_predicted_cost(rec, h), kind="stable")])  # an ordered sweep: hardest first
+    grp = interface.DeviceGroup(synthetic.DT_MPC, h, synthetic.F_MAX, nb, [0] * G, transport="p2p")
+    L = grp.L
+    out, times = {}, {}
+    for striped in (False, True):
+        grp.set_deal(striped)
+        grp.upload(rec)
+        grp.solve()
+        grp.synchronize()
+        ms = []
+        for i in range(G):
+            hdl, _, lo, n, st = grp.member(i)
+            assert grp.member_step(i) == (G if striped else 1) and lo == (i if striped else i * (nb // G)) and n == nb // G
+            L.hmpc_set_dispatch_order(hdl, 0)   # natural order inside a member: what is compared is the DEAL
+            best = 1e9
+            for _ in range(3):
+                t = C.c_float(0)
+                assert L.hmpc_time_solve(hdl, C.c_void_p(st), 5, C.byref(t)) == 0
+                best = min(best, t.value)
+            ms.append(best)
+        times[striped] = ms
+        grp.solve()
+        wrench, wstat = grp.gather_wrench()
+        forces, status = grp.download()
+        out[striped] = (wrench.copy(), wstat.copy(), forces.copy(), status.copy())
+    grp.close()
+    for a, b in zip(out[False], out[True]):
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    np.testing.assert_array_equal(out[True][0], out[True][2][:, :12])     # the gathered wrench = step 0 of the forces
+    assert (interface.status_code(out[True][3]) == 0).all()
+    cont, strp = np.array(times[False]), np.array(times[True])
+    print("member kernel ms, contiguous slices:", np.round(cont, 4), " striped:", np.round(strp, 4))
+    assert cont.max() / cont.min() > 1.15, cont        # the skew is real ...
+    assert strp.max() / strp.min() < 1.10, strp        # ... and the striped deal removes it
+    assert strp.max() < cont.max()                     # the member the gather waits for got faster
+
+
+@pytest.mark.parametrize("nb,G", [(101, 3), (7, 4), (2, 4), (0, 2)])
+def test_striped_deal_ragged_batches_equal_a_single_handle(nb, G):
+    """striped deal with batch sizes that do not divide (and members left empty): instance order on the host side, bit for bit."""
+    rec = records.pack_records(synthetic.make_batch(max(nb, 1), H, "mixed", seed=13, phase="random"), H)[:nb]
+    grp = interface.DeviceGroup(synthetic.DT_MPC, H, synthetic.F_MAX, max(nb, 1), [0] * G, transport="p2p")
+    grp.set_deal(True)
+    grp.upload(rec)
+    seen = []
+    for i in range(G):
+        _, _, lo, n, _ = grp.member(i)
+        seen += [lo + k * grp.member_step(i) for k in range(n)]
+    assert sorted(seen) == list(range(nb))
+    grp.solve()
+    wrench, wstat = grp.gather_wrench()
+    forces, status = grp.download()
+    grp.close()
+    if nb:
+        ref_f, ref_s = _single(rec)
+        np.testing.assert_array_equal(status, ref_s)
+        np.testing.assert_array_equal(forces.view(np.uint32), ref_f.view(np.uint32))
+        np.testing.assert_array_equal(wrench.view(np.uint32), ref_f[:, :12].view(np.uint32))
+        np.testing.assert_array_equal(wstat, ref_s)
