@@ -278,6 +278,9 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
      defined(HMPC_MFS_ONLY_WAVE)) && !defined(HMPC_DEV_TIMING)
 #error "HMPC_MFS_NO_* / HMPC_MFS_ONLY_WAVE give wrong results by design: timing builds only, add -DHMPC_DEV_TIMING"
 #endif
+#ifndef HMPC_MFS_PST_PAD
+#define HMPC_MFS_PST_PAD 18  // padding of a pivot-panel row in doubles (16: the round-4 layout), see MfsPanel
+#endif
 #ifndef HMPC_SCHUR_MFMA
 #define HMPC_SCHUR_MFMA 1  // block start of the fast 256-thread two-contact variants: Schur matrix inverted by 4 x 4 block pivots on the matrix cores (0: two scalar pivots per barrier in registers)
 #endif
@@ -403,7 +406,6 @@ template <int NTG, int NWV>
 struct MfsGrid {
   static constexpr int NTILES = NTG * (NTG + 1) / 2;
   static constexpr int TPW = (NTILES + NWV - 1) / NWV;  // accumulator tiles per wave (some waves may hold one less)
-  static constexpr int PST = 16 * NTG + 16;             // panel row stride in doubles (= 128 mod 256 bytes: the four rows of a read hit different banks)
 };
 template <int NTG, int NWV>
 using MfsAcc = hmpc_d4[MfsGrid<NTG, NWV>::TPW];  // a wave's accumulator tiles
@@ -423,7 +425,12 @@ static_assert(mfs_count(12, 4, 0) == 20 && mfs_count(12, 4, 1) == 20 && mfs_coun
 static_assert(mfs_count(8, 4, 0) == 9 && mfs_count(8, 4, 3) == 9, "8 x 8 deal");
 template <int NTG>
 struct MfsPanel {
-  static constexpr int PST = 16 * NTG + 16;
+  // panel row stride in doubles.  Round 4 used 16 NTG + 16 (= 0 mod 32 banks): the four rows of a B-operand read hit different
+  // banks, but the column-tile publishes -- four lanes per 16-lane group writing the four panel ROWS at one column -- were 4-way
+  // bank conflicts (LDS conflict cycles 11 % -> 22 % of the LDS-active cycles).  HMPC_MFS_PST_PAD = 18 gives a row
+  // stride of 4 mod 32 banks: those writes are conflict-free, a B-operand read costs one extra LDS cycle (two of its 32 lanes
+  // meet on a bank).
+  static constexpr int PST = 16 * NTG + HMPC_MFS_PST_PAD;
   double P[2][4][PST];   // pivot panel rows, double buffered; the K columns carry D - I
   double Dinv[2][4][4];  // inverse of the pivot block
   double Draw[4][4];     // the pivot block itself, as it is (recovering D from the panel's D - I would cost the small pivots --

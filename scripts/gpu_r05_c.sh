@@ -1,0 +1,13 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_group.py tests/test_gpu_dispatch_order.py tests/test_gpu_solve.py -m gpu -x -q -s 2>&1 | grep -v amdgpu.ids | tail -8
+echo "== current build (PST pad 18)"
+timeout 600 python scripts/quick_times.py standing_b8192 standing_b1024 h20_single_b4096 3contact_b8192 h20_double_b2048 2>&1 | grep -v amdgpu.ids
+cp hector_simulation_amd/libhector_mpc_hip.so /tmp/keep.so; cp hector_simulation_amd/libhector_mpc_hip.so.srchash /tmp/keep.hash
+for F in "-DHMPC_MFS_PST_PAD=16" "-DHMPC_MFS_PST_PAD=20"; do
+  echo "== flags: $F"
+  HMPC_EXTRA_FLAGS="$F" timeout 900 python scripts/quick_times.py standing_b8192 standing_b1024 h20_single_b4096 3contact_b8192 h20_double_b2048 2>&1 | grep -v amdgpu.ids
+done
+cp /tmp/keep.so hector_simulation_amd/libhector_mpc_hip.so; cp /tmp/keep.hash hector_simulation_amd/libhector_mpc_hip.so.srchash
+echo "== current build again"
+timeout 600 python scripts/quick_times.py standing_b8192 standing_b1024 h20_single_b4096 2>&1 | grep -v amdgpu.ids

@@ -18,7 +18,16 @@
 #include <vector>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+#ifdef LOOKAHEAD
+// -DLOOKAHEAD (round 5): the pivot block's inverse leaves the critical path.  The 36 tiles are dealt to THREE waves (12 each);
+// the fourth wave holds a private copy of the diagonal tile that hosts the NEXT pivot block, applies the step's update to it
+// first (one matrix instruction, same operands as the owner's: the same bits), picks the next pivot block out of it and runs the
+// LDL' while the other three waves are still in their matrix instructions; the owner of a diagonal tile hands it over through
+// LDS once every four steps.
+constexpr int N = 120, NP = 128, NT = 256, NTI = 8, TPW = 12;  // tiles per (tile-holding) wave
+#else
 constexpr int N = 120, NP = 128, NT = 256, NTI = 8, TPW = 9;  // tiles per wave
+#endif
 constexpr int PST = NP + 8;                                   // panel row stride (doubles)
 
 __device__ __forceinline__ double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -38,7 +47,8 @@ struct Smem {
   double P[2][4][PST];  // published pivot panel rows (double buffered); the K columns carry D - I
   double Dinv[2][4][4]; // inverse of the step's 4x4 pivot block, published with the panel by the wave that owns the diagonal tile
   double Draw[4][4];    // the pivot block as it is (D recovered from the panel's D - I would cost small pivots three digits)
-  double pad[5200];     // brings the footprint to the headline variant's (three workgroups per CU by LDS as well)
+  double DT[256];       // LOOKAHEAD: hand-over of a diagonal tile to the pivot wave, register r of lane l at 64 r + l
+  double pad[5200 - 256];     // brings the footprint to the headline variant's (three workgroups per CU by LDS as well)
 };
 
 // tile t (0..35, block-row-major over I <= J) -> (I, J)
@@ -55,6 +65,56 @@ constexpr int tile_j(int t) {
 
 // one wave's share of the sweeps; WV (its index in the workgroup) is a template parameter so that the tile coordinates are
 // compile-time constants: LDS addresses become immediate offsets, no address registers, no coordinate tables
+__device__ __forceinline__ void ldl_dinv_row(Smem &S, const int s, const int g, const int c);
+
+#ifdef LOOKAHEAD
+// the pivot wave (wave 3)
+__device__ __forceinline__ void pivot_wave(Smem &S, long long *cyc, int n) {
+  const int tid = threadIdx.x, ln = tid & 63, g = ln >> 4, c = ln & 15;
+#ifdef DESYNC
+  for (int d = 0; d < (int)((blockIdx.x * 37u) % 61u) * 64; ++d) __builtin_amdgcn_s_sleep(1);
+  __syncthreads();
+#endif
+  d4 dt;
+  auto pick = [&](const d4 &v, int rr) __attribute__((always_inline)) -> double {
+    const double lo = (rr & 1) ? v[1] : v[0], hi = (rr & 1) ? v[3] : v[2];
+    return (rr & 2) ? hi : lo;
+  };
+  auto load_dt = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dt[r] = S.DT[64 * r + ln];
+  };
+  // pivot block of step sp out of the private tile -> Draw -> row g of its inverse -> Dinv[sp & 1]
+  auto invert = [&](const int sp) __attribute__((always_inline)) {
+    const int rr = sp & 3, c0 = 4 * rr;
+    const double v = pick(dt, rr);
+    if (c >= c0 && c < c0 + 4) S.Draw[g][c - c0] = v;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    ldl_dinv_row(S, sp, g, c);
+  };
+  __syncthreads();  // (prologue: the owner of tile (0, 0) has handed it over)
+  load_dt();
+  invert(0);
+  __syncthreads();
+  const int nsteps = (n + 3) >> 2;
+#pragma unroll 1
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) {
+      const int Ik1 = (s + 1) >> 2;
+      if (((s + 1) & 3) == 0) load_dt();  // a new diagonal tile, handed over at the end of step s - 1
+      const double(*P)[PST] = S.P[s & 1];
+      const double x0 = S.Dinv[s & 1][g][0], x1 = S.Dinv[s & 1][g][1], x2 = S.Dinv[s & 1][g][2], x3 = S.Dinv[s & 1][g][3];
+      const int m = 16 * Ik1 + c;
+      const double a = -dfma(x3, P[3][m], dfma(x2, P[2][m], dfma(x1, P[1][m], x0 * P[0][m])));
+      const double b = P[g][m];
+      dt = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, dt, 0, 0, 0);
+      invert(s + 1);
+    }
+    __syncthreads();
+  }
+}
+#endif
+
 template <int WV>
 __device__ __forceinline__ void sweep_wave(Smem &S, const double *H, double *M, long long *cyc, int n) {
   const int tid = threadIdx.x, ln = tid & 63, g = ln >> 4, c = ln & 15;
@@ -95,33 +155,7 @@ __device__ __forceinline__ void sweep_wave(Smem &S, const double *H, double *M, 
   //   S = C - B' A^-1 B,  x_lo = S^-1 (v - B' A^-1 u),  x_hi = A^-1 u - (A^-1 B) x_lo      for e_g = [u; v]
   // Computed ONCE per step, by the wave that owns the diagonal tile, right after it has published the panel (its own LDS
   // writes are visible to it after a wait): lanes c == 0 publish the four rows.
-  auto publish_dinv = [&](const int s) __attribute__((always_inline)) {
-    // LDL' in pivot order: backward stable for the positive definite block (closed-form 2 x 2 determinants lose cond(D) eps)
-    const double(*D)[4] = S.Draw;
-    const double d00 = D[0][0], d10 = D[1][0], d20 = D[2][0], d30 = D[3][0];
-    const double d11 = D[1][1], d21 = D[2][1], d31 = D[3][1], d22 = D[2][2], d32 = D[3][2], d33 = D[3][3];
-    const double i0 = rcp_nr(d00);
-    const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
-    const double e1 = dfma(-l10, d10, d11), i1 = rcp_nr(e1);
-    const double m21 = dfma(-l20, d10, d21), m31 = dfma(-l30, d10, d31);
-    const double l21 = m21 * i1, l31 = m31 * i1;
-    const double e2 = dfma(-l21, m21, dfma(-l20, d20, d22)), i2 = rcp_nr(e2);
-    const double m32 = dfma(-l31, m21, dfma(-l30, d20, d32));
-    const double l32 = m32 * i2;
-    const double e3 = dfma(-l32, m32, dfma(-l31, m31, dfma(-l30, d30, d33))), i3 = rcp_nr(e3);
-    double y0 = (g == 0) ? 1.0 : 0.0, y1 = (g == 1) ? 1.0 : 0.0, y2 = (g == 2) ? 1.0 : 0.0, y3 = (g == 3) ? 1.0 : 0.0;
-    y1 = dfma(-l10, y0, y1);
-    y2 = dfma(-l21, y1, dfma(-l20, y0, y2));
-    y3 = dfma(-l32, y2, dfma(-l31, y1, dfma(-l30, y0, y3)));
-    const double x3 = y3 * i3;
-    const double x2 = dfma(-l32, x3, y2 * i2);
-    const double x1 = dfma(-l31, x3, dfma(-l21, x2, y1 * i1));
-    const double x0 = dfma(-l30, x3, dfma(-l20, x2, dfma(-l10, x1, y0 * i0)));
-    if (c == 0) {
-      double *dst = S.Dinv[s & 1][g];
-      dst[0] = x0, dst[1] = x1, dst[2] = x2, dst[3] = x3;
-    }
-  };
+  auto publish_dinv = [&](const int s) __attribute__((always_inline)) { ldl_dinv_row(S, s, g, c); };
   // One computed jump on the tile row of the pivot instead of two tests per tile: inside a case the tile coordinates AND the
   // pivot's tile row are compile-time constants, so only the tiles that really hold panel entries leave code behind.
   auto publish_ik = [&](auto ikc, const int s, const int rr) __attribute__((always_inline)) {
@@ -133,14 +167,18 @@ __device__ __forceinline__ void sweep_wave(Smem &S, const double *H, double *M, 
       if (tI[t] == IK) {  // compile time
         double v = pick(acc[t], rr);
         if (tJ[t] == IK) {
+#ifndef LOOKAHEAD
           if (c >= c0 && c < c0 + 4) S.Draw[g][c - c0] = v;
+#endif
           v -= (c == c0 + g) ? 1.0 : 0.0;
         }
         P[g][16 * tJ[t] + c] = v;
+#ifndef LOOKAHEAD
         if (tJ[t] == IK) {  // this wave owns the diagonal tile = the pivot block
           __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes have landed
           publish_dinv(s);
         }
+#endif
       } else if (tJ[t] == IK) {
         if (c >= c0 && c < c0 + 4) {
 #pragma unroll
@@ -149,7 +187,23 @@ __device__ __forceinline__ void sweep_wave(Smem &S, const double *H, double *M, 
       }
     }
   };
+  auto handover = [&](const int sp) __attribute__((always_inline)) {  // sp = -1: the prologue (tile (0, 0) as it is)
+#ifdef LOOKAHEAD
+    if (((sp + 1) & 3) == 0) {
+      const int In = (sp + 1) >> 2;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+        if (tI[t] == tJ[t]) {  // compile time
+          if (tI[t] == In) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S.DT[64 * r + ln] = acc[t][r];
+          }
+        }
+    }
+#endif
+  };
   auto publish = [&](const int s, const int rr) __attribute__((always_inline)) {
+    handover(s);
     switch (s >> 2) {  // uniform
       case 0: publish_ik(std::integral_constant<int, 0>(), s, rr); break;
       case 1: publish_ik(std::integral_constant<int, 1>(), s, rr); break;
@@ -207,8 +261,17 @@ __device__ __forceinline__ void sweep_wave(Smem &S, const double *H, double *M, 
         for (int r = 0; r < 4; ++r) acc[t][r] -= (r == rr) ? two : 0.0;
       }
   };
+#ifdef LOOKAHEAD
+  handover(-1);
+  __syncthreads();
+  {  // P(0) (publish() would hand tile 1 over at s = 3 only: handover(0) is a no-op)
+    publish(0, 0);
+  }
+  __syncthreads();
+#else
   publish(0, 0);
   __syncthreads();
+#endif
   const int nsteps = (n + 3) >> 2;
 #pragma unroll 1
   for (int s = 0; s < nsteps; ++s) {
@@ -240,9 +303,41 @@ __global__ __launch_bounds__(NT, 3) void sweep_kernel(const double *Hin, double 
     case 0: sweep_wave<0>(S, H, M, cyc, n); break;
     case 1: sweep_wave<1>(S, H, M, cyc, n); break;
     case 2: sweep_wave<2>(S, H, M, cyc, n); break;
+#ifdef LOOKAHEAD
+    default: pivot_wave(S, cyc, n); break;
+#else
     default: sweep_wave<3>(S, H, M, cyc, n); break;
+#endif
   }
 }
+
+__device__ __forceinline__ void ldl_dinv_row(Smem &S, const int s, const int g, const int c) {
+    // LDL' in pivot order: backward stable for the positive definite block (closed-form 2 x 2 determinants lose cond(D) eps)
+    const double(*D)[4] = S.Draw;
+    const double d00 = D[0][0], d10 = D[1][0], d20 = D[2][0], d30 = D[3][0];
+    const double d11 = D[1][1], d21 = D[2][1], d31 = D[3][1], d22 = D[2][2], d32 = D[3][2], d33 = D[3][3];
+    const double i0 = rcp_nr(d00);
+    const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+    const double e1 = dfma(-l10, d10, d11), i1 = rcp_nr(e1);
+    const double m21 = dfma(-l20, d10, d21), m31 = dfma(-l30, d10, d31);
+    const double l21 = m21 * i1, l31 = m31 * i1;
+    const double e2 = dfma(-l21, m21, dfma(-l20, d20, d22)), i2 = rcp_nr(e2);
+    const double m32 = dfma(-l31, m21, dfma(-l30, d20, d32));
+    const double l32 = m32 * i2;
+    const double e3 = dfma(-l32, m32, dfma(-l31, m31, dfma(-l30, d30, d33))), i3 = rcp_nr(e3);
+    double y0 = (g == 0) ? 1.0 : 0.0, y1 = (g == 1) ? 1.0 : 0.0, y2 = (g == 2) ? 1.0 : 0.0, y3 = (g == 3) ? 1.0 : 0.0;
+    y1 = dfma(-l10, y0, y1);
+    y2 = dfma(-l21, y1, dfma(-l20, y0, y2));
+    y3 = dfma(-l32, y2, dfma(-l31, y1, dfma(-l30, y0, y3)));
+    const double x3 = y3 * i3;
+    const double x2 = dfma(-l32, x3, y2 * i2);
+    const double x1 = dfma(-l31, x3, dfma(-l21, x2, y1 * i1));
+    const double x0 = dfma(-l30, x3, dfma(-l20, x2, dfma(-l10, x1, y0 * i0)));
+    if (c == 0) {
+      double *dst = S.Dinv[s & 1][g];
+      dst[0] = x0, dst[1] = x1, dst[2] = x2, dst[3] = x3;
+    }
+  }
 
 int main(int argc, char **argv) {
   const int nb = argc > 1 ? atoi(argv[1]) : 3072, n = argc > 2 ? atoi(argv[2]) : 120;
