@@ -626,7 +626,7 @@ def main() -> None:
     single_stream_s = time.perf_counter() - ts0
 
     # the headline loop once more in natural dispatch order (hmpc_set_dispatch_order(0)): what the ordering is worth
-    natural_s = None
+    natural_s = predicted_s = None
     if xch is None and world == 1:
         for m in mpcs:
             m.set_dispatch_order(False)
@@ -638,8 +638,22 @@ def main() -> None:
             step()
         torch.cuda.synchronize()
         natural_s = time.perf_counter() - tn0
+        # ... and ordered by the record-only cost predictor (mode 2: what a cold handle gets)
         for m in mpcs:
-            m.set_dispatch_order(True)
+            m.set_dispatch_order(2)
+        for _ in range(max(2, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        predicted_s = time.perf_counter() - tp0
+        for m in mpcs:
+            m.set_dispatch_order(1)
+        for _ in range(2):   # (back to the default mode: the next solves are ordered by a previous one again)
+            step()
+        torch.cuda.synchronize()
 
     # dominant kernel's own duration: HIP events on the launch stream, kernel launches only (no collective); tick batch `rec`
     # ordered by the solve of the other tick batch before it, as in the timed loop
@@ -748,7 +762,11 @@ def main() -> None:
                         "the same instances one tick apart (the other of the two tick batches) -- never of the same data; the sort "
                         "(one small launch) is inside the timed region; results do not depend on the order",
                 "natural_order": None if natural_s is None else {"value": world * B * args.steps / natural_s,
-                                                                 "ms_per_step": 1e3 * natural_s / args.steps}},
+                                                                 "ms_per_step": 1e3 * natural_s / args.steps},
+                "predicted_order": None if predicted_s is None else {
+                    "value": world * B * args.steps / predicted_s, "ms_per_step": 1e3 * predicted_s / args.steps,
+                    "what": "hmpc_set_dispatch_order(2): every solve ordered by the cost predicted from its records alone "
+                            "(what a cold handle gets; hmpc_builder.h predicted_cost_bucket)"}},
             "fp64_valu_frac": fp64_tf / FP64_VALU_PEAK_TF,
             "fp64_valu": {"achieved": fp64_tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                           "useful_flop_per_solve": fp64_flop,
@@ -765,54 +783,48 @@ def main() -> None:
         try:
             if args.no_side_configs or world > 1 or nc != 2:  # (side measurements belong to the default single-GPU line)
                 raise StopIteration
+            # Every side config in the three dispatch orders (hmpc_set_dispatch_order), with ONE protocol: solve tick k, then time
+            # ONE solve of the same instances one 5 ms tick later (best of 4) -- never a batch ordered by the answer to its own data:
+            #   natural   = mode 0;  predicted = mode 2 (what a COLD handle gets: cost predicted from the records alone);
+            #   next_tick = mode 1 (the default in an MPC loop: ordered by the previous tick's iteration counts)
+            def three_orders(fields2, hh, bb, ncs):
+                rec_a = records.pack_records(fields2, hh, ncs)
+                rec_b = records.pack_records(synthetic.advance_tick(fields2, hh, seed=9), hh, ncs)
+                res2 = {}
+                for oname, mode in (("natural", 0), ("predicted", 2), ("next_tick", 1)):
+                    mm = interface.BatchedMPC(synthetic.DT_MPC, hh, synthetic.F_MAX, bb, device=local_rank, contacts=ncs)
+                    mm.set_dispatch_order(mode)
+                    ts2 = []
+                    for _ in range(4):
+                        mm.upload(rec_a)
+                        mm.solve(stream)
+                        torch.cuda.synchronize()
+                        mm.upload(rec_b)
+                        ts2.append(mm.time_solve(1, stream))
+                    _, stq = mm.download()
+                    mm.close()
+                    res2[oname] = {"solves_per_s": bb / (min(ts2) * 1e-3), "kernel_ms": min(ts2)}
+                    res2["failed"] = int((interface.status_code(stq) != 0).sum())
+                    res2["iters_mean"] = float(interface.status_iters(stq).mean())
+                res2["solves_per_s"] = res2["next_tick"]["solves_per_s"]   # (the order an MPC loop runs in)
+                res2["kernel_ms"] = res2["next_tick"]["kernel_ms"]
+                return res2
+
             for name, gait2, hh, bb in (("cfg2_walking_b1024_fixed_phase", "walking", 10, 1024),
                                         ("metric_2contact_b1024", "standing", 10, 1024),
                                         ("cfg3_walking_sweep_b8192_per_gpu", "walking", 10, 8192),
                                         ("cfg4_h20_single_support_b4096", "single", 20, 4096),
                                         ("h20_double_support_240x320_b2048_wide_variant", "standing", 20, 2048)):
                 f2 = synthetic.make_batch(bb, hh, gait2, seed=2, phase=(0 if "fixed" in name else "random"))
-                m2 = interface.BatchedMPC(synthetic.DT_MPC, hh, synthetic.F_MAX, bb, device=local_rank)
-                m2.upload(records.pack_records(f2, hh))
-                m2.solve(stream)
-                torch.cuda.synchronize()
-                ms2 = m2.time_solve(10, stream)
-                _, st2 = m2.download()
-                extra[name] = {"solves_per_s": bb / (ms2 * 1e-3), "kernel_ms": ms2,
-                               "failed": int((interface.status_code(st2) != 0).sum())}
-                m2.set_dispatch_order(False)
-                ms2n = m2.time_solve(10, stream)
-                extra[name]["natural_order"] = {"solves_per_s": bb / (ms2n * 1e-3), "kernel_ms": ms2n}
-                m2.close()
+                extra[name] = three_orders(f2, hh, bb, 2)
             # BASELINE configs[4]: two feet + hand, 180 variables x 240 rows (the three-contact extension)
             for name, bb in (("cfg5_3contact_180x240_b2048_per_gpu", 2048), ("cfg5_3contact_180x240_b8192", 8192)):
-                f3 = synthetic.make_batch3(bb, 10, "standing", seed=5, hand="contact")
-                m3 = interface.BatchedMPC(synthetic.DT_MPC, 10, synthetic.F_MAX, bb, device=local_rank, contacts=3)
-                rec3 = records.pack_records(f3, 10, 3)
-                m3.upload(rec3)
-                m3.solve(stream)
-                torch.cuda.synchronize()
-                ms3 = m3.time_solve(5, stream)
-                _, st3 = m3.download()
-                extra[name] = {"solves_per_s": bb / (ms3 * 1e-3), "kernel_ms": ms3,
-                               "failed": int((interface.status_code(st3) != 0).sum())}
-                m3.set_dispatch_order(False)
-                ms3n = m3.time_solve(5, stream)
-                extra[name]["natural_order"] = {"solves_per_s": bb / (ms3n * 1e-3), "kernel_ms": ms3n}
-                # the hint one tick old instead of exact: solve tick k, time ONE solve of tick k+1
-                m3.set_dispatch_order(True)
-                rec3n = records.pack_records(synthetic.advance_tick(f3, 10, seed=9), 10, 3)
-                t3 = []
-                for _ in range(4):
-                    m3.upload(rec3)
-                    m3.solve(stream)
-                    torch.cuda.synchronize()
-                    m3.upload(rec3n)
-                    t3.append(m3.time_solve(1, stream))
-                extra[name]["next_tick"] = {"solves_per_s": bb / (min(t3) * 1e-3), "kernel_ms": min(t3)}
-                m3.close()
-            extra["dispatch_order_note"] = ("side configs re-solve ONE batch: their dispatch order (longest previous solve first, the "
-                                            "default) comes from the previous solve of the same data; `natural_order` = "
-                                            "hmpc_set_dispatch_order(0), `next_tick` = ordered by the solve of the batch one tick earlier")
+                extra[name] = three_orders(synthetic.make_batch3(bb, 10, "standing", seed=5, hand="contact"), 10, bb, 3)
+            extra["dispatch_order_note"] = ("every side config: solve tick k, then ONE timed solve of the same instances one 5 ms tick later "
+                                            "(best of 4), in three dispatch orders -- `natural` (hmpc_set_dispatch_order 0), `predicted` (2: "
+                                            "cost predicted from the records alone, what a cold handle gets), `next_tick` (1, the default: "
+                                            "ordered by the previous tick's iteration counts); `solves_per_s` = next_tick.  Batches of "
+                                            "single-support QPs only (walking) are never reordered.")
             # rows f1+f2 -> solve -> f3 as ONE device-resident entry (hmpc_tick_solve_device): tick structs in HBM in, joint
             # torques in HBM out, no host call between the launches; every instance routed on the device to the smallest
             # kernel variant that holds it (walking ticks run on the 60-variable kernel without any host hint)

@@ -19,7 +19,9 @@
 //   W  block warm start, in rounds: every moment / line-contact row (rows 4-6 of a leg-step's 8) and one friction row per
 //      axis (rows 0-3) violated at the unconstrained minimiser enter the working set at once.  Their Schur matrix N M N'
 //      is formed block-locally (a row touches one leg-step, so n_i' M n_j needs only the 6x6 block its owner already
-//      holds), inverted in registers, rows of the foot-x moment window whose multiplier comes out negative are switched
+//      holds), inverted -- since round 5 by the same 4 x 4 block pivots on v_mfma_f64_16x16x4_f64 as stage S (schur_invert: 3 x 3
+//      / 4 x 4 / 5 x 5 tiles for the 120-variable / three-contact / wide variants; the 128-thread and the safe variants keep the
+//      register-resident two-pivots-per-barrier sweeps) --, rows of the foot-x moment window whose multiplier comes out negative are switched
 //      to their other bound, other rows with a negative multiplier are removed again -> a valid Goldfarb-Idnani state,
 //      ~20 iterations saved.  While enough further rows are violated at the point reached, another round takes the
 //      working set plus all of them.
@@ -277,6 +279,9 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #if (defined(HMPC_MFS_NO_LDL) || defined(HMPC_MFS_NO_STEPS) || defined(HMPC_MFS_NO_LOAD) || defined(HMPC_MFS_NO_RELAYOUT) || \
      defined(HMPC_MFS_ONLY_WAVE)) && !defined(HMPC_DEV_TIMING)
 #error "HMPC_MFS_NO_* / HMPC_MFS_ONLY_WAVE give wrong results by design: timing builds only, add -DHMPC_DEV_TIMING"
+#endif
+#ifndef HMPC_MFS_RCP_NEWTON
+#define HMPC_MFS_RCP_NEWTON 2  // Newton steps after v_rcp_f64 in the LDL' of a 4 x 4 pivot block (1 measured: see profiles/r05)
 #endif
 #ifndef HMPC_MFS_PST_PAD
 #define HMPC_MFS_PST_PAD 18  // padding of a pivot-panel row in doubles (16: the round-4 layout), see MfsPanel
@@ -602,10 +607,13 @@ __device__ __forceinline__ void mfs_steps(MfsPanel<NTG> &PN, MfsAcc<NTG, NWV> &a
     const double lo = (rr & 1) ? v[1] : v[0], hi = (rr & 1) ? v[3] : v[2];
     return (rr & 2) ? hi : lo;
   };
-  auto rcp1 = [](double d) __attribute__((always_inline)) -> double {  // v_rcp_f64 (2^-24) + two Newton steps: last bit
+  auto rcp1 = [](double d) __attribute__((always_inline)) -> double {  // v_rcp_f64 (2^-24) + Newton steps (two: last bit; one: 2e-15)
     double r = __builtin_amdgcn_rcp(d);
     r = dfma(dfma(-d, r, 1.0), r, r);
-    return dfma(dfma(-d, r, 1.0), r, r);
+#if HMPC_MFS_RCP_NEWTON >= 2
+    r = dfma(dfma(-d, r, 1.0), r, r);
+#endif
+    return r;
   };
   // row g of D^-1 for the pivot block just published
   auto publish_dinv = [&](const int s) __attribute__((always_inline)) {

@@ -28,14 +28,20 @@ python scripts/phase_profile.py walking 10 6144 >> $O/phase_cycles.txt 2>/dev/nu
 python scripts/phase_profile.py single 20 4096 >> $O/phase_cycles.txt 2>/dev/null
 python scripts/phase_profile.py standing 10 2048 3 >> $O/phase_cycles.txt 2>/dev/null
 python scripts/dev/latency_vs_batch.py 2>/dev/null | grep -v amdgpu > $O/latency_vs_batch.txt
+python scripts/dev/lpt_times.py 2>/dev/null | grep -v amdgpu > $O/dispatch_order.txt
 python scripts/soak.py > $O/soak.txt 2>&1
+python scripts/stress.py 2>/dev/null | grep -v amdgpu > $O/stress.txt
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/gpu_tests.txt
 # (1) last: the bench lines read profiles/hbm_traffic.json, which only counts for the build it was taken on -- refresh it
 # from the PMC passes above first (on this box's copy of the tree; the caller runs the summary again on its own copy)
-ROUND=${1:-r04}
+ROUND=${1:-r05}
 python scripts/summarize_rocprof.py $ROUND > /dev/null 2>&1
 python bench.py --steps 20 --warmup 3 > $O/bench_standing.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 3 --gait walking --no-cpu-baseline > $O/bench_walking.json 2>> $O/bench.err
 python bench.py --steps 10 --warmup 2 --horizon 20 --gait single --batch 4096 --no-cpu-baseline > $O/bench_h20_single.json 2>> $O/bench.err
+# the N > 1 path launched by bench.py itself (two ranks on the one GPU over the gloo TEST transport), and the refusal of --gpus 8
+python bench.py --gpus 2 --backend gloo --steps 10 --warmup 3 --check 64 > $O/bench_gpus2_gloo.json 2>> $O/bench.err
+python bench.py --gpus 8 --steps 1 > /dev/null 2> $O/bench_gpus8_refused.txt; echo "exit code $?" >> $O/bench_gpus8_refused.txt
 find $O -name '*.db' -delete
 find $O -name '*_agent_info.csv' -delete
 cat $O/bench_standing.json | cut -c1-600
