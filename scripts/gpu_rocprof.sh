@@ -47,3 +47,10 @@ find $O -name '*_agent_info.csv' -delete
 cat $O/bench_standing.json | cut -c1-600
 head -3 $O/kt/kt_kernel_stats.csv
 ls $O
+# A/B kept for the record: one Newton step instead of two after v_rcp_f64 in the pivot block's LDL' (timing + accuracy at 10x)
+cp hector_simulation_amd/libhector_mpc_hip.so /tmp/keep.so; cp hector_simulation_amd/libhector_mpc_hip.so.srchash /tmp/keep.hash
+( echo "== product build"; python scripts/quick_times.py standing_b8192 h20_single_b4096 3contact_b8192 2>&1 | grep -v amdgpu
+  echo "== -DHMPC_MFS_RCP_NEWTON=1"; HMPC_EXTRA_FLAGS="-DHMPC_MFS_RCP_NEWTON=1" python scripts/quick_times.py standing_b8192 h20_single_b4096 3contact_b8192 2>&1 | grep -v amdgpu
+  HMPC_EXTRA_FLAGS="-DHMPC_MFS_RCP_NEWTON=1" python scripts/dev/stress_120.py 512 2>/dev/null | grep -v amdgpu ) > $O/rcp_newton_ab.txt
+cp /tmp/keep.so hector_simulation_amd/libhector_mpc_hip.so; cp /tmp/keep.hash hector_simulation_amd/libhector_mpc_hip.so.srchash
+ls $O

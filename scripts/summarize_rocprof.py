@@ -82,7 +82,7 @@ def main():
         }, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
     for r in rows:
         print("%-10s %-28s n=%3d mean %.4g" % r)
-    for name in ("phase_cycles.txt", "latency_vs_batch.txt", "soak.txt", "dispatch_order.txt", "stress.txt", "gpu_tests.txt"):
+    for name in ("phase_cycles.txt", "latency_vs_batch.txt", "soak.txt", "dispatch_order.txt", "stress.txt", "gpu_tests.txt", "rcp_newton_ab.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
     extra = []
