@@ -103,3 +103,33 @@ def fit_and_report():
 
 if __name__ == "__main__":
     fit_and_report()
+
+
+def shipped_score(rec, h, nc):
+    """hmpc_builder.h predicted_cost_bucket, restated (the bucket is this score x 48, clamped to 0..63)."""
+    nf = 73 if nc == 3 else 54
+    f = rec[:, : 4 * (nf + 12 * h)].copy().view(np.float32)
+    vx, qw, qx, qy, qz = f[:, 3], f[:, 6], f[:, 7], f[:, 8], f[:, 9]
+    u = (f[:, nf + 9] - vx) + 2.0 * 0.5 * (f[:, 13] + f[:, 14])
+    sr, sp = 2.0 * (qw * qx + qy * qz), 2.0 * (qw * qy - qx * qz)
+    return np.where(u > 0, u, -0.05 * u) + 0.5 * (np.abs(sr) + np.abs(sp))
+
+
+def report_shipped():
+    print("== the shipped predictor: score = hinge((vx_cmd - vx) + 2 mean foot x; slope 1 / 0.05) + 0.5 (|sin roll| + |sin pitch|)")
+    for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pred", "*.npz"))):
+        d = np.load(path)
+        h, nc, it = int(d["h"]), int(d["nc"]), d["iters"].astype(np.float64)
+        score = shipped_score(d["rec"], h, nc)
+        base, c = (400.0, 20.0) if nc == 3 else (200.0, 7.0)
+        cost = base + c * it
+        slots = 512 if nc == 3 else 768
+        nat = lpt_makespan(cost, range(len(it)), slots)
+        best = lpt_makespan(cost, np.argsort(-it, kind="stable"), slots)
+        ms = lpt_makespan(cost, np.argsort(-np.clip((score * 48).astype(int), 0, 63), kind="stable"), slots)
+        print(f"  {os.path.basename(path):28s} corr(score, iterations) {np.corrcoef(score, it)[0, 1]:.2f}   simulated makespan: natural / "
+              f"by true iterations / by the predictor's buckets = 1 / {best / nat:.3f} / {ms / nat:.3f}")
+
+
+if __name__ == "__main__":
+    report_shipped()
