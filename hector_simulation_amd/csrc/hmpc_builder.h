@@ -170,20 +170,27 @@ __device__ __forceinline__ int predicted_cost_bucket(const unsigned char *rec, i
 // Longest-first dispatch (hmpc_set_dispatch_order): the instances of the batch ordered by the active-set iterations their
 // PREVIOUS solve took (status word bits 8-19), most first -- or, when there is no previous solve of this batch (records !=
 // nullptr: a cold handle, a new batch size, the first tick of a device-built pipeline), by predicted_cost_bucket of their
-// records -- a counting sort by one workgroup (64 buckets, iterations >= 63
+// records (keys != nullptr, written by predicted_cost_kernel) -- a counting sort by one workgroup (64 buckets, iterations >= 63
 // share the first).  The solve kernels then take instance order[blockIdx.x]: the hardware starts workgroups in index
 // order, so the long solves start first and the short ones fill the last, partly occupied round of workgroup slots.  The
 // position inside a bucket is decided by atomics and may differ from run to run -- that only changes which slot an
 // instance runs in, never its result.
-__global__ __launch_bounds__(1024) void dispatch_order_kernel(const uint32_t *status, int batch, int *order,
-                                                              const unsigned char *records, int stride, int h, int nc) {
+// keys of the predictor, one thread per instance over the whole chip (a single sorting workgroup reading 8 192 scattered records
+// twice took ~30 us -- 2 % of a b8192 solve; this launch takes ~3 us and the sort then reads one byte per instance)
+__global__ __launch_bounds__(256) void predicted_cost_kernel(const unsigned char *records, int stride, int batch, int h, int nc,
+                                                             unsigned char *keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < batch) keys[i] = (unsigned char)predicted_cost_bucket(records + (size_t)i * stride, h, nc);
+}
+
+__global__ __launch_bounds__(1024) void dispatch_order_kernel(const uint32_t *status, int batch, int *order, const unsigned char *keys) {
   // per-wave counters: a batch whose iteration counts all fall into two or three buckets (walking) would otherwise send every
   // one of its atomics to the same few LDS words (measured: 15 us for 8 192 instances; ~2 us this way)
   __shared__ int cnt[16][64];
   __shared__ int base[64];
   const int tid = threadIdx.x, wv = tid >> 6;
   auto key = [&](const int i) -> int {
-    if (records) return predicted_cost_bucket(records + (size_t)i * stride, h, nc);  // (uniform branch)
+    if (keys) return (int)keys[i];  // (uniform branch) predicted cost buckets, 0..63
     const int it = (int)((status[i] >> 8) & 0xFFFu);
     return it > 63 ? 63 : it;
   };

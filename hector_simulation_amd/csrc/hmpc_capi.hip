@@ -109,6 +109,7 @@ struct hmpc_handle {
   int dispatch_order, order_batch;
   bool order_valid;
   int *d_order;
+  unsigned char *d_keys;  // predicted cost bucket per instance (cold-handle order), allocated on first use
   // size classes of a device-resident batch whose widest reduced QP the host was not told (hmpc_set_max_reduced_vars < 0):
   // stance leg-steps per instance, written on the device by the record builder (cls_valid) or, for records handed in by
   // pointer, by classify_records_kernel at the head of every solve
@@ -311,8 +312,14 @@ static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
   if (h->dispatch_order != 0 && h->d_order && h->batch > DISPATCH_ORDER_MIN_BATCH && h->batch <= DISPATCH_ORDER_MAX_BATCH &&
       !small_qps_only && !h->d_ext_H) {
     const bool from_previous = h->dispatch_order == 1 && h->order_batch == h->batch;
+    if (!from_previous) {
+      if (!h->d_keys) HIP_TRY(hipMalloc(&h->d_keys, (size_t)h->max_batch));
+      hipLaunchKernelGGL(hmpc::predicted_cost_kernel, dim3((h->batch + 255) / 256), dim3(256), 0, stream, h->d_records, (int)h->stride,
+                         h->batch, h->setup.horizon, h->nc, h->d_keys);
+      HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(hmpc::dispatch_order_kernel, dim3(1), dim3(1024), 0, stream, h->d_status, h->batch, h->d_order,
-                       from_previous ? (const unsigned char *)nullptr : h->d_records, (int)h->stride, h->setup.horizon, h->nc);
+                       from_previous ? (const unsigned char *)nullptr : h->d_keys);
     HIP_TRY(hipGetLastError());
     h->order_valid = true;
   }
@@ -458,7 +465,8 @@ int hmpc_create_ex(hmpc_handle **out, const struct problem_setup *setup, int max
     return HMPC_E_HIP;
   }
   h->dispatch_order = 1;
-  if (max_batch > DISPATCH_ORDER_MIN_BATCH && hipMalloc(&h->d_order, (size_t)max_batch * sizeof(int)) != hipSuccess) {
+  if (max_batch > DISPATCH_ORDER_MIN_BATCH && (hipMalloc(&h->d_order, (size_t)max_batch * sizeof(int)) != hipSuccess ||
+                                               hipMalloc(&h->d_keys, (size_t)max_batch) != hipSuccess)) {
     g_hip_err = "hipMalloc failed in hmpc_create";
     hmpc_destroy(h);
     return HMPC_E_HIP;
@@ -482,6 +490,7 @@ int hmpc_destroy(hmpc_handle *h) {
   if (h->d_dbg_i) hipFree(h->d_dbg_i);
   if (h->d_prof) hipFree(h->d_prof);
   if (h->d_wset) hipFree(h->d_wset);
+  if (h->d_keys) hipFree(h->d_keys);
   if (h->d_scratch) hipFree(h->d_scratch);
   if (h->d_flagged) hipFree(h->d_flagged);
   if (h->d_flag_list) hipFree(h->d_flag_list);
@@ -575,6 +584,10 @@ int hmpc_set_dispatch_order(hmpc_handle *h, int mode) {
   if (mode != 0 && !h->d_order && h->max_batch > DISPATCH_ORDER_MIN_BATCH) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMalloc(&h->d_order, (size_t)h->max_batch * sizeof(int)));
+  }
+  if (mode != 0 && !h->d_keys && h->max_batch > DISPATCH_ORDER_MIN_BATCH) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMalloc(&h->d_keys, (size_t)h->max_batch));
   }
   h->dispatch_order = mode;
   h->order_batch = 0;  // the next solve is ordered by the predictor (mode 1, 2) and leaves the iteration counts the one after it sorts by (mode 1)

@@ -253,7 +253,7 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #define HMPC_BLOCK_ROUNDS_3C 3   // ... three-contact variant
 #endif
 #ifndef HMPC_BLOCK_MIN_NEW
-#define HMPC_BLOCK_MIN_NEW 5     // a further round needs at least this many newly violated rows (256-/128-thread variants)
+#define HMPC_BLOCK_MIN_NEW 3     // a further round needs at least this many newly violated rows (256-/128-thread variants; 5 until the Schur matrix went to the matrix cores: profiles/r05/block_round_ab.txt)
 #endif
 #ifndef HMPC_BLOCK_MIN_NEW_3C
 #define HMPC_BLOCK_MIN_NEW_3C 3  // ... three-contact variant (its single-row iteration is dearer)
@@ -288,6 +288,9 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #endif
 #ifndef HMPC_SCHUR_MFMA
 #define HMPC_SCHUR_MFMA 1  // block start of the fast 256-thread two-contact variants: Schur matrix inverted by 4 x 4 block pivots on the matrix cores (0: two scalar pivots per barrier in registers)
+#endif
+#ifndef HMPC_SCHUR_MFMA_128
+#define HMPC_SCHUR_MFMA_128 0   // ... the 128-thread (single-support) variants: measured, see profiles/r05/schur_128_ab.txt
 #endif
 #ifndef HMPC_SCHUR_MFMA_3C
 #define HMPC_SCHUR_MFMA_3C 1    // ... the fast three-contact variant as well (4 x 4 tiles = 64 rows)
@@ -2004,7 +2007,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   constexpr bool LAZY = (BPT == 2);
   // (the fast 256-thread two-contact variants sit exactly on their 168-register budget: their integer roles are recomputed at
   //  every use as well -- one instruction each -- instead of being the allocator's first victims)
-  constexpr bool LAZY_IDX = LAZY || (NT == 256 && BPT == 1 && NC == 2 && QCAP != 0 && QCAP < NMAX);
+  constexpr bool LAZY_IDX = LAZY || (NT == 256 && BPT == 1 && NC == 2 && QCAP != 0 && QCAP < NMAX) || (NT == 128 && HMPC_SCHUR_MFMA_128);
   const auto c_e = lazy_int<LAZY_IDX>([](int t) { return t >> 3; });
   const auto c_rr = lazy_int<LAZY_IDX>([](int t) { return t & 7; });
   // the lower bound of a row is 0 -- except in the last-resort pass (args.relax != 0), where it is recomputed on use
@@ -2241,7 +2244,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     // Schur matrix of the fast variants on the matrix cores (schur_invert): 3 x 3 tiles = 48 rows for the 120-variable variants,
     // 4 x 4 = 64 rows with three contacts, 5 x 5 = 80 rows for the wide variant (eight waves)
     constexpr int NTGS = (NT >= 512) ? 5 : (NC == 3 ? 4 : 3);
-    constexpr bool SCHUR_MFMA = HMPC_SCHUR_MFMA && !LONGRUN && NT >= 256 && SM::QMAX >= 16 * NTGS &&
+    constexpr bool SCHUR_MFMA = HMPC_SCHUR_MFMA && !LONGRUN && (NT >= 256 || HMPC_SCHUR_MFMA_128) && SM::QMAX >= 16 * NTGS &&
                                 (NC == 2 || HMPC_SCHUR_MFMA_3C) && (NT < 512 || HMPC_SCHUR_MFMA_WIDE);
     constexpr int KBMAX = SCHUR_MFMA ? 16 * NTGS
                                      : ((NT >= 512) ? 71 : ((NT >= 256) ? (NC == 3 ? (KBMAX_3C < SM::QMAX ? KBMAX_3C : SM::QMAX) : 45) : 34));  // KBMAX(KBMAX+1)/2 <= EPT*NT
@@ -2355,8 +2358,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         switch (wv) {  // uniform: per-wave specialised code
           case 0: schur_invert<NTGS, NW, 0>(SP, k0, Ep); break;
           case 1: schur_invert<NTGS, NW, 1>(SP, k0, Ep); break;
-          case 2: schur_invert<NTGS, NW, 2>(SP, k0, Ep); break;
-          case 3: schur_invert<NTGS, NW, 3>(SP, k0, Ep); break;
+          case 2: schur_invert<NTGS, NW, (NW > 2 ? 2 : 0)>(SP, k0, Ep); break;  // (cases 2-3: not in the two-wave variants)
+          case 3: schur_invert<NTGS, NW, (NW > 2 ? 3 : 0)>(SP, k0, Ep); break;
           case 4: schur_invert<NTGS, NW, (NW > 4 ? 4 : 0)>(SP, k0, Ep); break;  // (cases 4-7: eight-wave variants only)
           case 5: schur_invert<NTGS, NW, (NW > 4 ? 5 : 0)>(SP, k0, Ep); break;
           case 6: schur_invert<NTGS, NW, (NW > 4 ? 6 : 0)>(SP, k0, Ep); break;

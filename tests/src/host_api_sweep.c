@@ -201,7 +201,52 @@ int main(void) {
   CHECK(hmpc_group_set_exchange_repair(g, 0) == HMPC_OK && hmpc_group_solve(g) == HMPC_OK && hmpc_group_gather_wrench(g, wrench, st) == HMPC_OK);
   CHECK(hmpc_group_set_exchange_repair(g, 1) == HMPC_OK && hmpc_group_set_exchange_repair(NULL, 1) == HMPC_E_ARG);
   CHECK(hmpc_group_upload_records(g, recs, 0) == HMPC_OK && hmpc_group_solve(g) == HMPC_OK && hmpc_group_gather_wrench(g, wrench, st) == HMPC_OK);
+  /* round 5: the striped deal (member i holds instances i, i + 3, ...): same host-facing results, in instance order */
+  {
+    float *wr2 = (float *)calloc(12 * N, sizeof(float));
+    float *fo2 = (float *)calloc((size_t)N * 12 * H, sizeof(float));
+    uint32_t *st3 = (uint32_t *)calloc(N, sizeof(uint32_t));
+    make_records(recs, stride, 0.08);
+    CHECK(hmpc_group_deal(g) == HMPC_DEAL_CONTIGUOUS && hmpc_group_set_deal(g, 7) == HMPC_E_ARG && hmpc_group_set_deal(NULL, 1) == HMPC_E_ARG);
+    CHECK(hmpc_group_upload_records(g, recs, N - 1) == HMPC_OK && hmpc_group_solve(g) == HMPC_OK);
+    CHECK(hmpc_group_gather_wrench(g, wrench, st) == HMPC_OK && hmpc_group_download(g, forces, NULL) == HMPC_OK);
+    CHECK(hmpc_group_member_step(g, 1) == 1);
+    CHECK(hmpc_group_set_deal(g, HMPC_DEAL_STRIPED) == HMPC_OK && hmpc_group_deal(g) == HMPC_DEAL_STRIPED);
+    CHECK(hmpc_group_upload_records(g, recs, N - 1) == HMPC_OK && hmpc_group_solve(g) == HMPC_OK);
+    CHECK(hmpc_group_gather_wrench(g, wr2, st3) == HMPC_OK && hmpc_group_download(g, fo2, NULL) == HMPC_OK);
+    {
+      int lo = -1, nn = -1;
+      CHECK(hmpc_group_member(g, 2, NULL, NULL, &lo, &nn, NULL) == HMPC_OK && lo == 2 && hmpc_group_member_step(g, 2) == 3);
+      CHECK(nn == (N - 1 - 2 + 2) / 3 && hmpc_group_member_step(g, 3) == HMPC_E_ARG);
+    }
+    CHECK(memcmp(wrench, wr2, sizeof(float) * 12 * (N - 1)) == 0 && memcmp(st, st3, sizeof(uint32_t) * (N - 1)) == 0);
+    CHECK(memcmp(forces, fo2, sizeof(float) * (size_t)(N - 1) * 12 * H) == 0);
+    CHECK(hmpc_group_set_deal(g, HMPC_DEAL_CONTIGUOUS) == HMPC_OK);
+    free(wr2), free(fo2), free(st3);
+  }
   CHECK(hmpc_group_synchronize(g) == HMPC_OK && hmpc_group_destroy(g) == HMPC_OK);
+
+  /* round 5: strided upload (every second record of a host array), the dispatch-order modes, the legacy iteration cap */
+  {
+    hmpc_handle *h5 = NULL;
+    CHECK(hmpc_create(&h5, &ps, N, 0) == HMPC_OK);
+    unsigned char *wide = (unsigned char *)calloc((size_t)2 * N, stride);
+    make_records(recs, stride, 0.05);
+    for (int k = 0; k < N; ++k) memcpy(wide + (size_t)2 * k * stride, recs + (size_t)k * stride, stride);
+    float *fa = (float *)calloc((size_t)N * 12 * H, sizeof(float)), *fb = (float *)calloc((size_t)N * 12 * H, sizeof(float));
+    uint32_t *sa = (uint32_t *)calloc(N, sizeof(uint32_t)), *sb = (uint32_t *)calloc(N, sizeof(uint32_t));
+    CHECK(hmpc_upload_records(h5, recs, N) == HMPC_OK && hmpc_solve(h5, NULL) == HMPC_OK && hmpc_download(h5, fa, sa) == HMPC_OK);
+    CHECK(hmpc_upload_records_strided_async(h5, wide, N, stride / 2, NULL) == HMPC_E_ARG); /* pitch below one record */
+    CHECK(hmpc_upload_records_strided_async(h5, wide, N, 2 * stride, NULL) == HMPC_OK);
+    for (int mode = 0; mode <= 2; ++mode) {
+      CHECK(hmpc_set_dispatch_order(h5, mode) == HMPC_OK && hmpc_solve(h5, NULL) == HMPC_OK && hmpc_download(h5, fb, sb) == HMPC_OK);
+      CHECK(memcmp(fa, fb, sizeof(float) * (size_t)N * 12 * H) == 0 && memcmp(sa, sb, sizeof(uint32_t) * N) == 0);
+    }
+    CHECK(hmpc_set_dispatch_order(h5, 3) == HMPC_E_ARG && hmpc_set_dispatch_order(h5, 1) == HMPC_OK);
+    CHECK(hmpc_destroy(h5) == HMPC_OK);
+    free(wide), free(fa), free(fb), free(sa), free(sb);
+    CHECK(hmpc_legacy_set_max_iterations(-1) == HMPC_E_ARG && hmpc_legacy_set_max_iterations(0) == HMPC_OK);
+  }
 
   /* round 4: double support over h = 20 far outside the nominal ranges -- instances that outgrow the wide variant's working set
    * go through the safe pass whose packed Schur inverse lives in global memory (scratch grown on demand inside hmpc_download) */
