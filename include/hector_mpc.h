@@ -347,7 +347,9 @@ int hmpc_group_batch(const hmpc_group *g);
 int hmpc_group_member(hmpc_group *g, int member, hmpc_handle **handle, int *device, int *lo, int *n, void **solve_stream);
 int hmpc_group_upload_records(hmpc_group *g, const void *host_records, int batch);
 /* How the next batch is dealt to the members (enum hmpc_group_deal).  Host-facing results (hmpc_group_gather_wrench,
- * hmpc_group_download) are in instance order either way; member sizes are the same either way; in striped mode row r of slot s
+ * hmpc_group_download) are in instance order either way (and the same bits, as long as every member's handle picks the same
+ * kernel variant under both deals -- a member that is dealt single-support instances only runs the 60-variable variant, whose
+ * answers agree with the 120-variable one's to solver precision); member sizes are the same either way; in striped mode row r of slot s
  * of the device-resident gathered block is instance s + r G, and hmpc_group_member_step returns G (1 for contiguous slices). */
 int hmpc_group_set_deal(hmpc_group *g, int deal);
 int hmpc_group_deal(const hmpc_group *g);

@@ -219,8 +219,17 @@ int main(void) {
       CHECK(hmpc_group_member(g, 2, NULL, NULL, &lo, &nn, NULL) == HMPC_OK && lo == 2 && hmpc_group_member_step(g, 2) == 3);
       CHECK(nn == (N - 1 - 2 + 2) / 3 && hmpc_group_member_step(g, 3) == HMPC_E_ARG);
     }
-    CHECK(memcmp(wrench, wr2, sizeof(float) * 12 * (N - 1)) == 0 && memcmp(st, st3, sizeof(uint32_t) * (N - 1)) == 0);
-    CHECK(memcmp(forces, fo2, sizeof(float) * (size_t)(N - 1) * 12 * H) == 0);
+    /* the same optimum for every instance: to solver precision, not bit for bit -- this batch alternates double-support and
+     * walking instances with period 3, so the striped deal hands members 1 and 2 walking instances only and their handles
+     * pick the 60-variable kernel variant where the contiguous slices (both kinds in every slice) ran the 120-variable one */
+    for (int k = 0; k < N - 1; ++k) {
+      CHECK(HMPC_STATUS_CODE(st[k]) == HMPC_S_OK && HMPC_STATUS_CODE(st3[k]) == HMPC_S_OK);
+      for (int c = 0; c < 12 * H; ++c) {
+        const double a = forces[(size_t)k * 12 * H + c], b = fo2[(size_t)k * 12 * H + c];
+        CHECK(fabs(a - b) <= 1e-5 * fmax(1.0, fabs(a)));
+      }
+      CHECK(memcmp(wr2 + 12 * k, fo2 + (size_t)12 * H * k, 48) == 0); /* the gathered wrench IS step 0 of the member's forces */
+    }
     CHECK(hmpc_group_set_deal(g, HMPC_DEAL_CONTIGUOUS) == HMPC_OK);
     free(wr2), free(fo2), free(st3);
   }
