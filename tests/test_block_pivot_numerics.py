@@ -129,3 +129,46 @@ def test_block_pivot_sweeps_give_the_inverse(oracle, gait, scale):
     if scale == 10 and gait == "standing":
         # what decided for LDL': at 10x the nominal ranges the closed-form pivot inverse is off by 2e-4 on one of these
         assert worst["partitioned"] > 1e3 * worst["ldl"], worst
+
+
+@pytest.mark.parametrize("gait,scale", [("standing", 1), ("standing", 6)])
+def test_block_pivot_steps_invert_the_schur_matrix_of_the_block_start(oracle, gait, scale):
+    """Round 5: the Schur matrix S0 = N_W M N_W' of the block start goes through the same steps (hmpc_kernel.h schur_invert).
+    Restated on the oracle's QP data: W = the rows 4-6 and one friction row per axis violated at the unconstrained minimiser
+    (the block start's first round), S0 from M = H^-1 (moment rows ~ 1 / alpha_M ~ 50 on its diagonal, friction rows ~ (1 + mu^2) M_FF:
+    equilibrated like H by powers of two) and E = S0^-1 from the block-pivot steps against numpy's inverse; the multipliers u = E (b - N x_u) it yields agree to 1e-9.
+    Identity padding up to a multiple of four rows, as in the kernel's tiles."""
+    rec = records.pack_records(hard_batch(4, 10, gait, 17, scale), 10)
+    seen = 0
+    for kk in range(4):
+        o = oracle.assemble_record(rec[kk], 10, synthetic.DT_MPC, synthetic.F_MAX)
+        H, g, A = (np.asarray(o[k], dtype=np.float64) for k in ("H_red", "g_red", "A_red"))
+        lb, ub = np.asarray(o["lb_red"], dtype=np.float64), np.asarray(o["ub_red"], dtype=np.float64)
+        M = np.linalg.inv(H)
+        xu = -M @ g
+        ax = A @ xu
+        rows, sides = [], []
+        for c in range(A.shape[0]):
+            rr = c % 8
+            lo_v, up_v = ax[c] < lb[c] - 1e-9, ax[c] > ub[c] + 1e-9
+            if rr <= 6 and (lo_v or up_v):
+                if rr < 4 and (c ^ 1) in rows:   # one friction row per axis
+                    continue
+                rows.append(c)
+                sides.append(1.0 if lo_v else -1.0)
+        if len(rows) < 4:
+            continue
+        rows, sides = rows[:48], np.array(sides[:48])   # the fast variants' block-start capacity (3 x 3 tiles)
+        N = sides[:, None] * A[rows]
+        S0 = N @ M @ N.T
+        if np.linalg.cond(S0) > 1e12:   # (a dependent pair: the kernel's pivot test rejects such a set; not this test's subject)
+            continue
+        seen += 1
+        assert np.diag(S0).min() > 0
+        E = block_pivot_inverse(S0)
+        Eref = np.linalg.inv(S0)
+        assert np.abs(E - Eref).max() <= 1e-8 * np.abs(Eref).max(), (np.abs(E - Eref).max() / np.abs(Eref).max(), np.linalg.cond(S0))
+        b = np.where(sides > 0, lb[rows], -ub[rows])
+        d = b - N @ xu
+        assert np.abs(E @ d - Eref @ d).max() <= 1e-9 * max(1.0, np.abs(Eref @ d).max())
+    assert seen >= 2
