@@ -256,7 +256,7 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #define HMPC_BLOCK_MIN_NEW 3     // a further round needs at least this many newly violated rows (256-/128-thread variants; 5 until the Schur matrix went to the matrix cores: profiles/r05/block_round_ab.txt)
 #endif
 #ifndef HMPC_BLOCK_MIN_NEW_3C
-#define HMPC_BLOCK_MIN_NEW_3C 3  // ... three-contact variant (its single-row iteration is dearer)
+#define HMPC_BLOCK_MIN_NEW_3C 2  // ... three-contact variant (its single-row iteration is dearer; 3 until round 5)
 #endif
 #ifndef HMPC_CHAIN_BALANCE
 #define HMPC_CHAIN_BALANCE 1     // H chains of the 120-variable h <= 10 variant: block-diagonals dealt to the waves by length
@@ -279,6 +279,12 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #if (defined(HMPC_MFS_NO_LDL) || defined(HMPC_MFS_NO_STEPS) || defined(HMPC_MFS_NO_LOAD) || defined(HMPC_MFS_NO_RELAYOUT) || \
      defined(HMPC_MFS_ONLY_WAVE)) && !defined(HMPC_DEV_TIMING)
 #error "HMPC_MFS_NO_* / HMPC_MFS_ONLY_WAVE give wrong results by design: timing builds only, add -DHMPC_DEV_TIMING"
+#endif
+#ifndef HMPC_REFINE_FROM_X
+#define HMPC_REFINE_FROM_X 1  // final refinement: residual at the loop's own iterate instead of a recomputed x(u) (fast variants; +0.8 ... 1.3 %, same soak: profiles/r05/block_round_ab.txt)
+#endif
+#ifndef HMPC_MFS_DEAL_PAIRED
+#define HMPC_MFS_DEAL_PAIRED 1  // 120-variable matrix-core sweeps: tile rows dealt to the waves in pairs (I, 7 - I) instead of contiguous runs (+1.0 ... 1.3 %, profiles/r05/block_round_ab.txt)
 #endif
 #ifndef HMPC_MFS_RCP_NEWTON
 #define HMPC_MFS_RCP_NEWTON 2  // Newton steps after v_rcp_f64 in the LDL' of a 4 x 4 pivot block (1 measured: see profiles/r05)
@@ -396,6 +402,11 @@ constexpr int mfs_owner(int ntg, int nwv, int I, int J) {
       default: return 3;
     }
   }
+#if HMPC_MFS_DEAL_PAIRED
+  // 8 x 8 grid on four waves (120 variables): tile rows dealt in pairs I, 7 - I (8 + 1, 7 + 2, 6 + 3, 5 + 4 tiles): every wave
+  // touches exactly two tile rows (two A operands per step instead of up to four) and owns two diagonal tiles
+  if (ntg == 8 && nwv == 4) return I < 4 ? I : 7 - I;
+#endif
   const int ntiles = ntg * (ntg + 1) / 2, base = ntiles / nwv, rem = ntiles % nwv;
   int t = 0;  // index of (I, J) in block-row-major order
   for (int i = 0; i < I; ++i) t += ntg - i;
@@ -859,7 +870,7 @@ __device__ __forceinline__ void mfma_sweeps(MfsPanel<NTG> &PN, double *stage, co
 // S0 = N_W M N_W' (k0 <= 16 NTG rows, packed lower triangle in LDS) is inverted by the 4 x 4 block-pivot steps above instead of
 // two scalar pivots per barrier on a packed triangle spread over the threads' registers: (k0 + 3) / 4 barrier-separated steps
 // instead of k0 / 2, and the update is one matrix instruction per 16 x 16 tile instead of ~12 binary64 instructions per entry
-// and thread.  Same power-of-two equilibration as stage S (the diagonal of S0 spans 1/H_ii: six orders of magnitude).
+// and thread.  Same power-of-two equilibration as stage S (the diagonal of S0: ~50 for a moment / line-contact row, ~1e4 for a friction row).
 template <int NTG>
 struct SchurPanel {
   MfsPanel<NTG> pn;
@@ -2817,11 +2828,16 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
 
     // ---- refinement of the multipliers on the final working set: u += E (b_W - N_W x(u)), x(u) = x_u + M N_W' u ----
     for (int it = 0; it <= HMPC_REFINE; ++it) {
+      // (HMPC_REFINE_FROM_X: the first correction takes its residual at the iterate the loop above left -- x was moved along with u
+      //  step by step, and what the correction is there to remove is the drift of E's rank-one updates, orders of magnitude above
+      //  the difference between that x and x(u) -- instead of recomputing x(u) first: one gather + one product with M less)
+      if (!(HMPC_REFINE_FROM_X && !LONGRUN && it == 0 && HMPC_REFINE > 0)) {
       gather_w(Q.u, 1.0, 0.0);
       __syncthreads();
       rmatvec(Q.w);
       if (is_v) Q.x[tid] = Q.xu[tid] + Q.z[tid];
       __syncthreads();
+      }
       if (it == HMPC_REFINE) break;
       active_residual(Q.x);
       __syncthreads();
