@@ -2,7 +2,9 @@
  * devices 0..G-1), contiguous slices per device, the solved step-0 wrenches gathered on every device and on the host.
  *   gcc -std=c11 -Iinclude examples/batched_multi.c -Lhector_simulation_amd -lhector_mpc_hip \
  *       -Wl,-rpath,$PWD/hector_simulation_amd -o batched_multi
- *   ./batched_multi [n_devices [p2p|auto [contacts]]]   (default: as many as hmpc_group_create accepts, probing 8,4,2,1)
+ *   ./batched_multi [n_devices [p2p|auto [contacts [striped]]]]   (default: as many as hmpc_group_create accepts, probing 8,4,2,1)
+ * "striped": the batch -- a sweep ordered by commanded velocity -- is dealt round-robin (hmpc_group_set_deal: member i holds
+ * instances i, i + G, ...) instead of cut into contiguous slices, so that every GPU gets the same mix of easy and hard instances.
  * "p2p" with n_devices > visible devices lists device 0 repeatedly (how a one-GPU box exercises the multi-member path).
  * contacts = 3: the loco-manipulation extension (BASELINE config 5 runs it on 4 GPUs) -- hmpc_group_create_ex, records of
  * hmpc_pack_record_ex, and an exchange of 18 step-0 values [F_L F_R F_H M_L M_R M_H] + status per instance. */
@@ -18,6 +20,7 @@ int main(int argc, char **argv) {
   const int want = argc > 1 ? atoi(argv[1]) : 0;
   const int p2p = argc > 2 && !strcmp(argv[2], "p2p");
   const int nc = (argc > 3 && atoi(argv[3]) == 3) ? 3 : 2, W = 6 * nc; /* contacts; step-0 wrench width */
+  const int striped = argc > 4 && !strcmp(argv[4], "striped");
   hmpc_group *g = NULL;
   int rc = HMPC_E_ARG, G = 0;
   if (p2p) {
@@ -63,7 +66,8 @@ int main(int argc, char **argv) {
   float *wrench = (float *)malloc(sizeof(float) * N * W);
   float *forces = (float *)malloc(sizeof(float) * N * W * H);
   uint32_t *st = (uint32_t *)malloc(sizeof(uint32_t) * N), *st2 = (uint32_t *)malloc(sizeof(uint32_t) * N);
-  rc = hmpc_group_upload_records(g, recs, N);
+  rc = hmpc_group_set_deal(g, striped ? HMPC_DEAL_STRIPED : HMPC_DEAL_CONTIGUOUS);
+  if (rc == HMPC_OK) rc = hmpc_group_upload_records(g, recs, N);
   if (rc == HMPC_OK) rc = hmpc_group_solve(g);
   if (rc == HMPC_OK) rc = hmpc_group_gather_wrench(g, wrench, st); /* the exchange step */
   if (rc == HMPC_OK) rc = hmpc_group_download(g, forces, st2);     /* everything, for the cross-check below */
@@ -75,7 +79,9 @@ int main(int argc, char **argv) {
   for (int i = 0; i < G; ++i) {
     int dev, lo, n;
     hmpc_group_member(g, i, NULL, &dev, &lo, &n, NULL);
-    printf("member %d: device %d, instances [%d, %d)\n", i, dev, lo, lo + n);
+    const int step = hmpc_group_member_step(g, i);
+    if (step == 1) printf("member %d: device %d, instances [%d, %d)\n", i, dev, lo, lo + n);
+    else printf("member %d: device %d, %d instances %d, %d, %d, ...\n", i, dev, n, lo, lo + step, lo + 2 * step);
   }
   printf("rc %d, group of %d (%s), %d contacts, %d of %d not ok, %d gathered rows differ from the full download; instance 0: Fz_L %.3f Fz_R %.3f\n",
          rc, G, hmpc_group_transport(g) == HMPC_GROUP_RCCL ? "rccl" : "p2p", hmpc_group_contacts(g), bad, N, mismatch, wrench[2], wrench[5]);

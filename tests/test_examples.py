@@ -50,7 +50,7 @@ def test_examples_run_on_gpu(tmp_path, src, cc, std):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("args", [["1"], ["3", "p2p"], ["4", "p2p", "3"], ["1", "auto", "3"]])
+@pytest.mark.parametrize("args", [["1"], ["3", "p2p"], ["4", "p2p", "3"], ["1", "auto", "3"], ["3", "p2p", "2", "striped"]])
 def test_multi_device_example_runs_on_gpu(tmp_path, args):
     """examples/batched_multi.c: a group of one over RCCL (what a one-GPU box can run of the real transport) and a group of
     three members on device 0 over the P2P transport (ragged 334/333/333 slices); with "3": groups of three-contact handles
@@ -60,6 +60,8 @@ def test_multi_device_example_runs_on_gpu(tmp_path, args):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 of 1000 not ok, 0 gathered rows differ" in r.stdout
     assert f"{args[2] if len(args) > 2 else 2} contacts" in r.stdout
+    if "striped" in args:
+        assert "334 instances 0, 3, 6, ..." in r.stdout and "333 instances 2, 5, 8, ..." in r.stdout
 
 
 def test_host_api_sweep_compiles_and_fails_loudly_without_gpu(tmp_path):
