@@ -280,6 +280,9 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
      defined(HMPC_MFS_ONLY_WAVE)) && !defined(HMPC_DEV_TIMING)
 #error "HMPC_MFS_NO_* / HMPC_MFS_ONLY_WAVE give wrong results by design: timing builds only, add -DHMPC_DEV_TIMING"
 #endif
+#ifndef HMPC_S0_ACTIVE_ROWS
+#define HMPC_S0_ACTIVE_ROWS 1  // block start, S0 = N M N': every lane iterates over its own active rows (0: all lanes count through rows rlo .. rhi)
+#endif
 #ifndef HMPC_REFINE_FROM_X
 #define HMPC_REFINE_FROM_X 1  // final refinement: residual at the loop's own iterate instead of a recomputed x(u) (fast variants; +0.8 ... 1.3 %, same soak: profiles/r05/block_round_ab.txt)
 #endif
@@ -2333,6 +2336,38 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         const unsigned long long am1 = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * E1(s)]);
         if (am0 != 0ull && am1 != 0ull) {
           const int leg0 = S.ls_leg[E0(s)], leg1 = S.ls_leg[E1(s)];
+#if HMPC_S0_ACTIVE_ROWS
+          // Every lane walks over ITS OWN active rows (bit scan of the 8 activity bytes of a leg-step).  Counting r1 and r0 through
+          // rlo .. rhi instead made each wave execute the union of its lanes' rows -- nearly all 7 x 7 combinations, a 36-FMA block
+          // product each, for the 1-2 rows a leg-step really has (blk:S0 14 k cycles per workgroup).  Same arithmetic per entry.
+          auto rowmask = [&](const unsigned long long am) __attribute__((always_inline)) -> unsigned {
+            const unsigned long long t = am & 0x0101010101010101ull;  // (+1 and -1 both have bit 0 set)
+            const unsigned m8 = (unsigned)((t * 0x0102040810204080ull) >> 56);  // bit r = byte r of am is non-zero (no carries: the partial products land on distinct bits)
+            return m8 & ((2u << rhi) - 1u) & ~((1u << rlo) - 1u);
+          };
+          const unsigned m0all = rowmask(am0);
+          unsigned m1 = rowmask(am1);
+          while (m1 != 0u) {
+            const int r1 = __ffs((int)m1) - 1;
+            m1 &= m1 - 1u;
+            const int ac1 = (int)(signed char)((am1 >> (8 * r1)) & 0xff);
+            double cn1[GS], t6[GS];
+#pragma unroll
+            for (int k = 0; k < GS; ++k) cn1[k] = (double)ac1 * S.Cn[leg1][r1][k];
+            blk_rows(s, cn1, t6);  // (a diagonal block is stored as the full symmetric 6x6)
+            const int s1 = Q.slot[8 * E1(s) + r1];
+            unsigned m0 = DIAG(s) ? (m0all & ((2u << r1) - 1u)) : m0all;  // (diagonal block: r0 <= r1)
+            while (m0 != 0u) {
+              const int r0 = __ffs((int)m0) - 1;
+              m0 &= m0 - 1u;
+              const int ac0 = (int)(signed char)((am0 >> (8 * r0)) & 0xff);
+              double v = 0.0;
+#pragma unroll
+              for (int k = 0; k < GS; ++k) v = dfma((double)ac0 * S.Cn[leg0][r0][k], t6[k], v);
+              Eat(Q.slot[8 * E0(s) + r0], s1) = v;
+            }
+          }
+#else
           for (int r1 = rlo; r1 <= rhi; ++r1) {
             const int ac1 = (int)(signed char)((am1 >> (8 * r1)) & 0xff);
             if (ac1 == 0) continue;
@@ -2350,6 +2385,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
               Eat(Q.slot[8 * E0(s) + r0], s1) = v;
             }
           }
+#endif
         }
       }
       __syncthreads();
