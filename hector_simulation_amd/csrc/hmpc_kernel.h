@@ -280,6 +280,9 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
      defined(HMPC_MFS_ONLY_WAVE)) && !defined(HMPC_DEV_TIMING)
 #error "HMPC_MFS_NO_* / HMPC_MFS_ONLY_WAVE give wrong results by design: timing builds only, add -DHMPC_DEV_TIMING"
 #endif
+#ifndef HMPC_MFS_PUBLISH_FIRST
+#define HMPC_MFS_PUBLISH_FIRST 1  // matrix-core steps: the pivot block's owner issues all its panel stores before it waits for the raw block
+#endif
 #ifndef HMPC_S0_ACTIVE_ROWS
 #define HMPC_S0_ACTIVE_ROWS 1  // block start, S0 = N M N': every lane iterates over its own active rows (0: all lanes count through rows rlo .. rhi)
 #endif
@@ -681,12 +684,14 @@ __device__ __forceinline__ void mfs_steps(MfsPanel<NTG> &PN, MfsAcc<NTG, NWV> &a
             v -= (c == c0 + g) ? 1.0 : 0.0;
           }
           P[g][16 * T.j[t] + c] = v;
+#if !HMPC_MFS_PUBLISH_FIRST
           if (T.j[t] == IK) {  // this wave owns the pivot block: its own LDS writes are visible to it after a wait
             __builtin_amdgcn_s_waitcnt(0xc07f);
 #ifndef HMPC_MFS_NO_LDL  // developer switch (register pressure)
             publish_dinv(s);
 #endif
           }
+#endif
         } else if (T.j[t] == IK) {
           if (c >= c0 && c < c0 + 4) {
 #pragma unroll
@@ -694,6 +699,21 @@ __device__ __forceinline__ void mfs_steps(MfsPanel<NTG> &PN, MfsAcc<NTG, NWV> &a
           }
         }
       }
+#if HMPC_MFS_PUBLISH_FIRST
+      // the wave that owns the pivot block inverts it AFTER all of its panel stores are issued: their issue overlaps the LDS
+      // round trip of the raw block (with the paired deal the owner publishes its whole tile row)
+      {
+        bool owner = false;  // compile time
+#pragma unroll
+        for (int t = 0; t < CNT; ++t) owner = owner || (T.i[t] == IK && T.j[t] == IK);
+        if (owner) {
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // this wave's own LDS writes are visible to it after a wait
+#ifndef HMPC_MFS_NO_LDL  // developer switch (register pressure)
+          publish_dinv(s);
+#endif
+        }
+      }
+#endif
     }
   };
   auto publish = [&](const int s) __attribute__((always_inline)) {
@@ -897,17 +917,25 @@ __device__ __forceinline__ void schur_load(MfsAcc<NTG, NWV> &acc, const int k0, 
   constexpr MfsTiles<NTG, NWV, WV> T;
   constexpr int CNT = mfs_count(NTG, NWV, WV);
   const int ln = threadIdx.x & 63, g = ln >> 4, c = ln & 15;
+  // the scaling exponents straight from the diagonal of S0 (what schur_scale_exponents leaves in kexp for the store at the end):
+  // no barrier between that pass and this one
+  auto kof = [&](const int i) __attribute__((always_inline)) -> int {
+    if (i >= k0) return 0;
+    const int ex = ((__double2hiint(Ep[(unsigned)(i * (i + 1) / 2 + i)]) >> 20) & 2047) - 1023;
+    return -(ex >> 1);
+  };
+  (void)kexp;
 #pragma unroll
   for (int t = 0; t < CNT; ++t) {
     const int j = 16 * T.j[t] + c;
-    const int kj = (int)kexp[j];
+    const int kj = kof(j);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 16 * T.i[t] + g + 4 * r;
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       const bool valid = hi < k0;
       const double v = Ep[(unsigned)(valid ? hi * (hi + 1) / 2 + lo : 0)];
-      acc[t][r] = valid ? v * __hiloint2double((1023 + (int)kexp[i] + kj) << 20, 0) : ((i == j) ? 1.0 : 0.0);  // identity padding
+      acc[t][r] = valid ? v * __hiloint2double((1023 + kof(i) + kj) << 20, 0) : ((i == j) ? 1.0 : 0.0);  // identity padding
     }
   }
 }
@@ -2283,7 +2311,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       }
       count_candidates();
       if (ub((!refresh && k0 - q < BLOCK_MIN_NEW) || k0 > (LONGRUN ? SM::QMAX : KBMAX))) return false;  // not worth a round / does not fit: the iteration below goes on
-      __syncthreads();  // wcount is free again
+      // (no barrier here: what follows writes act / slot / Wrow entries that nobody reads before the barrier behind the slot deal,
+      //  and wcount is not written again before the release loop, several barriers on)
       ++iters;
       tick = true;  // rows 0..7 may be in the set from here on
     } else
@@ -2388,6 +2417,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
 #endif
         }
       }
+      if constexpr (SCHUR_MFMA) {  // (cleared before the barrier that ends the formation of S0: the mat-vec staging is free here)
+        if (tid == 0) reinterpret_cast<SchurPanel<NTGS> *>(&Q.ST[0][0])->pn.bad = 0;
+      }
       __syncthreads();
       PROF_MARK(P_B_S0);
       // (c) inversion of the k0 x k0 Schur matrix by symmetric sweeps with the packed triangle spread over the threads'
@@ -2399,9 +2431,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         // pivot panels in the mat-vec staging (free here), E written back over S0 in the packed triangle
         static_assert(sizeof(SchurPanel<NTGS>) <= sizeof(Q.ST), "the Schur panels live in the mat-vec staging");
         SchurPanel<NTGS> &SP = *reinterpret_cast<SchurPanel<NTGS> *>(&Q.ST[0][0]);
-        schur_scale_exponents<NTGS>(k0, Ep, SP.kexp);
-        if (tid == 0) SP.pn.bad = 0;
-        __syncthreads();
+        schur_scale_exponents<NTGS>(k0, Ep, SP.kexp);  // (read again at the store, many barriers later; the tile loader takes its own from the diagonal)
         switch (wv) {  // uniform: per-wave specialised code
           case 0: schur_invert<NTGS, NW, 0>(SP, k0, Ep); break;
           case 1: schur_invert<NTGS, NW, 1>(SP, k0, Ep); break;
@@ -2913,20 +2943,20 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     double umin = (tid < q) ? Q.u[tid] : INF;
     val = wave_min(val);
     umin = wave_min(umin);
-    if (ln == 0) Q.redv[wv] = val, Q.redw[wv] = umin;
+    const double xm = wave_min(is_v ? -__builtin_fabs(Q.x[tid]) : 0.0);
+    if (ln == 0) Q.redv[wv] = val, Q.redw[wv] = umin, Q.rec[wv].raw = xm;  // (the three reductions share one barrier; the selection
+                                                                        //  records are free here -- and not a byte of LDS is added:
+                                                                        //  the 128-thread variants fit six workgroups per CU by 300 B)
     __syncthreads();
+    double xmax = 1.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       val = (Q.redv[w] < val) ? Q.redv[w] : val;
       umin = (Q.redw[w] < umin) ? Q.redw[w] : umin;
+      xmax = (-Q.rec[w].raw > xmax) ? -Q.rec[w].raw : xmax;
     }
-    __syncthreads();
-    const double xm = wave_min(is_v ? -__builtin_fabs(Q.x[tid]) : 0.0);
-    if (ln == 0) Q.redw[wv] = xm;
-    __syncthreads();
-    double xmax = 1.0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) xmax = (-Q.redw[w] > xmax) ? -Q.redw[w] : xmax;
+    // (no barrier behind the reads: the only other writer of the three arrays -- a second call in the last-resort pass -- comes
+    //  after the barriers of that pass)
     constexpr double KKT_TOL = LONGRUN ? 2e-5 : 2e-6;
     return !(val < -KKT_TOL * xmax || umin < -1e-6 * xmax);  // relative to the force scale
   };
