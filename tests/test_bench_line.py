@@ -176,3 +176,39 @@ def test_bench_more_gpus_than_visible_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, cwd=ROOT, env=env2)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_self_launch_builds_the_torchrun_command(monkeypatch):
+    """bench.py --gpus N without WORLD_SIZE: the re-exec goes through torch.distributed.run with N ranks on 127.0.0.1, passes the
+    caller's own arguments on, marks the children (HMPC_BENCH_SELF_LAUNCHED) and refuses when fewer devices are visible -- checked
+    here without a GPU by standing in for the device count and the process launch."""
+    import argparse
+    import importlib.util
+
+    import torch
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    argv = ["--gpus", "4", "--contacts", "3", "--batch", "2048", "--steps", "5"]
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    rc = bench.self_launch(argparse.Namespace(gpus=4, backend="nccl"), argv)
+    assert rc == 7  # the ranks' exit code is passed on
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-len(argv):] == argv and os.path.basename(cmd[-len(argv) - 1]) == "bench.py"
+    assert seen["env"]["HMPC_BENCH_SELF_LAUNCHED"] == "1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # fewer devices than ranks: refused (exit code 2, nothing launched) -- unless the ranks may share devices (gloo test transport)
+    seen.clear()
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert bench.self_launch(argparse.Namespace(gpus=4, backend="nccl"), argv) == 2 and not seen
+    assert bench.self_launch(argparse.Namespace(gpus=4, backend="gloo"), argv) == 7 and seen
