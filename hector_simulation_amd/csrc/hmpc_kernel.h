@@ -33,6 +33,9 @@
 
 #include <type_traits>
 
+#ifndef HMPC_MFMA_SWEEP_WIDE
+#define HMPC_MFMA_SWEEP_WIDE 1  // stage S on the matrix cores for the fast wide variant (240 variables, 512 threads, two blocks per thread): 15 x 15 tiles on eight waves
+#endif
 #ifndef HMPC_REFINE
 #define HMPC_REFINE 1  // corrections u += E (b_W - N_W x(u)) applied to the multipliers of the final working set
 #endif
@@ -108,7 +111,8 @@ struct Smem {
   // floating point in both directions (H_ii spans 2e-4 .. 500; the 4 x 4 pivot blocks of the scaled matrix are far better
   // conditioned than the raw ones, which is what the explicitly inverted pivot block needs)
   static constexpr bool MFS2 = (NMAX == 120 && NT == 256 && BPT == 1 && NC == 2);  // shapes whose fast variants sweep on the matrix cores
-  static constexpr bool MFS3 = (NMAX == 180 && NT == 256 && BPT == 2 && NC == 3);
+  static constexpr bool MFS3 = (NMAX == 180 && NT == 256 && BPT == 2 && NC == 3) ||
+                               (HMPC_MFMA_SWEEP_WIDE && NMAX == 240 && NT == 512 && BPT == 2 && NC == 2 && QCAP != 0);  // (round 5: the wide variant)
   signed char kexp[(MFS2 || MFS3) ? 16 * ((NMAX + 15) / 16) : 1];
   unsigned char rmap[U * HMAX];            // original variable U*step+comp -> sweep index (255 = eliminated)
   unsigned char ls_leg[NG], ls_step[NG];
@@ -1803,12 +1807,12 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     __syncthreads();
     switch (wv) {  // uniform: per-wave specialised code
 #define HMPC_MFS3_WAVE(W)                                                                  \
-  MfsAcc<MFS3_NTG, 4> acc;                                                                 \
-  mfs_load_parked<MFS3_NTG, 4, W, NMAX>(acc, n, hb, S.kexp);                               \
+  MfsAcc<MFS3_NTG, NW> acc;                                                                \
+  mfs_load_parked<MFS3_NTG, NW, W, NMAX>(acc, n, hb, S.kexp);                              \
   __syncthreads(); /* every tile is loaded before the panel (which aliases the parked blocks) is written */ \
-  mfs_steps<MFS3_NTG, 4, W>(PN, acc, n);                                                   \
+  mfs_steps<MFS3_NTG, NW, W>(PN, acc, n);                                                  \
   double aw[BPT][GS][GS];                                                                  \
-  mfs_relayout<MFS3_NTG, 4, W, NMAX, BPT, NT>(stage, acc, n, S.kexp, e0a, e1a, lva, aw);   \
+  mfs_relayout<MFS3_NTG, NW, W, NMAX, BPT, NT>(stage, acc, n, S.kexp, e0a, e1a, lva, aw);  \
   mfs_move_blocks<BPT>(a, aw);
 #ifdef HMPC_MFS_ONLY_WAVE  // developer switch (register pressure of one wave's code)
       default: { HMPC_MFS3_WAVE(HMPC_MFS_ONLY_WAVE) } break;
@@ -1816,7 +1820,11 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       case 0: { HMPC_MFS3_WAVE(0) } break;
       case 1: { HMPC_MFS3_WAVE(1) } break;
       case 2: { HMPC_MFS3_WAVE(2) } break;
-      default: { HMPC_MFS3_WAVE(3) } break;
+      case 3: { HMPC_MFS3_WAVE(3) } break;
+      case 4: { HMPC_MFS3_WAVE((NW > 4 ? 4 : 0)) } break;  // (cases 4-7: the eight-wave wide variant only)
+      case 5: { HMPC_MFS3_WAVE((NW > 4 ? 5 : 0)) } break;
+      case 6: { HMPC_MFS3_WAVE((NW > 4 ? 6 : 0)) } break;
+      default: { HMPC_MFS3_WAVE((NW > 4 ? 7 : 0)) } break;
 #endif
 #undef HMPC_MFS3_WAVE
     }
