@@ -2,16 +2,21 @@
 """bench.py -- MPC QP solves/sec (horizon=10, 2 contacts) of the HIP path, with roofline and CPU-baseline legs.
 
     python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 8 --gait walking                  # BASELINE config 3: 8 x 8 192 walking sweep
+    python bench.py --gpus 4 --contacts 3 --batch 2048       # BASELINE config 5: 4 x 2 048 three-contact QPs
+    python bench.py --gpus N --exchange none                 # diagnosis: N ranks, NO collective -- per-rank kernel-only rates
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 Both forms run N ranks, one per GPU: started WITHOUT torchrun (no WORLD_SIZE in the environment) and N > 1, bench.py
 re-executes itself under `python -m torch.distributed.run --nproc-per-node N` (127.0.0.1, a free port) and passes the
 ranks' exit code on -- it never silently runs one GPU.  It exits non-zero, with the reason on stderr, when fewer than N
-devices are visible or when --gpus disagrees with the WORLD_SIZE it was launched with.
-The multi-GPU configurations of BASELINE.json:
-    python bench.py --gpus 8 --gait walking                  # config 3: 8 x 8 192 walking sweep
-    python bench.py --gpus 4 --contacts 3 --batch 2048       # config 5: 4 x 2 048 three-contact QPs
+devices are visible or when an explicit --gpus disagrees with the WORLD_SIZE it was launched with (no --gpus under
+torchrun = WORLD_SIZE ranks).  Rank bring-up (process group over RCCL + the first collective) runs under a 120-second
+watchdog: a rank that cannot bring RCCL up prints its device list, the RCCL version and the HSA_* / NCCL_* / RCCL_*
+environment to stderr and the job exits non-zero within two minutes instead of hanging; `--exchange none` keeps the
+control plane (barriers, the max over ranks) on gloo and runs no data-path collective at all, so that a broken collective
+still yields a diagnosable per-rank line.
 (`--backend gloo` is a TEST transport that lets the N ranks share GPUs: `python bench.py --gpus 2 --backend gloo` on a
 one-GPU box runs the N = 2 code path, every rank checking its own shard.)
 
@@ -19,6 +24,8 @@ A "step" is one pass of the hot path (assembly + QP solve, one kernel launch) ov
 instances whose packed records already live in HBM (consecutive steps alternate between two launch streams / two output
 blocks, --streams 1 for strictly serial launches); for N > 1 every rank owns a contiguous shard of the global batch
 (weak scaling, per-GPU batch fixed) and the step ends with the all_gather (RCCL) of the solved forces.
+The timed region is K steps between barrier + synchronize on both sides, max over ranks; it is repeated --windows times
+(default 5) and `value` / `ms_per_step` are the MEDIAN window's, with every window's value, min and max in `windows`.
 Rank 0 prints ONE JSON line.  Workload = the case BASELINE.json's metric string names: randomized 2-contact
 (standing gait) instances, horizon 10 -> 120 x 160 QPs (SURVEY.md section 8d "metric_2contact").
 """
@@ -30,6 +37,7 @@ import os
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -412,6 +420,85 @@ def merge_parity(per_rank: list) -> dict:
     return out
 
 
+DIAG_ENV_PREFIXES = ("HSA_", "NCCL_", "RCCL_", "HIP_", "ROCR_", "CUDA_VISIBLE", "TORCH_NCCL", "TORCH_DISTRIBUTED", "MASTER_", "GLOO_")
+DIAG_ENV_NAMES = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK")
+
+
+def rank_diagnostics(rank, local_rank, what: str, exc=None) -> str:
+    """What a maintainer needs when a rank cannot be brought up (first contact with an N-GPU node): devices visible to the
+    rank, the RCCL torch was built with, and every environment variable that steers HSA / RCCL / the rendezvous."""
+    lines = [f"[bench] rank {rank} (LOCAL_RANK {local_rank}): {what}" + (f": {exc!r}" if exc is not None else "")]
+    try:
+        import torch
+
+        nd = torch.cuda.device_count()
+        lines.append(f"[bench]   torch {torch.__version__}, hip {getattr(torch.version, 'hip', None)}, RCCL {rccl_version(torch)}, "
+                     f"{nd} device(s) visible")
+        for i in range(nd):
+            pr = torch.cuda.get_device_properties(i)
+            lines.append(f"[bench]   device {i}: {pr.name} {getattr(pr, 'gcnArchName', '')} pci {getattr(pr, 'pci_bus_id', '?')} "
+                         f"{pr.total_memory >> 30} GiB")
+    except Exception as e2:  # diagnostics must never raise
+        lines.append(f"[bench]   (device query failed: {e2!r})")
+    env = {k: v for k, v in sorted(os.environ.items()) if k.startswith(DIAG_ENV_PREFIXES) or k in DIAG_ENV_NAMES}
+    lines.append("[bench]   env: " + (" ".join(f"{k}={v}" for k, v in env.items()) or "(none of HSA_* NCCL_* RCCL_* HIP_* ROCR_* set)"))
+    lines.append("[bench]   try: `python bench.py --gpus N --exchange none` (no data-path collective: per-rank kernel-only rates), "
+                 "NCCL_DEBUG=INFO, HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC is the only mode this driver supports)")
+    return "\n".join(lines)
+
+
+class BringUpWatchdog:
+    """Bounds rank bring-up: if the guarded region (init_process_group + the first collective) is still running after
+    `seconds`, the rank prints its diagnostics and the PROCESS exits with code 3 -- torchrun then tears the other ranks down
+    -- instead of sitting in the default 10-minute store / communicator time-outs."""
+
+    def __init__(self, seconds: float, rank, local_rank, what: str):
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.args = (rank, local_rank, what, seconds)
+
+    def _fire(self):
+        rank, local_rank, what, seconds = self.args
+        sys.stderr.write(rank_diagnostics(rank, local_rank, f"ERROR: {what} did not finish within {seconds:.0f} s") + "\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+def bring_up_process_group(torch, dist, backend: str, rank: int, local_rank: int, timeout_s: float):
+    """init_process_group with a bounded time-out, then ONE collective on the transport the exchange will use, all under the
+    watchdog.  Any failure: diagnostics on stderr, exit code 3."""
+    from datetime import timedelta
+
+    try:
+        with BringUpWatchdog(timeout_s + 30.0, rank, local_rank, f"bring-up of the {backend} process group"):
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                        timeout=timedelta(seconds=timeout_s))
+                probe = torch.ones(1, device=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend="gloo", timeout=timedelta(seconds=timeout_s))
+                probe = torch.ones(1)
+            dist.all_reduce(probe)  # the first collective creates the communicator: a broken transport fails HERE
+            if probe.is_cuda:
+                torch.cuda.synchronize()
+            if int(probe.item()) != dist.get_world_size():
+                raise RuntimeError(f"first all_reduce returned {probe.item()} for a world of {dist.get_world_size()}")
+    except SystemExit:
+        raise
+    except BaseException as exc:
+        sys.stderr.write(rank_diagnostics(rank, local_rank, f"ERROR: could not bring up the {backend} process group", exc) + "\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+
 def self_launch(args, argv) -> int:
     """`python bench.py --gpus N` without torchrun: N ranks all the same.  Re-executes this file under
     torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a free port) and returns its exit code.
@@ -447,7 +534,14 @@ def main() -> None:
                    int(sys.argv[7]) if len(sys.argv) > 7 else 1)
         return
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of the job.  Default: WORLD_SIZE when launched under torchrun, else 1")
+    ap.add_argument("--windows", type=int, default=5,
+                    help="the timed region (K steps between barrier + synchronize) is repeated this many times; value / ms_per_step "
+                         "are the median window's, every window is in the line")
+    ap.add_argument("--bringup-timeout", type=float, default=120.0,
+                    help="seconds a rank may take to bring up its process group and first collective before it prints its "
+                         "diagnostics and exits 3")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8192, help="MPC instances per GPU per step")
@@ -464,8 +558,10 @@ def main() -> None:
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip the other_configs side measurements (profiling runs: only the headline kernel launches)")
     ap.add_argument("--streams", type=int, default=2, help="launch streams used alternately by consecutive steps (1..4; 2 measured best but for +0.8 %% at 3)")
-    ap.add_argument("--exchange", default="wrench", choices=["wrench", "full"],
-                    help="N>1: what the ranks all_gather per solve (wrench = step-0 wrench + status, SURVEY 8e)")
+    ap.add_argument("--exchange", default="wrench", choices=["wrench", "full", "none"],
+                    help="N>1: what the ranks all_gather per solve (wrench = step-0 wrench + status, SURVEY 8e).  none = a DIAGNOSTIC "
+                         "mode without any data-path collective: the control plane (barriers, max over ranks) runs on gloo, the line "
+                         "carries every rank's kernel-only rate -- what to run when the RCCL exchange of the default mode fails")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the N>1 code path (process group, posted all_gather per solve, stream ordering) with whatever "
                          "WORLD_SIZE is -- also 1: what the one-GPU test of the torchrun path uses")
@@ -477,8 +573,12 @@ def main() -> None:
                     help="solve = the metric (default); builder = rows f1-f3 only (record builder + wrench kernels)")
     ap.add_argument("--check", type=int, default=256, help="instances checked against the oracle after the timed region")
     args = ap.parse_args()
+    gpus_given = args.gpus is not None
+    if not gpus_given:  # (an external `torchrun --nproc-per-node N bench.py` without --gpus runs N ranks)
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    args.windows = max(1, args.windows)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # started without torchrun: N ranks all the same (never a silent one-GPU run that prints n_gpus = 1)
         raise SystemExit(self_launch(args, sys.argv[1:]))
@@ -493,16 +593,19 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the solve path has no CPU fallback")
-    if args.gpus != world:
+    if gpus_given and args.gpus != world:
         # launched under torchrun with another rank count than --gpus asks for: a line whose n_gpus contradicts its command
         raise SystemExit(f"[bench] ERROR: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
                          "(or plain `python bench.py --gpus N`, which starts the N ranks itself)")
     ndev = torch.cuda.device_count()
+    # control-plane / exchange backend: RCCL (product), gloo (TEST transport), or -- --exchange none -- gloo for the barriers only
+    ctl_backend = "gloo" if args.exchange == "none" else args.backend
     if args.backend == "gloo":
         local_rank = local_rank % ndev  # test transport: ranks may share a device
     elif local_rank >= ndev:
-        raise SystemExit(f"[bench] ERROR: rank {rank} (LOCAL_RANK {local_rank}) has no GPU: {ndev} device(s) visible for "
-                         f"{world} ranks -- RCCL needs one device per rank (--backend gloo is the device-sharing TEST transport)")
+        sys.stderr.write(rank_diagnostics(rank, local_rank, f"ERROR: no GPU for this rank: {ndev} device(s) visible for {world} ranks -- "
+                                          "RCCL needs one device per rank (--backend gloo is the device-sharing TEST transport)") + "\n")
+        raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -514,10 +617,7 @@ def main() -> None:
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend="gloo")
+        bring_up_process_group(torch, dist, ctl_backend, rank, local_rank, args.bringup_timeout)
     n_gpus = world
 
     h, B, nc = args.horizon, args.batch, args.contacts
@@ -576,32 +676,39 @@ def main() -> None:
             solve_on(k)
             if xch is not None:
                 xch.post(k, d_forces_l[k], d_status_l[k])  # slot = launch stream: never reused while that stream's step owns it
-            elif world > 1:
+            elif world > 1 and args.exchange == "full":
                 sharding.gather_forces(d_forces_l[k], world * B)
         nstep[0] += 1
 
+    def fence():
+        if xch is not None:
+            xch.wait_all()   # every posted exchange is complete inside the timed region
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         step()
-    if xch is not None:
-        xch.wait_all()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if xch is not None:
-        xch.wait_all()   # every posted exchange is complete inside the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    fence()
+    # the timed region: EXACTLY K steps between barrier + synchronize on both sides, max over ranks -- repeated `--windows` times;
+    # the line's value is the median window's, every window is reported
+    window_s = []
+    for _ in range(args.windows):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if ctl_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        window_s.append(el)
+    elapsed = float(np.median(window_s))
+    if args.windows % 2 == 0:  # (the median of an even count is no window's own time: take the upper middle one)
+        elapsed = sorted(window_s)[args.windows // 2]
     ms_per_step = 1e3 * elapsed / args.steps
 
     exchange_check = None
@@ -731,16 +838,19 @@ def main() -> None:
                                    f"horizon {h}, reduced QP up to {n_red}x{n_red // 6 * 8}; records and forces device-resident in/out; "
                                    "two batches of the same instances one 5 ms tick apart, solved alternately",
                        "batch_per_gpu": B, "global_batch": world * B, "horizon": h, "contacts": nc,
-                       "exchange_backend": (args.backend + (" (TEST transport: host-staged, ranks may share a GPU)" if args.backend == "gloo" else " (RCCL)"))
-                       if (world > 1 or args.force_exchange) else None,
+                       "exchange_backend": (("none (--exchange none: NO data-path collective; barriers and the max over ranks on gloo)" if args.exchange == "none" else
+                                             args.backend + (" (TEST transport: host-staged, ranks may share a GPU)" if args.backend == "gloo" else " (RCCL)"))
+                                            if (world > 1 or args.force_exchange) else None),
                        "launch_streams": nstream,
                        "world": world, "launcher": ("bench.py re-executed itself under torch.distributed.run (--gpus N without torchrun)"
                                                     if os.environ.get("HMPC_BENCH_SELF_LAUNCHED") else
                                                     ("torch.distributed.run (external)" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1 else "python (single process)")),
                        "devices_visible": ndev, "rank_devices": [sm["device"] for sm in summaries],
                        "rccl_version": rccl_version(torch) if (world > 1 or args.force_exchange) else None,
-                       "parallelism": (f"batch shards x{world}, all_gather of "
-                                       f"{'step-0 wrench + status (overlapped with the next solve)' if xch is not None else 'all forces'}")
+                       "parallelism": ((f"batch shards x{world}, all_gather of "
+                                        f"{'step-0 wrench + status (overlapped with the next solve)' if xch is not None else 'all forces'}")
+                                       if args.exchange != "none" else
+                                       f"batch shards x{world}, NO exchange (diagnostic mode: every rank solves its shard, nothing is gathered)")
                        if world > 1 else ("single GPU" + (", exchange code path forced on (group of one)" if xch is not None else "")),
                        **({"exchange_selfcheck_ok": exchange_check} if exchange_check is not None else {})},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -752,6 +862,12 @@ def main() -> None:
                                  "active-set iteration inside one workgroup (LDS/VALU fp64 latency)"},
             "roofline_mfma": {"bound": "mfma", "achieved": ach_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                               "frac": ach_tf / MFMA_F32_PEAK_TF, "algorithmic_mflop_per_solve": mfl},
+            "windows": {"n": args.windows, "steps_each": args.steps,
+                        "values": [world * B * args.steps / w for w in window_s],
+                        "value_min": world * B * args.steps / max(window_s), "value_max": world * B * args.steps / min(window_s),
+                        "spread": (max(window_s) - min(window_s)) / elapsed,
+                        "note": "the timed region (K steps between barrier + synchronize, max over ranks) repeated n times back to "
+                                "back; value / ms_per_step are the median window's"},
             "single_stream": {"value": B * args.steps / single_stream_s, "ms_per_step": 1e3 * single_stream_s / args.steps,
                               "note": "this rank's K passes launched back to back on one stream, no exchange; the headline value "
                                       "alternates two streams (config.launch_streams) so that the partly filled last round of "
@@ -820,6 +936,66 @@ def main() -> None:
             # BASELINE configs[4]: two feet + hand, 180 variables x 240 rows (the three-contact extension)
             for name, bb in (("cfg5_3contact_180x240_b2048_per_gpu", 2048), ("cfg5_3contact_180x240_b8192", 8192)):
                 extra[name] = three_orders(synthetic.make_batch3(bb, 10, "standing", seed=5, hand="contact"), 10, bb, 3)
+            # OFF-NOMINAL INPUT RANGES: the metric's workload (2-contact standing, h = 10, this batch size)
+            # with attitude / velocity / angular-velocity / joint / command ranges at 1x, 3x and 6x SURVEY 8d's
+            # (synthetic.hard_batch), device-resident, INCLUDING the device-side repair of whatever the fast variant flags
+            # (hmpc_set_device_repair: continuation of overflowed working sets + safe pass, no host round trip).  Same protocol as
+            # above: solve tick k, time ONE solve of tick k + 1, best of 4.
+            def range_scale(scale):
+                from oracle import oracle_py
+
+                fs = synthetic.hard_batch(B, h, "standing", 17, scale)
+                rec_a = records.pack_records(fs, h)
+                rec_b = records.pack_records(synthetic.advance_tick(fs, h, seed=9), h)
+                m0 = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, B, device=local_rank)
+                m0.set_auto_resolve(False)      # what the fast pass alone leaves flagged
+                m0.upload(rec_b)
+                m0.solve(stream)
+                torch.cuda.synchronize()
+                t_fast = m0.time_solve(1, stream)
+                _, st0 = m0.download()
+                m0.close()
+                c0 = interface.status_code(st0)
+                m1 = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, B, device=local_rank)
+                m1.set_auto_resolve(False)
+                m1.set_device_repair(True)
+                ts3 = []
+                for _ in range(4):
+                    m1.upload(rec_a)
+                    m1.solve(stream)
+                    torch.cuda.synchronize()
+                    m1.upload(rec_b)
+                    ts3.append(m1.time_solve(1, stream))
+                f1, st1 = m1.download()          # (auto-resolve off: exactly what the device-side passes left)
+                m1.close()
+                c1 = interface.status_code(st1)
+                flagged = np.flatnonzero(c0 != 0)
+                others = np.flatnonzero(c0 == 0)
+                idx = np.concatenate([flagged[:32], others[:64 - min(32, flagged.size)]])
+                refq = oracle_py.solve_records(np.ascontiguousarray(rec_b[idx]), h, synthetic.DT_MPC, synthetic.F_MAX, first=0, count=idx.size)
+                qq = refq["q_soln"]
+                ee = np.abs(f1[idx].astype(np.float64) - qq).max(axis=1) / np.maximum(1.0, np.abs(qq).max(axis=1))
+                okc = (c1[idx] == 0)
+                return {"scale": scale, "solves_per_s": B / (min(ts3) * 1e-3), "kernel_ms": min(ts3),
+                        "fast_pass_only_kernel_ms": t_fast,
+                        "flagged_fraction_fast_pass": float((c0 != 0).mean()),
+                        "flag_codes_fast_pass": {interface.STATUS_NAMES[int(k)]: int(v) for k, v in zip(*np.unique(c0, return_counts=True))},
+                        "not_ok_after_device_repair": int(((c1 != 0) & (c1 != 6)).sum()),
+                        "iters_mean": float(interface.status_iters(st1).mean()), "iters_max": int(interface.status_iters(st1).max()),
+                        "active_max": int(interface.status_nactive(st1).max()),
+                        "checked_vs_qpoases": int(idx.size), "checked_flagged": int(min(32, flagged.size)),
+                        "max_rel_force_err_vs_qpoases": float(ee[okc].max()) if okc.any() else None,
+                        "qpoases_failed_in_checked": int(refq["n_bad"])}
+
+            rs = {f"range_scale_{sc}": range_scale(sc) for sc in (1, 3, 6)}
+            for sc in (3, 6):
+                rs[f"range_scale_{sc}"]["fraction_of_range_scale_1"] = rs[f"range_scale_{sc}"]["solves_per_s"] / rs["range_scale_1"]["solves_per_s"]
+            extra.update(rs)
+            extra["range_scale_note"] = ("2-contact standing h=10 instances with the SURVEY 8d input ranges multiplied by `scale` "
+                                         "(synthetic.hard_batch, seed 17, random gait phase, yaw-rate command), this batch size, ONE "
+                                         "device-resident solve of tick k+1 after tick k (best of 4) with hmpc_set_device_repair on: the "
+                                         "time includes every launch the library enqueues -- dispatch-order sort, fast variant, the "
+                                         "continuation of instances whose working set outgrew the fast variant's 64 rows, the safe pass")
             extra["dispatch_order_note"] = ("every side config: solve tick k, then ONE timed solve of the same instances one 5 ms tick later "
                                             "(best of 4), in three dispatch orders -- `natural` (hmpc_set_dispatch_order 0), `predicted` (2: "
                                             "cost predicted from the records alone, what a cold handle gets), `next_tick` (1, the default: "

@@ -24,6 +24,7 @@ EXPORTS = [
     "hmpc_group_gather_wrench", "hmpc_group_download", "hmpc_group_synchronize", "hmpc_group_last_error",
     "hmpc_group_create_ex", "hmpc_group_contacts", "hmpc_group_set_deal", "hmpc_group_deal", "hmpc_group_member_step",
     "hmpc_upload_records_strided_async", "hmpc_set_max_iterations", "hmpc_legacy_set_max_iterations", "hmpc_tick_solve_device", "hmpc_set_dispatch_order",
+    "hmpc_set_handover",
 ]
 
 
@@ -109,6 +110,7 @@ def load():
     L.hmpc_reset_tick_warm_start.argtypes = [vp]
     L.hmpc_resolve_failed.argtypes = [vp, C.POINTER(ci)]
     L.hmpc_set_auto_resolve.argtypes = [vp, ci]
+    L.hmpc_set_handover.argtypes = [vp, ci]
     L.hmpc_set_device_repair.argtypes = [vp, ci]
     L.hmpc_group_set_exchange_repair.argtypes = [vp, ci]
     L.hmpc_set_device_outputs.argtypes = [vp, vp, vp]

@@ -118,11 +118,19 @@ struct hmpc_handle {
   // packed Schur inverses of the EGLOBAL safe variants: [e_slices][nmax (nmax + 1) / 2] doubles, grown on demand
   double *d_escratch;
   size_t e_bytes;
+  // hand-over of full working sets (KernelArgs::spill): one slot per instance (slot = instance index), allocated on the first
+  // launch of a variant that saves its state; spill_stride = bytes per slot of the allocation, spill_cap = slots
+  unsigned char *d_spill;
+  int *d_spill_slot;
+  size_t spill_stride;
+  int spill_cap;
+  int handover;  // hmpc_set_handover (default on)
 };
 // longest-first dispatch (hmpc_set_dispatch_order, on by default): only where a launch has a tail to shorten -- more instances
 // than the ~512-1536 workgroup slots of the chip -- and not beyond what the one-workgroup sort handles in a few microseconds
 constexpr int DISPATCH_ORDER_MIN_BATCH = 512, DISPATCH_ORDER_MAX_BATCH = 32768;
-constexpr int REPAIR_GRID_CAP = 2048;  // workgroups of the device-side safe launch = most instances it can repair per solve
+constexpr int REPAIR_GRID_CAP = 65536;  // workgroups of the device-side safe launch = most instances it can repair per solve (until round 6: 2 048; workgroups beyond the flagged count leave at once)
+constexpr int SPILL_SLOT_CAP = 32768;   // hand-over slots per handle at most (101 KB each for 120 variables: 3.3 GB of the 288 GB); instances beyond it are re-solved cold
 constexpr int EGLOBAL_CHUNK = 512;         // host-driven safe pass of the global-E variants: instances per launch (118 MB of scratch at 240 variables)
 constexpr int REPAIR_GRID_CAP_WIDE = 256;  // ... of the wide variant's, whose safe pass keeps 231 KB per workgroup in global memory
 
@@ -192,6 +200,7 @@ struct LaunchOpt {
   bool ultimate = false;   // safe pass, second level (three contacts): the variant whose working set cannot overflow
   int cls_lo = 0, cls_hi = -1;  // cls_hi >= 0: only instances whose size class lies in [cls_lo, cls_hi] (h->d_cls)
   int safe_variant = -1;   // safe pass over an index list: this entry of variants() instead of the one derived from pick_variant
+  bool resume = false;     // safe pass over an index list: instances whose fast solve left its state in a hand-over slot continue from it
 };
 
 static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
@@ -223,6 +232,25 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
       HIP_TRY(hipMalloc(&h->d_escratch, need));
       h->e_bytes = need;
     }
+  }
+  // hand-over slots: allocated on the first launch of a variant that saves its state (one slot per instance of the handle).
+  // The per-instance slot table is written by EVERY ordinary launch of such a variant (-1 where nothing was saved), also when
+  // saving itself is off for the launch, so that a later safe pass never meets an entry of an earlier batch.
+  const bool can_save = v.spill_stride > 0 && !o.assemble_only && !o.d_index_list;
+  const bool saves = can_save && h->handover && !h->d_ext_H;
+  if (can_save && !h->d_spill_slot) {
+    HIP_TRY(hipMalloc(&h->d_spill_slot, (size_t)h->max_batch * sizeof(int)));
+    HIP_TRY(hipMemset(h->d_spill_slot, 0xff, (size_t)h->max_batch * sizeof(int)));
+  }
+  if (saves && (!h->d_spill || h->spill_stride < v.spill_stride)) {
+    if (h->d_spill) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(h->d_spill));
+      h->d_spill = nullptr;
+    }
+    const int cap = h->max_batch < SPILL_SLOT_CAP ? h->max_batch : SPILL_SLOT_CAP;
+    HIP_TRY(hipMalloc(&h->d_spill, (size_t)cap * v.spill_stride));
+    h->spill_stride = v.spill_stride, h->spill_cap = cap;
   }
   kernel_fn fn = o.assemble_only ? v.assemble : v.solve;
   if (!h->attrs_set[vi]) {
@@ -261,6 +289,13 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   a.cls = (o.cls_hi >= 0) ? h->d_cls : nullptr;
   a.cls_lo = o.cls_lo, a.cls_hi = o.cls_hi;
   a.e_scratch = h->d_escratch;
+  a.spill = nullptr, a.spill_stride = 0, a.spill_cap = 0, a.spill_slot = nullptr, a.resume = 0;
+  if (can_save) {
+    a.spill_slot = h->d_spill_slot;
+    if (saves) a.spill = h->d_spill, a.spill_stride = h->spill_stride, a.spill_cap = h->spill_cap;
+  } else if (o.d_index_list && o.resume && v.resumes && h->handover && h->d_spill && h->d_spill_slot && o.relax == 0.0 && !h->d_ext_H) {
+    a.spill = h->d_spill, a.spill_stride = h->spill_stride, a.spill_cap = h->spill_cap, a.spill_slot = h->d_spill_slot, a.resume = 1;
+  }
   for (int off = 0; off < grid_all; off += chunk) {
     const int grid = (grid_all - off < chunk) ? grid_all - off : chunk;
     if (off > 0) a.index_list = o.d_index_list + off;  // (only list launches are ever chunked)
@@ -362,6 +397,7 @@ static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
   s.warm = 0;
   s.carry_wset = carry_wset;
   s.d_list_count = h->d_flag_count;
+  s.resume = true;  // instances whose working set outgrew the fast variant continue from the state it handed over
   return launch_safe(h, stream, s);
 }
 
@@ -445,6 +481,7 @@ int hmpc_create_ex(hmpc_handle **out, const struct problem_setup *setup, int max
   h->max_stance = -1;
   h->warm = 1;
   h->auto_resolve = 1;
+  h->handover = 1;
   const size_t nf = (size_t)max_batch * 6 * n_contacts * setup->horizon;
   if (hipMalloc(&h->d_records_own, (size_t)max_batch * h->stride) != hipSuccess ||
       hipMalloc(&h->d_forces_own, nf * sizeof(float)) != hipSuccess ||
@@ -498,6 +535,8 @@ int hmpc_destroy(hmpc_handle *h) {
   if (h->d_cls) hipFree(h->d_cls);
   if (h->d_order) hipFree(h->d_order);
   if (h->d_escratch) hipFree(h->d_escratch);
+  if (h->d_spill) hipFree(h->d_spill);
+  if (h->d_spill_slot) hipFree(h->d_spill_slot);
   delete h;
   return HMPC_OK;
 }
@@ -507,7 +546,7 @@ static int upload_common(hmpc_handle *h, const void *host_records, int batch, bo
   if (!h || !host_records || batch < 0) return HMPC_E_ARG;
   if (batch > h->max_batch) return HMPC_E_BATCH;
   if (pitch == 0) pitch = h->stride;
-  if (pitch < h->stride) return HMPC_E_ARG;
+  if (pitch < h->stride || pitch % 4 != 0) return HMPC_E_ARG;
   HIP_TRY(hipSetDevice(h->device));
   if (pitch != h->stride) {
     if (batch > 0)
@@ -601,6 +640,12 @@ int hmpc_set_max_iterations(hmpc_handle *h, int max_iter) {
   return HMPC_OK;
 }
 
+int hmpc_set_handover(hmpc_handle *h, int on) {
+  if (!h) return HMPC_E_ARG;
+  h->handover = on ? 1 : 0;
+  return HMPC_OK;
+}
+
 int hmpc_set_auto_resolve(hmpc_handle *h, int on) {
   if (!h) return HMPC_E_ARG;
   h->auto_resolve = on ? 1 : 0;
@@ -673,6 +718,12 @@ int hmpc_set_device_repair(hmpc_handle *h, int on) {
   return HMPC_OK;
 }
 
+// an HMPC_S_MAXITER status is the CALLER's answer (not re-solved) exactly when the kernel says so: the caller's cap was the
+// bound in force, i.e. the iteration count reached it (hmpc_kernel.h: `capped`; the variants' own bounds are 4 m + 16 and up)
+static bool capped_by_caller(const hmpc_handle *h, uint32_t status) {
+  return h->iter_cap > 0 && (int)HMPC_STATUS_ITERS(status) >= h->iter_cap && (int)HMPC_STATUS_ITERS(status) <= h->iter_cap + 1;
+}
+
 int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
   if (!h) return HMPC_E_ARG;
   if (n_resolved) *n_resolved = 0;
@@ -684,8 +735,10 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
   std::vector<int> idx;
   for (int i = 0; i < h->batch; ++i) {
     const uint32_t c = HMPC_STATUS_CODE(st[i]);
-    // (a solve that ran into the caller's own iteration cap, hmpc_set_max_iterations, is the caller's answer: not re-solved)
-    if (c == HMPC_S_WORKSET || (c == HMPC_S_MAXITER && h->iter_cap <= 0) || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT)
+    // (a solve that ran into the caller's own iteration cap, hmpc_set_max_iterations, is the caller's answer: not re-solved --
+    //  the kernel's rule: the cap counts only when it is below the variant's own bound, i.e. when the iteration count of the
+    //  status word reached it; a solve that hit the VARIANT's bound under a generous cap is re-solved like any other)
+    if (c == HMPC_S_WORKSET || (c == HMPC_S_MAXITER && !capped_by_caller(h, st[i])) || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT)
       idx.push_back(i);
   }
   if (idx.empty()) return HMPC_OK;
@@ -700,7 +753,9 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
   // the safe pass starts cold, as the reference does (launch parameter; the handle's own setting is not touched)
   LaunchOpt so;
   so.d_index_list = d_idx, so.n_list = (int)idx.size(), so.warm = 0;
+  so.resume = true;  // (first pass only: a slot is consumed by the continuation, later passes start cold)
   int rc = launch_safe(h, h->last_stream, so);
+  so.resume = false;
   if (rc != HMPC_OK) return rc;
   HIP_TRY(hipStreamSynchronize(h->last_stream));
   if (n_resolved) *n_resolved = (int)idx.size();
@@ -728,7 +783,7 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
     HIP_TRY(hipMemcpy(st.data(), h->d_status, (size_t)h->batch * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (int i : idx) {
       const uint32_t c = HMPC_STATUS_CODE(st[i]);
-      if ((c == HMPC_S_MAXITER && h->iter_cap <= 0) || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT || c == HMPC_S_WORKSET) still.push_back(i);
+      if ((c == HMPC_S_MAXITER && !capped_by_caller(h, st[i])) || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT || c == HMPC_S_WORKSET) still.push_back(i);
     }
     if (still.empty()) break;
     HIP_TRY(hipMemcpy(d_idx, still.data(), still.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1182,7 +1237,7 @@ static void solve_global(void) {
   if (rc == HMPC_OK) {
     st = *pst;
     const uint32_t c0 = HMPC_STATUS_CODE(st);
-    if (c0 == HMPC_S_WORKSET || (c0 == HMPC_S_MAXITER && g_handle->iter_cap <= 0) || c0 == HMPC_S_INFEASIBLE || c0 == HMPC_S_KKT) {
+    if (c0 == HMPC_S_WORKSET || (c0 == HMPC_S_MAXITER && !capped_by_caller(g_handle, st)) || c0 == HMPC_S_INFEASIBLE || c0 == HMPC_S_KKT) {
       // flagged by the fast variant: the safe pass (full-size working set, then relaxed bounds), as hmpc_download gives it
       rc = hmpc_resolve_failed(g_handle, nullptr);
       if (rc == HMPC_OK && hipMemcpy(g_pin + g_pin_rec_bytes, g_dev_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess)

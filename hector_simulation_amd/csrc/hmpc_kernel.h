@@ -29,6 +29,7 @@
 //      explicitly (bordering / Schur-complement downdates: no triangular solves), M applied in place from the register
 //      blocks with a fixed-order staged reduction (deterministic).  One refinement step of the multipliers at the end (HMPC_REFINE).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -166,6 +167,25 @@ struct Smem {
     Asm a;
     Sol s;
   } u;
+};
+
+// Layout of one hand-over slot (KernelArgs::spill): what a fast variant whose working set is full leaves for the continuation
+// variant.  Every member of Smem::Sol before Ep has the same offset in all variants of one shape (NMAX, HMAX, NT, NC, BPT) -- QCAP
+// only sizes Ep, the last member -- so the bytes go from the fast variant's LDS into the continuation variant's as they are:
+//   [0, A_BYTES)            Sol bytes [0, offsetof(ST)): x, x_u, z, w
+//   [A_BYTES, E_OFF)        Sol bytes [offsetof(piv), offsetof(Ep)): pivot rows (unused), u, d, r, col, reductions, act, slot, flpc, Wrow
+//   [E_OFF, ...)            the packed Schur inverse, q (q + 1) / 2 doubles
+//   [stride - M_BYTES, stride)   the 6 x 6 register blocks of M = H^-1, entry (ii, jj) of thread t at (ii GS + jj) NT + t (coalesced)
+// q and the iteration count travel in the status word.  The host sizes the stride for the source variant's QCAP (Variant::spill_stride).
+template <class SM, int NT, int BPT>
+struct SpillLayout {
+  typedef typename SM::Sol SolT;
+  static constexpr size_t A_BYTES = offsetof(SolT, ST);
+  static constexpr size_t B_OFF = offsetof(SolT, piv), B_BYTES = offsetof(SolT, Ep) - offsetof(SolT, piv);
+  static constexpr size_t E_OFF = A_BYTES + B_BYTES;
+  static constexpr size_t M_BYTES = (size_t)BPT * GS * GS * NT * sizeof(double);
+  static constexpr size_t stride_for(int rows) { return (E_OFF + (size_t)rows * (rows + 1) / 2 * sizeof(double) + M_BYTES + 255) / 256 * 256; }
+  static_assert(A_BYTES % 8 == 0 && B_OFF % 8 == 0 && B_BYTES % 8 == 0, "copied as 8-byte words");
 };
 
 // index of H(i,j), i <= j, in the folded upper-triangle staging array: row i (< NMAX/2) and row NMAX-1-i share one
@@ -1011,6 +1031,20 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     if (c < args.cls_lo || c > args.cls_hi) return;
   }
   PROF_DECL;
+  // Hand-over of a full working set (KernelArgs::spill, SpillLayout): the fast 120-variable variants SAVE their state, the safe
+  // variants of the same shape (working set = variable count, in LDS) RESUME from it -- they assemble the instance again (index
+  // tables, constraint normals, g: cheap and bit-identical), then take M, E and the Goldfarb-Idnani state from the slot instead of
+  // running stages H, S and the start
+  constexpr bool SHAPE_HANDOVER = !ASM_ONLY && NMAX == 120 && NT == 256 && NC == 2 && BPT == 1 && !SM::EGLOBAL;
+  constexpr bool SPILLS = SHAPE_HANDOVER && QCAP < NMAX;
+  constexpr bool RESUMABLE = SHAPE_HANDOVER && QCAP >= NMAX;
+  using SPL = SpillLayout<SM, NT, BPT>;
+  bool resumed = false;
+  if constexpr (RESUMABLE) {
+    // (the slot must be this instance's own and its status word must still say "working set full": both are written by the fast
+    //  variant in the same solve; anything else -- a stale entry of an earlier batch -- starts cold)
+    if (args.resume) resumed = ub(args.spill_slot[inst] == inst && inst < args.spill_cap && (args.status[inst] & 0xffu) == (uint32_t)S_WORKSET);
+  }
 
   // ---------------- A0: one coalesced burst brings the instance's record into LDS ----------------
   {
@@ -1433,6 +1467,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     }
   };
   double a[BPT][GS][GS];
+  if (!(RESUMABLE && resumed)) {  // (a resumed solve takes M from its hand-over slot: no H, no sweeps)
   if constexpr (SM::FULLBLK) {
     // H on the matrix cores, through the block-Toeplitz structure of B_qp.  With Phi_k = Acd^k Bcd,
     //     H(a,b) = 2 [ sum_{i >= b} Phi_{i-a}' S Phi_{i-b} + alpha delta_ab ]          (U x U block, steps a <= b)
@@ -1708,6 +1743,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         }
     }
   }
+  }  // !resumed
 
   PROF_MARK(P_HG);
   if (ASM_ONLY) {
@@ -1757,6 +1793,19 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // sweeps of a leg-step are statically unrolled (static register indices).
   const bool is_v = tid < n, is_c = tid < m;
   // (the register blocks were loaded from the staging area of H at the end of stage A5)
+  if (RESUMABLE && resumed) {
+    if constexpr (RESUMABLE) {
+      // ---- hand-over: M from the slot's tail (the layout the fast variant's threads left: same block ownership)
+      __syncthreads();  // g has been formed from the staging of the assembly, which the solver state aliases
+      own_blocks();
+      const unsigned char *slotp = args.spill + (size_t)args.spill_slot[inst] * args.spill_stride;
+      const double *mb = reinterpret_cast<const double *>(slotp + args.spill_stride - SPL::M_BYTES);
+#pragma unroll
+      for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < GS; ++jj) a[0][ii][jj] = mb[(ii * GS + jj) * NT + tid];
+    }
+  } else
   if constexpr (MFMA_SWEEP) {
     // ---- matrix-core sweeps (mfma_sweeps above): tiles from the staging of H, 4 x 4 block pivots, M back in the 6 x 6 blocks
     auto hinfo = [&](const int i) __attribute__((always_inline)) -> int {  // i < n, sweep order
@@ -2107,6 +2156,20 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   const auto v_k = lazy_int<LAZY_IDX>([](int t) { return t % GS; });
   const int v_leg_r = (!LAZY_IDX && is_v) ? S.ls_leg[v_e] : 0;
   auto var_leg = [&]() __attribute__((always_inline)) -> int { if constexpr (!LAZY_IDX) return v_leg_r; else return (tid < n) ? (int)S.ls_leg[v_e] : 0; };
+  int q = 0, iters = 0, code = S_OK;
+  if (RESUMABLE && resumed) {
+    if constexpr (RESUMABLE) {
+      // ---- hand-over: the Goldfarb-Idnani state the fast variant stopped in (x minimises over the working set, u >= 0, E current)
+      const uint32_t st0 = args.status[inst];
+      q = uni((int)((st0 >> 20) & 0xfffu)), iters = uni((int)((st0 >> 8) & 0xfffu));
+      const double *sp = reinterpret_cast<const double *>(args.spill + (size_t)args.spill_slot[inst] * args.spill_stride);
+      double *qa = reinterpret_cast<double *>(&Q), *qb = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(&Q) + SPL::B_OFF);
+      for (int t = tid; t < (int)(SPL::A_BYTES / 8); t += NT) qa[t] = sp[t];
+      for (int t = tid; t < (int)(SPL::B_BYTES / 8); t += NT) qb[t] = sp[SPL::A_BYTES / 8 + t];
+      for (int t = tid; t < q * (q + 1) / 2; t += NT) Ep[(unsigned)t] = sp[SPL::E_OFF / 8 + t];
+      __syncthreads();
+    }
+  } else {
   for (int t = tid; t < SM::MMAX; t += NT) {
     Q.act[t] = 0;
     Q.slot[t] = 0;
@@ -2122,9 +2185,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     Q.x[tid] = xv;
   }
   __syncthreads();
+  }
   PROF_MARK(P_XU);
 
-  int q = 0, iters = 0, code = S_OK;
   constexpr bool SAFE = SM::EGLOBAL || QCAP >= NMAX;  // the working set cannot overflow
   // ... and of those, the variants hmpc_resolve_failed / the device-side repair launch (always cold): the only ones that ever run
   // for hundreds of iterations (the 60-variable fast variants also have QCAP = NMAX, but are fast variants)
@@ -2741,6 +2804,15 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         code = S_MAXITER;
         break;
       }
+      if constexpr (SPILLS) {
+        // a violated row and a full working set: stop HERE, between two iterations, where (x, u, W, E) is a complete
+        // Goldfarb-Idnani state that the continuation variant can take over (inside an iteration -- after partial steps for
+        // the row being added -- it is not).  Conservative by at most one row: the step might have dropped a row first.
+        if (q >= SM::QMAX) {
+          code = S_WORKSET;
+          break;
+        }
+      }
       wsel = uni(wsel);
       const int p = uni(Q.rec[wsel].idx), sgi = uni(Q.rec[wsel].side);
       const int ep = p >> 3;
@@ -2924,6 +2996,31 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     // a refinement that moved x across another constraint sends us back into the main loop (rare)
   }
 
+  if constexpr (SPILLS) {
+    if (args.spill_slot) {  // uniform
+      int slot = -1;
+      if (code == S_WORKSET && args.spill) {  // uniform: hand the live state over (SpillLayout)
+        __syncthreads();
+        // instance i owns slot i (no counter to reset, no atomics, the same place every run); instances beyond the buffer's
+        // capacity -- batches above the host's slot cap -- are flagged as before and re-solved cold
+        if (inst < args.spill_cap) {
+          slot = inst;
+          double *sp = reinterpret_cast<double *>(args.spill + (size_t)slot * args.spill_stride);
+          const double *qa = reinterpret_cast<const double *>(&Q);
+          const double *qb = reinterpret_cast<const double *>(reinterpret_cast<const unsigned char *>(&Q) + SPL::B_OFF);
+          for (int t = tid; t < (int)(SPL::A_BYTES / 8); t += NT) sp[t] = qa[t];
+          for (int t = tid; t < (int)(SPL::B_BYTES / 8); t += NT) sp[SPL::A_BYTES / 8 + t] = qb[t];
+          for (int t = tid; t < q * (q + 1) / 2; t += NT) sp[SPL::E_OFF / 8 + t] = Ep[(unsigned)t];
+          double *mb = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(sp) + args.spill_stride - SPL::M_BYTES);
+#pragma unroll
+          for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < GS; ++jj) mb[(ii * GS + jj) * NT + tid] = a[0][ii][jj];
+        }
+      }
+      if (tid == 0) args.spill_slot[inst] = slot;
+    }
+  }
   PROF_MARK(P_POLISH);
   // final KKT check: primal slack (every row not in the working set), residual of the working set's rows, multiplier signs
   __syncthreads();
@@ -3030,6 +3127,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     }
   }
   if (tid == 0) {
+    if constexpr (RESUMABLE) {
+      if (resumed) args.spill_slot[inst] = -1;  // the slot is consumed: a later pass over this instance starts cold
+    }
     args.status[inst] = (uint32_t)code | ((uint32_t)(iters & 0xfff) << 8) | ((uint32_t)(q & 0xfff) << 20);
     // (an instance that ran into the CALLER'S iteration cap is the caller's answer: it is neither counted nor listed for the
     //  safe pass -- the device-side repair would otherwise re-solve it cold and overwrite its last iterate)

@@ -62,6 +62,21 @@ struct KernelArgs {
   // scratch for the variants that keep the packed Schur inverse in global memory (Smem::EGLOBAL): NMAX (NMAX + 1) / 2
   // doubles per WORKGROUP of the launch (indexed by blockIdx.x)
   double *e_scratch;
+  // Hand-over of a solve whose working set outgrew the fast variant's on-chip capacity (round 6; replaces "flag S_WORKSET and
+  // re-solve cold").  A fast 120-variable variant that finds a violated row while its working set is full writes its live
+  // Goldfarb-Idnani state -- point x, x_u, multipliers u, the working set (act / slot / Wrow), the packed Schur inverse E and the
+  // 6 x 6 register blocks of M = H^-1 -- to the instance's own slot of `spill` (slot = instance index; spill_stride bytes each,
+  // spill_cap slots; layout: SpillLayout in hmpc_kernel.h) and leaves the slot number in spill_slot[inst] (-1: nothing saved).
+  // The continuation -- the safe variant of the same shape, whose working set holds as many rows as there are variables,
+  // launched over the flagged list with `resume` set -- re-assembles the instance's constraint data (cheap, bit-identical),
+  // takes M, E and the state from the slot instead of inverting H and starting cold, goes on with the iteration where the
+  // fast variant stopped, and marks the slot consumed.  nullptr / 0 = off (a full working set is flagged S_WORKSET as before and
+  // re-solved cold).
+  unsigned char *spill;
+  size_t spill_stride;
+  int spill_cap;
+  int *spill_slot;  // [batch]
+  int resume;       // continuation launch: instances with spill_slot[inst] >= 0 resume from their slot
 };
 constexpr int NPROF = 32;
 enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A, P_A0, P_A1, P_A2, P_G };

@@ -22,6 +22,10 @@ struct Variant {
   kernel_fn solve, assemble;
   size_t smem;
   int dbg_floats;
+  // hand-over of a full working set (KernelArgs::spill): bytes of one slot when this variant SAVES its state (fast 120-variable
+  // variants), 0 otherwise; resumes = this variant can continue from such a slot (the safe variants of the same shape)
+  size_t spill_stride;
+  bool resumes;
 };
 
 // index = position in hmpc_capi.hip's variants(); (NMAX, HMAX, NT, QCAP, NC, BPT), group = translation unit that builds it.

@@ -15,9 +15,13 @@ template <int NMAX, int HMAX, int NT, int QCAP, int NC, int BPT>
 Variant make_variant() {
   static_assert(sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>) <= 160 * 1024, "LDS budget of a gfx950 CU");
   static_assert(BPT == 1 || NT >= 512 || sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>) <= 80 * 1024, "two workgroups per CU");
+  using SM = hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>;
+  // (the same shape test as SHAPE_HANDOVER / SPILLS / RESUMABLE in hmpc_kernel.h)
+  constexpr bool handover = NMAX == 120 && NT == 256 && NC == 2 && BPT == 1 && QCAP != 0;
   return Variant{NMAX, HMAX, NT, QCAP, NC, hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, false, NC, BPT>,
-                 hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, true, NC, BPT>, sizeof(hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>),
-                 hmpc::DbgLayout<NMAX, NC>::TOTAL};
+                 hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, true, NC, BPT>, sizeof(SM),
+                 hmpc::DbgLayout<NMAX, NC>::TOTAL,
+                 (handover && QCAP < NMAX) ? hmpc::SpillLayout<SM, NT, BPT>::stride_for(QCAP) : 0, handover && QCAP >= NMAX};
 }
 }  // namespace
 

@@ -139,6 +139,10 @@ class BatchedMPC:
     def set_auto_resolve(self, on: bool) -> None:
         _check(self.L.hmpc_set_auto_resolve(self.h, 1 if on else 0), "hmpc_set_auto_resolve")
 
+    def set_handover(self, on: bool) -> None:
+        """Continue (default) or re-solve cold the instances whose working set outgrew the fast variant (hmpc_set_handover)."""
+        _check(self.L.hmpc_set_handover(self.h, 1 if on else 0), "hmpc_set_handover")
+
     def set_device_repair(self, on: bool) -> None:
         """Device-side safe pass inside every solve (include/hector_mpc.h hmpc_set_device_repair)."""
         _check(self.L.hmpc_set_device_repair(self.h, 1 if on else 0), "hmpc_set_device_repair")

@@ -146,6 +146,24 @@ def advance_tick(fields: dict, horizon: int, seed: int = 0, dt_tick: float = 0.0
     return out
 
 
+def hard_batch(batch: int, horizon: int = 10, gait: str = "standing", seed: int = 17, scale: float = 1.0) -> dict:
+    """``make_batch`` (random phase, yaw-rate command) with the attitude, velocity, angular-velocity, joint and commanded-
+    velocity ranges of SURVEY.md section 8d multiplied by ``scale`` -- the off-nominal stress rows (scripts/stress.py,
+    tests/test_gpu_robustness.py, bench.py's ``range_scale_*`` side configs): at 3x / 6x / 10x the final working sets of the
+    2-contact QP grow from ~50 to 72 / 91 / 95 rows and a cold qpOASES run takes up to 104 / 193 / 242 iterations."""
+    f = make_batch(batch, horizon, gait, seed=seed, phase="random", yaw_rate_cmd=True)
+    rng = np.random.default_rng(seed + 1)
+    rpy = rng.uniform(-0.1 * scale, 0.1 * scale, (batch, 3))
+    f["q"] = quat_from_rpy(rpy[:, 0], rpy[:, 1], rpy[:, 2])
+    f["v"] = rng.uniform(-0.3 * scale, 0.3 * scale, (batch, 3))
+    f["w"] = rng.uniform(-0.5 * scale, 0.5 * scale, (batch, 3))
+    f["joint_angles"] = rng.uniform(-0.15 * scale, 0.15 * scale, (batch, 10))
+    tr = f["traj"].reshape(batch, horizon, 12)
+    tr[:, :, 9] *= scale
+    f["traj"] = tr.reshape(batch, -1)
+    return f
+
+
 ALPHA3 = np.array([1e-4, 1e-4, 5e-4] * 3 + [1e-2] * 9, dtype=np.float64)
 F_MAX_HAND = 150.0
 

@@ -206,12 +206,26 @@ int hmpc_set_dispatch_order(hmpc_handle *h, int mode);
 int hmpc_set_max_iterations(hmpc_handle *h, int max_iter);
 int hmpc_legacy_set_max_iterations(int max_iter);
 int hmpc_set_auto_resolve(hmpc_handle *h, int on);
+/* Hand-over of a full working set (round 6; default on).  A fast two-contact variant (<= 120 reduced variables) whose working
+ * set is full (HMPC_STATUS_NACTIVE = 64) when another row is violated no longer throws its work away: it writes its live
+ * Goldfarb-Idnani state -- x, multipliers, working set, the packed Schur inverse and the register-resident H^-1 -- to the
+ * instance's slot of a per-handle buffer in HBM (101 KB per instance of max_batch, allocated at the first solve; at most
+ * 32 768 slots) and flags the instance HMPC_S_WORKSET as before; the safe pass -- the device-side one of hmpc_set_device_repair or
+ * the host-driven one of hmpc_resolve_failed / hmpc_download -- then CONTINUES that solve on the variant whose working set cannot
+ * overflow instead of re-solving it cold without the block start: same optimum (the QP is strictly convex), a fraction of the
+ * iterations (the reference's qpOASES run needs up to 190 working-set changes for such an instance, SolverMPC.cpp:699-712; the
+ * continuation the 20-40 that were still missing).  on = 0: the round-5 behaviour (flag, re-solve cold).  Three-contact handles
+ * and the wide variant (> 120 reduced variables) always take the cold path. */
+int hmpc_set_handover(hmpc_handle *h, int on);
 /* Device-side safe pass (default off for a plain handle): when on, hmpc_solve enqueues, behind the fast launch and on the
  * same stream, the safe variant over the list of instances the fast launch flagged (the list and its length stay on the
  * device; workgroups beyond the length leave at once) -- device-resident outputs, hmpc_download_async and the group
  * exchange then see repaired forces/status without any host involvement.  Costs one 4-byte memset and one (normally
- * empty) extra launch per solve; repairs at most min(batch, 2048) instances per solve, the rest stay flagged for
- * hmpc_resolve_failed / hmpc_download. */
+ * empty) extra launch per solve; repairs every flagged instance of batches up to 65 536 (the wide variant's instances, whose safe
+ * pass keeps 231 KB of global scratch per workgroup: the first 256 positions of the flagged list -- which it shares with the
+ * <= 120-variable instances of an unsized h > 10 batch, so fewer than 256 wide ones may be reached), the rest stay flagged for
+ * hmpc_resolve_failed / hmpc_download.  Instances whose working set merely outgrew the fast variant are CONTINUED, not
+ * re-solved (hmpc_set_handover). */
 int hmpc_set_device_repair(hmpc_handle *h, int on);
 /* NOTE (device repair): the list of flagged instances and its counter belong to the handle -- keep the solves of ONE handle
  * on one stream at a time (use one handle per stream to overlap launches, as bench.py does). */
@@ -220,7 +234,7 @@ int hmpc_set_device_repair(hmpc_handle *h, int on);
  * and must stay valid until the stream reaches them.  hmpc_download_async does not run the safe pass: check the status
  * words after synchronising and call hmpc_resolve_failed + hmpc_download for a batch that has flagged instances. */
 int hmpc_upload_records_async(hmpc_handle *h, const void *host_records, int batch, void *stream);
-/* ... every pitch_bytes-th record of a larger host array (pitch_bytes >= hmpc_record_stride, a multiple of 4): record k of the
+/* ... every pitch_bytes-th record of a larger host array (pitch_bytes >= hmpc_record_stride and a multiple of 4, else HMPC_E_ARG): record k of the
  * batch is read at host_records + k * pitch_bytes -- one strided copy, no host staging (what a striped device group uses). */
 int hmpc_upload_records_strided_async(hmpc_handle *h, const void *host_records, int batch, size_t pitch_bytes, void *stream);
 int hmpc_download_async(hmpc_handle *h, float *forces, uint32_t *status, void *stream);
@@ -368,8 +382,7 @@ int hmpc_group_device_gathered(hmpc_group *g, int member, const uint32_t **gathe
  * returns host copies in instance order of the batch the exchange was posted for (its slices are remembered at post
  * time): wrench [batch][6 nc] (12 for two contacts), status [batch] (either may be NULL).
  * The exchange carries REPAIRED rows: every member's solve is followed on its stream, without a host round trip, by the
- * safe variant over the instances the fast variant flagged (hmpc_set_device_repair, on by default for group members; up to
- * 2048 per member per solve).  hmpc_group_set_exchange_repair(g, 0) turns that off: the exchange then carries the fast
+ * safe variant over the instances the fast variant flagged (hmpc_set_device_repair, on by default for group members).  hmpc_group_set_exchange_repair(g, 0) turns that off: the exchange then carries the fast
  * pass's results as they are (a flagged instance shows in its status word, its wrench is not valid) and only
  * hmpc_group_download repairs.  Instances that defeat even the safe variant (degenerate vertices, < 0.1 % at 6x the
  * nominal input ranges) stay flagged in the status word either way; hmpc_group_download's relaxed passes handle them. */

@@ -11,15 +11,7 @@ from oracle import oracle_py, pool
 import importlib.util
 spec = importlib.util.spec_from_file_location("stress_mod", os.path.join(ROOT, "scripts", "stress.py"))
 gait, h, scale, nb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 1024
-def hard_batch(nb, h, gait, seed, scale):
-    f = synthetic.make_batch(nb, h, gait, seed=seed, phase="random", yaw_rate_cmd=True)
-    rng = np.random.default_rng(seed + 1)
-    rpy = rng.uniform(-0.1 * scale, 0.1 * scale, (nb, 3))
-    f["q"] = synthetic.quat_from_rpy(rpy[:, 0], rpy[:, 1], rpy[:, 2])
-    f["v"] = rng.uniform(-0.3 * scale, 0.3 * scale, (nb, 3)); f["w"] = rng.uniform(-0.5 * scale, 0.5 * scale, (nb, 3))
-    f["joint_angles"] = rng.uniform(-0.15 * scale, 0.15 * scale, (nb, 10))
-    tr = f["traj"].reshape(nb, h, 12); tr[:, :, 9] *= scale; f["traj"] = tr.reshape(nb, -1)
-    return f
+hard_batch = synthetic.hard_batch  # (nb, h, gait, seed, scale): the off-nominal stress rows
 f = hard_batch(nb, h, gait, 17, scale); rec = records.pack_records(f, h)
 mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb); mpc.upload(rec); mpc.solve(); forces, status = mpc.download()
 x64, obj64 = mpc.download_f64(); mpc.close()

@@ -12,15 +12,7 @@ sys.path.insert(0, ROOT)
 from hector_simulation_amd import interface, records, synthetic  # noqa: E402
 
 
-def hard_batch(nb, h, gait, seed, scale):
-    f = synthetic.make_batch(nb, h, gait, seed=seed, phase="random", yaw_rate_cmd=True)
-    rng = np.random.default_rng(seed + 1)
-    rpy = rng.uniform(-0.1 * scale, 0.1 * scale, (nb, 3))
-    f["q"] = synthetic.quat_from_rpy(rpy[:, 0], rpy[:, 1], rpy[:, 2])
-    f["v"] = rng.uniform(-0.3 * scale, 0.3 * scale, (nb, 3))
-    f["w"] = rng.uniform(-0.5 * scale, 0.5 * scale, (nb, 3))
-    f["joint_angles"] = rng.uniform(-0.15 * scale, 0.15 * scale, (nb, 10))
-    return f
+hard_batch = synthetic.hard_batch  # (nb, h, gait, seed, scale): the off-nominal stress rows
 
 
 def ref_solve(args):
