@@ -24,12 +24,18 @@ EXPORTS = [
     "hmpc_group_gather_wrench", "hmpc_group_download", "hmpc_group_synchronize", "hmpc_group_last_error",
     "hmpc_group_create_ex", "hmpc_group_contacts", "hmpc_group_set_deal", "hmpc_group_deal", "hmpc_group_member_step",
     "hmpc_upload_records_strided_async", "hmpc_set_max_iterations", "hmpc_legacy_set_max_iterations", "hmpc_tick_solve_device", "hmpc_set_dispatch_order",
-    "hmpc_set_handover",
+    "hmpc_set_handover", "hmpc_default_params", "hmpc_set_params", "hmpc_get_params", "hmpc_legacy_set_params", "hmpc_group_set_params",
 ]
 
 
 class ProblemSetup(C.Structure):
     _fields_ = [("dt", C.c_float), ("mu", C.c_float), ("f_max", C.c_float), ("horizon", C.c_int)]
+
+
+class Params(C.Structure):
+    """include/hector_mpc.h struct hmpc_params (robot / contact constants; defaults = the reference's literals)."""
+    _fields_ = [("mass", C.c_float), ("inertia", C.c_float * 3), ("mu", C.c_float), ("lt", C.c_float), ("lh", C.c_float),
+                ("gravity", C.c_float)]
 
 
 class TickInputs(C.Structure):
@@ -111,6 +117,12 @@ def load():
     L.hmpc_resolve_failed.argtypes = [vp, C.POINTER(ci)]
     L.hmpc_set_auto_resolve.argtypes = [vp, ci]
     L.hmpc_set_handover.argtypes = [vp, ci]
+    L.hmpc_default_params.argtypes = [C.POINTER(Params)]
+    L.hmpc_default_params.restype = None
+    L.hmpc_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.hmpc_get_params.argtypes = [vp, C.POINTER(Params)]
+    L.hmpc_legacy_set_params.argtypes = [C.POINTER(Params)]
+    L.hmpc_group_set_params.argtypes = [vp, C.POINTER(Params)]
     L.hmpc_set_device_repair.argtypes = [vp, ci]
     L.hmpc_group_set_exchange_repair.argtypes = [vp, ci]
     L.hmpc_set_device_outputs.argtypes = [vp, vp, vp]

@@ -6,6 +6,7 @@
 // There is NO CPU fallback: without a gfx950 device every entry point fails (HMPC_E_NO_DEVICE) and the legacy
 // entry points print the error and leave the previous solution in place.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -44,7 +45,8 @@ thread_local std::string g_hip_err;
 const Variant *variants() {
   static const Variant v[] = {hmpc_variant_0(), hmpc_variant_1(), hmpc_variant_2(),  hmpc_variant_3(),
                               hmpc_variant_4(), hmpc_variant_5(), hmpc_variant_6(),  hmpc_variant_7(),
-                              hmpc_variant_8(), hmpc_variant_9(), hmpc_variant_10(), hmpc_variant_11()};
+                              hmpc_variant_8(), hmpc_variant_9(), hmpc_variant_10(), hmpc_variant_11(),
+                              hmpc_variant_12(), hmpc_variant_13()};
   return v;
 }
 constexpr int N_FAST = 4;       // two-contact fast variants [0, N_FAST), their safe variants N_FAST + (h > 10)
@@ -56,7 +58,11 @@ constexpr int V2_WIDE = 9;
 // workgroup; 231 KB for 240 variables -- more than a CU's LDS): the safe pass of the wide variant, and the second safe pass of
 // the three-contact one (whose LDS-resident safe variant holds 140 of 180 possible rows)
 constexpr int V2_WIDE_SAFE = 10, V3_SAFE_G = 11;
-constexpr int N_VARIANTS = 12;
+// the CONTINUATION variants of the 120-variable shapes (h <= 10, h <= 20): working set of HMPC_QCAP_CONT = 96 rows, 70 KB of LDS = two
+// workgroups per CU; they take over -- state and all -- the solves whose working set outgrew the fast variants' 64 rows, run block
+// rounds of up to 96 rows on them, and leave what outgrows them in turn (HMPC_S_WORKSET again) to the 120-row safe variants
+constexpr int V2_CONT = 12;  // + (h > 10)
+constexpr int N_VARIANTS = 14;
 constexpr int MAX_VARS_ANY = 240;
 constexpr int DBG_FLOATS_MAX = hmpc::DbgLayout<240, 2>::TOTAL > hmpc::DbgLayout<180, 3>::TOTAL
                                    ? hmpc::DbgLayout<240, 2>::TOTAL
@@ -125,6 +131,7 @@ struct hmpc_handle {
   size_t spill_stride;
   int spill_cap;
   int handover;  // hmpc_set_handover (default on)
+  hmpc_params params;  // robot / contact constants (hmpc_set_params; defaults = the reference's literals)
 };
 // longest-first dispatch (hmpc_set_dispatch_order, on by default): only where a launch has a tail to shorten -- more instances
 // than the ~512-1536 workgroup slots of the chip -- and not beyond what the one-workgroup sort handles in a few microseconds
@@ -201,6 +208,8 @@ struct LaunchOpt {
   int cls_lo = 0, cls_hi = -1;  // cls_hi >= 0: only instances whose size class lies in [cls_lo, cls_hi] (h->d_cls)
   int safe_variant = -1;   // safe pass over an index list: this entry of variants() instead of the one derived from pick_variant
   bool resume = false;     // safe pass over an index list: instances whose fast solve left its state in a hand-over slot continue from it
+  bool continuation = false;  // list launch of the CONTINUATION variant (V2_CONT): only instances with a hand-over slot, everything else on the list is left alone
+  bool skip_ok = false;    // list launch: instances an earlier pass over the same list solved are left alone
 };
 
 static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
@@ -208,7 +217,8 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   const Variant *pv = &pick_variant(h, &vi);
   if (o.variant >= 0) vi = o.variant, pv = &variants()[vi];
   if (o.d_index_list) {  // safe variant: working set as large as the variable count
-    if (o.safe_variant >= 0) vi = o.safe_variant;
+    if (o.continuation) vi = V2_CONT + (h->setup.horizon > 10 ? 1 : 0);
+    else if (o.safe_variant >= 0) vi = o.safe_variant;
     else if (vi == V2_WIDE) vi = V2_WIDE_SAFE;             // ... which for 240 variables only global memory holds
     else if (h->nc == 3) vi = o.ultimate ? V3_SAFE_G : V3_SAFE;
     else vi = (h->setup.horizon <= 10) ? N_FAST : N_FAST + 1;
@@ -294,8 +304,15 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
     a.spill_slot = h->d_spill_slot;
     if (saves) a.spill = h->d_spill, a.spill_stride = h->spill_stride, a.spill_cap = h->spill_cap;
   } else if (o.d_index_list && o.resume && v.resumes && h->handover && h->d_spill && h->d_spill_slot && o.relax == 0.0 && !h->d_ext_H) {
-    a.spill = h->d_spill, a.spill_stride = h->spill_stride, a.spill_cap = h->spill_cap, a.spill_slot = h->d_spill_slot, a.resume = 1;
+    a.spill = h->d_spill, a.spill_stride = h->spill_stride, a.spill_cap = h->spill_cap, a.spill_slot = h->d_spill_slot;
+    a.resume = o.continuation ? 2 : 1;
+  } else if (o.continuation) {
+    return HMPC_OK;  // nothing was handed over (hand-over off / no slots): the continuation pass has nothing to do
   }
+  a.skip_ok = o.skip_ok ? 1 : 0;
+  a.inv_mass = 1.0f / h->params.mass;  // (binary32 division, correctly rounded: the value the reference's 1.f / 9.f folds to for the default)
+  a.Ib[0] = h->params.inertia[0], a.Ib[1] = h->params.inertia[1], a.Ib[2] = h->params.inertia[2];
+  a.mu = h->params.mu, a.lt = h->params.lt, a.lh = h->params.lh, a.gravity = h->params.gravity;
   for (int off = 0; off < grid_all; off += chunk) {
     const int grid = (grid_all - off < chunk) ? grid_all - off : chunk;
     if (off > 0) a.index_list = o.d_index_list + off;  // (only list launches are ever chunked)
@@ -397,7 +414,18 @@ static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
   s.warm = 0;
   s.carry_wset = carry_wset;
   s.d_list_count = h->d_flag_count;
-  s.resume = true;  // instances whose working set outgrew the fast variant continue from the state it handed over
+  // (1) continuation: instances whose working set outgrew the fast variant go on, from the state it handed over, on the variant
+  //     with 96 rows and block rounds of its own (two per CU); (2) the safe variant, cold, for everything still flagged -- what
+  //     the fast variant flagged for other reasons, and what outgrew the continuation variant as well
+  if (h->nc == 2 && h->handover && h->d_spill) {
+    LaunchOpt c = s;
+    c.continuation = true, c.resume = true;
+    rc = launch(h, stream, c);
+    if (rc != HMPC_OK) return rc;
+    s.skip_ok = true;
+    static const bool cont_only = getenv("HMPC_DEBUG_CONT_ONLY") && getenv("HMPC_DEBUG_CONT_ONLY")[0] == '1';  // developer switch: what the continuation pass alone leaves
+    if (cont_only) return HMPC_OK;
+  }
   return launch_safe(h, stream, s);
 }
 
@@ -482,6 +510,7 @@ int hmpc_create_ex(hmpc_handle **out, const struct problem_setup *setup, int max
   h->warm = 1;
   h->auto_resolve = 1;
   h->handover = 1;
+  hmpc_default_params(&h->params);
   const size_t nf = (size_t)max_batch * 6 * n_contacts * setup->horizon;
   if (hipMalloc(&h->d_records_own, (size_t)max_batch * h->stride) != hipSuccess ||
       hipMalloc(&h->d_forces_own, nf * sizeof(float)) != hipSuccess ||
@@ -640,6 +669,37 @@ int hmpc_set_max_iterations(hmpc_handle *h, int max_iter) {
   return HMPC_OK;
 }
 
+void hmpc_default_params(struct hmpc_params *p) {
+  if (!p) return;
+  p->mass = 9.0f;                                                   // SolverMPC.cpp:423
+  p->inertia[0] = 0.5413f, p->inertia[1] = 0.5200f, p->inertia[2] = 0.0691f;  // RobotState.cpp:45
+  p->mu = 2.0f, p->lt = 0.09f, p->lh = 0.06f;                       // SolverMPC.cpp:488-490
+  p->gravity = 9.81f;                                               // SolverMPC.cpp:420
+}
+
+static bool params_ok(const hmpc_params &p) {
+  auto pos = [](float v) { return v > 0.0f && v < 1e30f; };
+  return pos(p.mass) && pos(p.inertia[0]) && pos(p.inertia[1]) && pos(p.inertia[2]) && pos(p.mu) && p.lt == p.lt && p.lh == p.lh &&
+         p.gravity == p.gravity && fabsf(p.lt) < 1e30f && fabsf(p.lh) < 1e30f && fabsf(p.gravity) < 1e30f;
+}
+
+int hmpc_set_params(hmpc_handle *h, const struct hmpc_params *p) {
+  if (!h) return HMPC_E_ARG;
+  if (!p) {
+    hmpc_default_params(&h->params);
+    return HMPC_OK;
+  }
+  if (!params_ok(*p)) return HMPC_E_ARG;
+  h->params = *p;
+  return HMPC_OK;
+}
+
+int hmpc_get_params(const hmpc_handle *h, struct hmpc_params *p) {
+  if (!h || !p) return HMPC_E_ARG;
+  *p = h->params;
+  return HMPC_OK;
+}
+
 int hmpc_set_handover(hmpc_handle *h, int on) {
   if (!h) return HMPC_E_ARG;
   h->handover = on ? 1 : 0;
@@ -753,9 +813,17 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
   // the safe pass starts cold, as the reference does (launch parameter; the handle's own setting is not touched)
   LaunchOpt so;
   so.d_index_list = d_idx, so.n_list = (int)idx.size(), so.warm = 0;
-  so.resume = true;  // (first pass only: a slot is consumed by the continuation, later passes start cold)
-  int rc = launch_safe(h, h->last_stream, so);
-  so.resume = false;
+  int rc = HMPC_OK;
+  if (h->nc == 2 && h->handover && h->d_spill) {
+    // continuation first (see enqueue_solve): instances with a hand-over slot go on where the fast variant stopped
+    LaunchOpt c = so;
+    c.continuation = true, c.resume = true;
+    rc = launch(h, h->last_stream, c);
+    if (rc != HMPC_OK) return rc;
+    so.skip_ok = true;
+  }
+  rc = launch_safe(h, h->last_stream, so);
+  so.skip_ok = false;
   if (rc != HMPC_OK) return rc;
   HIP_TRY(hipStreamSynchronize(h->last_stream));
   if (n_resolved) *n_resolved = (int)idx.size();
@@ -1145,6 +1213,7 @@ static int g_q_len = 0;
 static int g_has_solved = 0;
 static uint32_t g_last_status = 0;
 static int g_setup_error = 0;
+static hmpc_params g_legacy_params = {9.0f, {0.5413f, 0.5200f, 0.0691f}, 2.0f, 0.09f, 0.06f, 9.81f};  // hmpc_legacy_set_params
 static int g_legacy_iter_cap = 0;  // hmpc_legacy_set_max_iterations: explicit opt-in (update_solver_settings is inert, as in the reference)
 // one tick = one pinned staging buffer [record | 12h forces | status word] and one contiguous device output block, so that
 // a blocking tick costs one asynchronous H2D copy, one launch, one asynchronous D2H copy and a single synchronisation
@@ -1229,6 +1298,7 @@ static void solve_global(void) {
   const size_t out_bytes = sizeof(float) * 12 * hz + sizeof(uint32_t);
   uint32_t st = 0;
   hmpc_set_max_iterations(g_handle, g_legacy_iter_cap);
+  hmpc_set_params(g_handle, &g_legacy_params);
   int rc = hmpc_upload_records_async(g_handle, rec, 1, nullptr);  // pinned source: a true asynchronous copy
   if (rc == HMPC_OK) rc = hmpc_solve(g_handle, nullptr);
   if (rc == HMPC_OK && (hipMemcpyAsync(g_pin + g_pin_rec_bytes, g_dev_out, out_bytes, hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
@@ -1292,6 +1362,14 @@ void update_solver_settings(int max_iter, double rho, double sigma, double solve
   g_update.solver_alpha = solver_alpha;
   g_update.terminate = terminate;
   (void)use_jcqp;
+}
+
+int hmpc_legacy_set_params(const struct hmpc_params *p) {
+  hmpc_params d;
+  hmpc_default_params(&d);
+  if (p && !params_ok(*p)) return HMPC_E_ARG;
+  g_legacy_params = p ? *p : d;
+  return HMPC_OK;
 }
 
 int hmpc_legacy_set_max_iterations(int max_iter) {

@@ -361,6 +361,16 @@ int hmpc_group_upload_records(hmpc_group *g, const void *host_records, int batch
 // ::test_striped_deal_balances_a_skewed_batch).  Same member sizes either way.  Host-facing results (hmpc_group_gather_wrench,
 // hmpc_group_download) are in instance order in both modes; the device-resident gathered block keeps its [member][row] layout,
 // row r of slot s being instance s + r G in striped mode.  Takes effect with the next upload / set_device_records.
+int hmpc_group_set_params(hmpc_group *g, const struct hmpc_params *p) {
+  if (!g) return HMPC_E_ARG;
+  GENTER();
+  for (auto &mm : g->m) {
+    const int rc = hmpc_set_params(mm.h, p);
+    if (rc != HMPC_OK) return rc;
+  }
+  return HMPC_OK;
+}
+
 int hmpc_group_set_deal(hmpc_group *g, int deal) {
   GENTER();
   if (!g || (deal != HMPC_DEAL_CONTIGUOUS && deal != HMPC_DEAL_STRIPED)) return HMPC_E_ARG;

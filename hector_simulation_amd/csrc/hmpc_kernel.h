@@ -37,6 +37,9 @@
 #ifndef HMPC_MFMA_SWEEP_WIDE
 #define HMPC_MFMA_SWEEP_WIDE 1  // stage S on the matrix cores for the fast wide variant (240 variables, 512 threads, two blocks per thread): 15 x 15 tiles on eight waves
 #endif
+#ifndef HMPC_QCAP_CONT
+#define HMPC_QCAP_CONT 96  // working-set capacity of the continuation variant of the 120-variable shapes (70 KB of LDS: two workgroups per CU)
+#endif
 #ifndef HMPC_REFINE
 #define HMPC_REFINE 1  // corrections u += E (b_W - N_W x(u)) applied to the multipliers of the final working set
 #endif
@@ -158,7 +161,8 @@ struct Smem {
     Rec rec[NW];
     alignas(8) signed char act[MMAX];
     alignas(8) unsigned char slot[MMAX];
-    unsigned char flpc[MMAX];  // row has already been switched to its other bound once by the block start
+    unsigned char flpc[MMAX];  // bit 0: row has already been switched to its other bound once by the block start; bits 1-7 (continuation and
+                               // safe variants): how often the single-row iteration has ADDED the row (anti-cycling, HMPC_READD_LIMIT)
     typedef typename std::conditional<(MMAX > 256), unsigned short, unsigned char>::type row_t;
     row_t Wrow[NMAX];  // working-set slot -> constraint row
     double Ep[EP_LDS];  // E = (N_W M N_W')^-1, packed lower triangle: E(i,j), i>=j, at i(i+1)/2 + j (EGLOBAL: in args.e_scratch)
@@ -278,6 +282,19 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #endif
 #ifndef HMPC_BLOCK_MIN_NEW
 #define HMPC_BLOCK_MIN_NEW 3     // a further round needs at least this many newly violated rows (256-/128-thread variants; 5 until the Schur matrix went to the matrix cores: profiles/r05/block_round_ab.txt)
+#endif
+#ifndef HMPC_READD_LIMIT
+#define HMPC_READD_LIMIT 6  // continuation / safe variants: single-row additions of ONE row before it is set aside (0: off)
+#endif
+#ifndef HMPC_CONT_ITER_BUDGET
+#define HMPC_CONT_ITER_BUDGET 64  // continuation variant: iterations a resumed solve may add before it is left to the safe pass
+#endif
+#ifndef HMPC_CONT_REFRESH
+#define HMPC_CONT_REFRESH 0      // continuation variant: 1 = E rebuilt from M every 48 working-set changes, as the safe variants do (measured: no difference in
+                                 // iterations or time at 6x, and that seventh instantiation of the round costs 113 spilled registers: off)
+#endif
+#ifndef HMPC_CONT_ROUNDS
+#define HMPC_CONT_ROUNDS 4       // continuation variant: block rounds a resumed solve runs before its single-row iteration
 #endif
 #ifndef HMPC_BLOCK_MIN_NEW_3C
 #define HMPC_BLOCK_MIN_NEW_3C 2  // ... three-contact variant (its single-row iteration is dearer; 3 until round 5)
@@ -1036,14 +1053,24 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // tables, constraint normals, g: cheap and bit-identical), then take M, E and the Goldfarb-Idnani state from the slot instead of
   // running stages H, S and the start
   constexpr bool SHAPE_HANDOVER = !ASM_ONLY && NMAX == 120 && NT == 256 && NC == 2 && BPT == 1 && !SM::EGLOBAL;
-  constexpr bool SPILLS = SHAPE_HANDOVER && QCAP < NMAX;
-  constexpr bool RESUMABLE = SHAPE_HANDOVER && QCAP >= NMAX;
+  constexpr bool SPILLS = SHAPE_HANDOVER && QCAP < HMPC_QCAP_CONT;      // the fast variants (working set of 64 rows, three per CU)
+  // the continuation variant (96 rows, two per CU): takes over what the fast variants hand over, with block rounds of its own (up to
+  // its 96 rows at once, the Schur matrix as 6 x 6 tiles on the matrix cores), and flags what outgrows it in turn for the safe variant
+  constexpr bool RESUMABLE = SHAPE_HANDOVER && QCAP >= HMPC_QCAP_CONT && QCAP < NMAX;
+  constexpr bool CONT = RESUMABLE;
   using SPL = SpillLayout<SM, NT, BPT>;
   bool resumed = false;
   if constexpr (RESUMABLE) {
     // (the slot must be this instance's own and its status word must still say "working set full": both are written by the fast
     //  variant in the same solve; anything else -- a stale entry of an earlier batch -- starts cold)
     if (args.resume) resumed = ub(args.spill_slot[inst] == inst && inst < args.spill_cap && (args.status[inst] & 0xffu) == (uint32_t)S_WORKSET);
+    if (args.resume == 2 && !resumed) return;  // a continuation-only launch: everything else on the list is the safe variant's
+  }
+  if constexpr (!ASM_ONLY && (SM::EGLOBAL || (QCAP >= NMAX && NMAX >= 120))) {  // (the safe-pass variants)
+    if (args.skip_ok) {  // second pass over a list of flagged instances: what the pass before it solved is left alone
+      const uint32_t c0 = args.status[inst] & 0xffu;
+      if (c0 == (uint32_t)S_OK || c0 == (uint32_t)S_OK_RELAXED) return;
+    }
   }
 
   // ---------------- A0: one coalesced burst brings the instance's record into LDS ----------------
@@ -1162,8 +1189,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       A.x0[6 + i] = in_w[i];
       A.x0[9 + i] = in_v[i];
     }
-    A.x0[12] = 9.81f;
-    const float Ib[3] = {0.5413f, 0.5200f, 0.0691f};
+    A.x0[12] = args.gravity;                                     // 9.81f in the reference (SolverMPC.cpp:420)
+    const float Ib[3] = {args.Ib[0], args.Ib[1], args.Ib[2]};  // 0.5413, 0.5200, 0.0691 (RobotState.cpp:45)
     float RI[9], Iw[9], Iinv[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -1172,13 +1199,13 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     chain_mm<3, 3, 3>(RI, Rt, Iw);
     inverse3(Iw, Iinv);
 
-    // continuous model -> forward Euler (SolverMPC.cpp:312-331, 145-146); mass 9.0 (:423)
+    // continuous model -> forward Euler (SolverMPC.cpp:312-331, 145-146); mass: hmpc_params (9.0 at :423)
     const float dt = args.dt;
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) A.Acd[i * 13 + 6 + j] = 0.0f + dt * Rbi[i * 3 + j];
     for (int i = 0; i < 3; ++i) A.Acd[(3 + i) * 13 + 9 + i] = 0.0f + dt * 1.0f;
     A.Acd[11 * 13 + 12] = 0.0f + dt * -1.0f;
-    const float inv_m = 1.0f / 9.0f;
+    const float inv_m = args.inv_mass;  // fl(1.0f / mass), mass = 9.0 in the reference (SolverMPC.cpp:423)
     for (int leg = 0; leg < NC; ++leg) {
       const float r0 = in_r[0 * NC + leg], r1 = in_r[1 * NC + leg], r2 = in_r[2 * NC + leg];
       float cm[9] = {0.0f, -r2, r1, r2, 0.0f, -r0, -r1, r0, 0.0f};
@@ -1202,7 +1229,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       const int leg = (tid == leg_lane0) ? 0 : (tid == leg_lane1 ? 1 : 2);
       float R[9], Rt[9];
       quat_to_R(in_q, R, Rt);
-      const float mu = 2.0f, lt = 0.09f, lh = 0.06f;
+      const float mu = args.mu, lt = args.lt, lh = args.lh;  // 2.0, 0.09, 0.06 in the reference (SolverMPC.cpp:488-490)
       const int b = (leg < 2) ? 5 * leg : 0;
       const float s0 = A.sc[b][0], c0 = A.sc[b][1], s1 = A.sc[b + 1][0], c1 = A.sc[b + 1][1];
       const float s2 = A.sc[b + 2][0], c2 = A.sc[b + 2][1], s3 = A.sc[b + 3][0], c3 = A.sc[b + 3][1];
@@ -2157,6 +2184,12 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   const int v_leg_r = (!LAZY_IDX && is_v) ? S.ls_leg[v_e] : 0;
   auto var_leg = [&]() __attribute__((always_inline)) -> int { if constexpr (!LAZY_IDX) return v_leg_r; else return (tid < n) ? (int)S.ls_leg[v_e] : 0; };
   int q = 0, iters = 0, code = S_OK;
+#ifdef HMPC_DEBUG_STATS  // developer build (scripts/dev/cont_probe.py): what happened inside a solve, packed into obj64
+  int dbg_bad = 0, dbg_rounds = 0, dbg_norounds_cap = 0, dbg_norounds_few = 0, dbg_dep = 0;
+#define HMPC_DBG(x) x
+#else
+#define HMPC_DBG(x)
+#endif
   if (RESUMABLE && resumed) {
     if constexpr (RESUMABLE) {
       // ---- hand-over: the Goldfarb-Idnani state the fast variant stopped in (x minimises over the working set, u >= 0, E current)
@@ -2192,8 +2225,25 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // ... and of those, the variants hmpc_resolve_failed / the device-side repair launch (always cold): the only ones that ever run
   // for hundreds of iterations (the 60-variable fast variants also have QCAP = NMAX, but are fast variants)
   constexpr bool LONGRUN = SM::EGLOBAL || (QCAP >= NMAX && NMAX >= 120);
+  // Anti-cycling (the variants that run the hard instances: continuation and safe).  At a degenerate vertex -- several rows
+  // active with zero multipliers -- round-off can make the dual iteration drop and re-add the same rows with zero-length steps
+  // until the iteration bound (seen: 600 iterations on the continuation variant, 1 664 on the safe one, each the whole tail of
+  // its launch).  In exact arithmetic a row is added at most 3 times per solve in all but the genuinely cycling instances
+  // (scripts/dev/emulate_rounds.py, 6x and 10x the input ranges), so a row the single-row iteration has already added
+  // HMPC_READD_LIMIT times is set aside like a redundant row: the final KKT check looks at every row again and decides.
+  constexpr bool ANTICYCLE = (LONGRUN || CONT) && HMPC_READD_LIMIT > 0;
   const int itmax_v = (SAFE || QCAP >= 140) ? 10 * m + 64 : 4 * m + 16;  // the safe variants may take as long as a cold qpOASES run (nWSR up to ~330 seen)
-  const int itmax = (args.iter_cap > 0 && args.iter_cap < itmax_v) ? args.iter_cap : itmax_v;
+  int itmax = (args.iter_cap > 0 && args.iter_cap < itmax_v) ? args.iter_cap : itmax_v;
+  bool budgeted = false, budget_hit = false;  // (continuation variant only)
+  if constexpr (CONT) {
+    // a resumed solve gets a budget of its own: in exact arithmetic the hardest instances need ~50 more changes from the hand-over
+    // (scripts/dev/emulate_rounds.py); one that is still going after HMPC_CONT_ITER_BUDGET is cycling at a degenerate vertex -- the
+    // safe pass's business (rebuilt E, relaxed bounds), not worth 600 iterations at the tail of this launch.  Such an instance usually
+    // SITS at its optimum and trades rows over violations of 1e-9, round-off: when the budget runs out between two iterations the
+    // multipliers are refined once and the final KKT check -- every row, relative to the force scale, the standard every solve is
+    // held to -- decides between ok and flagged
+    if (resumed && iters + HMPC_CONT_ITER_BUDGET < itmax) itmax = iters + HMPC_CONT_ITER_BUDGET, budgeted = true;
+  }
   bool c_ignored = false;  // this thread's row was found redundant at a degenerate vertex (violated by round-off only)
 
   // slack of this thread's constraint row on its tighter side at xv (unit-scaled); side = +1 lower, -1 upper
@@ -2350,13 +2400,14 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     // third copy of the phase tips the register allocation of the 168-VGPR variant over: 86 spilled registers, 1.43 -> 1.78 ms);
     // three contacts: three (1.13 -> 1.18 M solves/s over two)
     constexpr int BLOCK_ROUNDS = (NC == 3) ? HMPC_BLOCK_ROUNDS_3C : ((NT >= 256) ? HMPC_BLOCK_ROUNDS : 1);
+    constexpr int CONT_ROUNDS = HMPC_CONT_ROUNDS;  // block rounds of a resumed solve (the continuation variant: 256 VGPRs, a loop fits)
     constexpr bool BLOCK_FRICTION = HMPC_BLOCK_FRICTION && NT >= 256;
     constexpr int BLOCK_MIN_NEW = (NC == 3) ? HMPC_BLOCK_MIN_NEW_3C : HMPC_BLOCK_MIN_NEW;
     constexpr int EPT = (NC == 3 && NT < 512) ? HMPC_EPT_3C : 5;  // packed-triangle entries per thread during the Schur inversion
     constexpr int KBMAX_3C = (HMPC_EPT_3C >= 8) ? 63 : ((HMPC_EPT_3C == 7) ? 59 : 54);
     // Schur matrix of the fast variants on the matrix cores (schur_invert): 3 x 3 tiles = 48 rows for the 120-variable variants,
     // 4 x 4 = 64 rows with three contacts, 5 x 5 = 80 rows for the wide variant (eight waves)
-    constexpr int NTGS = (NT >= 512) ? 5 : (NC == 3 ? 4 : 3);
+    constexpr int NTGS = (NT >= 512) ? 5 : (NC == 3 ? 4 : (CONT ? 6 : 3));  // (continuation variant: 6 x 6 tiles = its 96 rows)
     constexpr bool SCHUR_MFMA = HMPC_SCHUR_MFMA && !LONGRUN && (NT >= 256 || HMPC_SCHUR_MFMA_128) && SM::QMAX >= 16 * NTGS &&
                                 (NC == 2 || HMPC_SCHUR_MFMA_3C) && (NT < 512 || HMPC_SCHUR_MFMA_WIDE);
     constexpr int KBMAX = SCHUR_MFMA ? 16 * NTGS
@@ -2380,7 +2431,24 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         fresh = viol && !partner;
         take = (ac != 0) || fresh;
       }
+      if constexpr (CONT) {
+        // One more independence rule, needed once the Fz cap (row 7) can be in the working set (it enters through single-row
+        // iterations only, i.e. never before the fast variants' rounds, but before the continuation variant's): the moment parts
+        // of the toe and heel rows 5 and 6 are parallel (+-t1), so their difference is a pure force row, and together with three
+        // more pure force rows of the leg-step (one friction row per axis + the cap) the six rows have rank 5.  When the set a
+        // round is about to take has that shape in a leg-step, one FRESH row of it stays out: the highest fresh friction row,
+        // else the fresh one of rows 6 / 5 (the rows already in the working set are independent by construction).
+        const unsigned long long tb = __ballot(take), fb = __ballot(fresh);
+        const int sh = ln & ~7;  // rows 8e .. 8e+7 sit in eight consecutive lanes of one wave
+        const unsigned t8 = (unsigned)(tb >> sh) & 0xffu, f8 = (unsigned)(fb >> sh) & 0xffu;
+        if (__popc(t8 & 0x8fu) == 3 && (t8 & 0x60u) == 0x60u) {
+          const unsigned ff = f8 & 0x0fu;
+          const int victim = ff ? 31 - __clz((int)ff) : ((f8 & 0x40u) ? 6 : 5);
+          if ((tid & 7) == victim && fresh) fresh = false, take = false;
+        }
+      }
       count_candidates();
+      HMPC_DBG(if (k0 > (LONGRUN ? SM::QMAX : KBMAX)) ++dbg_norounds_cap; else if (!refresh && k0 - q < BLOCK_MIN_NEW) ++dbg_norounds_few;)
       if (ub((!refresh && k0 - q < BLOCK_MIN_NEW) || k0 > (LONGRUN ? SM::QMAX : KBMAX))) return false;  // not worth a round / does not fit: the iteration below goes on
       // (no barrier here: what follows writes act / slot / Wrow entries that nobody reads before the barrier behind the slot deal,
       //  and wcount is not written again before the release loop, several barriers on)
@@ -2634,6 +2702,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       }
       q = k0;
       PROF_MARK(P_B_INV);
+      HMPC_DBG(++dbg_rounds; if (bad_start) ++dbg_bad;)
       if (ub(bad_start)) {
         // only possible for a working set inherited from the previous tick whose rows have become (nearly) dependent
         // under this tick's data: forget it and start from the empty set
@@ -2667,7 +2736,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         bool cand = false;
         if (tid < q && um < -1e-12) {
           const int c = Q.Wrow[tid];
-          cand = HMPC_FLIP4 && ((c & 7) == 4) && Q.flpc[c] == 0;
+          cand = HMPC_FLIP4 && ((c & 7) == 4) && (ANTICYCLE ? (Q.flpc[c] & 1) == 0 : Q.flpc[c] == 0);
         }
         const double wmin = wave_min(um);
         const unsigned long long b2 = __ballot(um == wmin);
@@ -2694,7 +2763,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
           if (cand) {
             const int c = Q.Wrow[tid];
             Q.act[c] = (signed char)(-Q.act[c]);
-            Q.flpc[c] = 1;
+            Q.flpc[c] = ANTICYCLE ? (unsigned char)(Q.flpc[c] | 1) : (unsigned char)1;
           }
           __syncthreads();
           {
@@ -2736,8 +2805,27 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     }
     return !ub(k0 == 0 || q == 0);  // (nothing to build on otherwise)
     };  // block_round
+  if constexpr (CONT) {
+    // a resumed solve: the state handed over is a Goldfarb-Idnani state, so further ROUNDS apply as they stand -- the working set
+    // plus every row violated at the point reached, all at once, up to this variant's capacity
+    if (resumed) {
+      // (instantiated one by one: written as a loop the phase keeps ~100 more registers alive -- 104 spilled at the 256 this variant has)
+      bool more = true;
+      if constexpr (CONT_ROUNDS > 0) more = block_round(1, false);
+      if constexpr (CONT_ROUNDS > 1) {
+        if (more) more = block_round(2, false);
+      }
+      if constexpr (CONT_ROUNDS > 2) {
+        if (more) more = block_round(3, false);
+      }
+      if constexpr (CONT_ROUNDS > 3) {
+        if (more) more = block_round(4, false);
+      }
+      static_assert(CONT_ROUNDS >= 0 && CONT_ROUNDS <= 4, "rounds are instantiated one by one");
+    }
+  }
   if constexpr (!LONGRUN)  // (the safe-pass variants are only ever launched cold: the opening rounds are not even compiled for them)
-  if (args.warm) {
+  if (args.warm && !(RESUMABLE && resumed)) {
     bool more = block_round(0, false);
     if constexpr (BLOCK_ROUNDS > 1) {
       if (more) more = block_round(1, false);
@@ -2757,12 +2845,15 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // current working set (a block round in refresh mode: S0 formed block-locally, inverted from scratch, multipliers and
   // point recomputed, rows whose multiplier comes out negative released).  The fast variants never run long enough to need it.
   constexpr int REFRESH_EVERY = 48, REFRESH_FINAL = 12;
+  // (the continuation variant runs the hard instances -- dozens to hundreds of further working-set changes on top of the fast
+  //  variant's -- and rebuilds E periodically as well: on the matrix cores, a refresh costs about four single-row iterations)
+  constexpr bool REFRESHES = LONGRUN || (CONT && HMPC_CONT_REFRESH);
   int since_refresh = 0;
   for (int pass = 0; pass < 3 && code == S_OK; ++pass) {
     const int iters_at_entry = uni(iters);  // (uniform: a scalar register)
     // ---- main loop ----
     while (true) {
-      if constexpr (LONGRUN) {
+      if constexpr (REFRESHES) {
         if (ub(since_refresh >= REFRESH_EVERY && q > 0)) {
           __syncthreads();
           (void)block_round(3, true);
@@ -2772,7 +2863,11 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       // (1) most violated constraint; the winning lane of each wave also publishes its constants
       double val = INF, raw = INF;
       int side = 1;
-      if (is_c && !c_ignored && Q.act[tid] == 0) val = my_slack(Q.x, side, raw);
+      if constexpr (ANTICYCLE) {
+        if (is_c && !c_ignored && Q.act[tid] == 0 && (Q.flpc[tid] >> 1) < HMPC_READD_LIMIT) val = my_slack(Q.x, side, raw);
+      } else {
+        if (is_c && !c_ignored && Q.act[tid] == 0) val = my_slack(Q.x, side, raw);
+      }
       PROF_MARK(P_T1);
       {
         const double wmin = wave_min(val);
@@ -2801,6 +2896,12 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       PROF_MARK(P_SEL);
       if (ub(!(pval < -FEAS_TOL))) break;
       if (iters >= itmax) {
+        if constexpr (CONT) {
+          if (budgeted) {  // (uniform)
+            budget_hit = true;
+            break;
+          }
+        }
         code = S_MAXITER;
         break;
       }
@@ -2915,6 +3016,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
           // redundant row violated by accumulated round-off.  The row is set aside and the iteration goes on; the final
           // KKT check (which looks at every row again, relative to the force scale) decides the status.
           if (tid == p) c_ignored = true;
+          HMPC_DBG(++dbg_dep;)
           break;
         }
         if (!dep && is_v) Q.x[tid] = dfma(t, Q.z[tid], Q.x[tid]);
@@ -2947,6 +3049,10 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
             Q.Wrow[q] = (typename SM::Sol::row_t)p;
             Q.act[p] = (signed char)sgi;
             Q.slot[p] = (unsigned char)q;
+            if constexpr (ANTICYCLE) {
+              const unsigned fc = Q.flpc[p];
+              if ((fc >> 1) < 127u) Q.flpc[p] = (unsigned char)(fc + 2u);
+            }
           }
           ++q;
           added = true;
@@ -2954,7 +3060,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         } else {
           drop_slot(l);  // partial (or pure dual) step: slot l leaves
         }
-        if constexpr (LONGRUN) ++since_refresh;
+        if constexpr (REFRESHES) ++since_refresh;
         PROF_MARK(P_UPD);
       }
       if (code != S_OK) break;
@@ -2962,7 +3068,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     if (code != S_OK || q == 0) break;
     // nothing happened in this pass: either the refined point of the previous pass is feasible, or (first pass) the block
     // start already is the optimum -- its x, u, E come straight from the inversion, there is nothing to refine
-    if (iters == iters_at_entry) break;
+    if (iters == iters_at_entry && !(CONT && budget_hit)) break;
     if constexpr (LONGRUN) {
       if (ub(since_refresh >= REFRESH_FINAL)) {  // the answer is read off a freshly built E; the loop above then confirms it
         __syncthreads();
@@ -2993,6 +3099,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       __syncthreads();
     }
     PROF_MARK(P_POLISH);
+    if constexpr (CONT) {
+      if (budget_hit) break;  // (no further pass: the KKT check below decides)
+    }
     // a refinement that moved x across another constraint sends us back into the main loop (rare)
   }
 
@@ -3141,6 +3250,10 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         if ((int)k < args.flag_cap) args.flag_list[k] = inst;
       }
     }
+#ifdef HMPC_DEBUG_STATS
+    if (args.obj64) args.obj64[inst] = (double)(dbg_bad + 10 * dbg_rounds + 1000 * dbg_norounds_cap + 10000 * dbg_norounds_few + 100000 * dbg_dep);
+    if (false)
+#endif
     if (args.obj64) {
       // objective through the KKT identity  0.5 x'Hx + g'x = 0.5 g'x + 0.5 u'b_W  (H itself was consumed by the sweeps)
       double o = 0.0;

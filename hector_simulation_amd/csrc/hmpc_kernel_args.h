@@ -76,7 +76,11 @@ struct KernelArgs {
   size_t spill_stride;
   int spill_cap;
   int *spill_slot;  // [batch]
-  int resume;       // continuation launch: instances with spill_slot[inst] >= 0 resume from their slot
+  // robot / contact constants (struct hmpc_params; defaults = the reference's literals): 1 / mass as the host's binary32 quotient
+  // (what the compiler folds 1.0f / 9.0f to), body inertia diagonal, friction coefficient, toe / heel lever arms, gravity state
+  float inv_mass, Ib[3], mu, lt, lh, gravity;
+  int resume;       // continuation launch: 1 = instances with a valid slot resume from it, the others start cold; 2 = ... the others are left alone
+  int skip_ok;      // list launch: instances whose status word says ok (an earlier pass over the same list solved them) are left alone
 };
 constexpr int NPROF = 32;
 enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A, P_A0, P_A1, P_A2, P_G };

@@ -8,6 +8,9 @@
 #ifndef HMPC_QCAP_FAST
 #define HMPC_QCAP_FAST 64  // working-set capacity of the fast 120-variable h <= 10 variant (49 KB LDS: three per CU)
 #endif
+#ifndef HMPC_QCAP_CONT
+#define HMPC_QCAP_CONT 96  // ... of the CONTINUATION variant of the 120-variable shapes (70 KB LDS: two per CU): takes over the solves whose working set outgrew the fast variant's
+#endif
 #ifndef HMPC_QCAP_WIDE
 #define HMPC_QCAP_WIDE 152 // ... of the 240-variable variant (double support over h = 11 .. 20)
 #endif
@@ -42,7 +45,9 @@ struct Variant {
   X(8, 2, 180, 10, 512, 100, 3, 1)                     \
   X(9, 3, 240, 20, 512, HMPC_QCAP_WIDE, 2, 2)          \
   X(10, 3, 240, 20, 512, 0, 2, 2)                      \
-  X(11, 2, 180, 10, 512, 0, 3, 1)
+  X(11, 2, 180, 10, 512, 0, 3, 1)                      \
+  X(12, 0, 120, 10, 256, HMPC_QCAP_CONT, 2, 1)         \
+  X(13, 1, 120, 20, 256, HMPC_QCAP_CONT, 2, 1)
 constexpr int HMPC_VARIANT_GROUPS = 4;
 
 #define HMPC_DECLARE_VARIANT(IDX, GRP, NMAX, HMAX, NT, QCAP, NC, BPT) Variant hmpc_variant_##IDX();

@@ -18,10 +18,11 @@ Variant make_variant() {
   using SM = hmpc::Smem<NMAX, HMAX, NT, QCAP, NC, BPT>;
   // (the same shape test as SHAPE_HANDOVER / SPILLS / RESUMABLE in hmpc_kernel.h)
   constexpr bool handover = NMAX == 120 && NT == 256 && NC == 2 && BPT == 1 && QCAP != 0;
+  static_assert(!handover || QCAP == HMPC_QCAP_FAST || QCAP >= HMPC_QCAP_CONT, "hand-over: the fast variants save, capacities from HMPC_QCAP_CONT on resume");
   return Variant{NMAX, HMAX, NT, QCAP, NC, hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, false, NC, BPT>,
                  hmpc::hmpc_kernel<NMAX, HMAX, NT, QCAP, true, NC, BPT>, sizeof(SM),
                  hmpc::DbgLayout<NMAX, NC>::TOTAL,
-                 (handover && QCAP < NMAX) ? hmpc::SpillLayout<SM, NT, BPT>::stride_for(QCAP) : 0, handover && QCAP >= NMAX};
+                 (handover && QCAP < HMPC_QCAP_CONT) ? hmpc::SpillLayout<SM, NT, BPT>::stride_for(QCAP) : 0, handover && QCAP >= HMPC_QCAP_CONT && QCAP < NMAX};
 }
 }  // namespace
 

@@ -139,6 +139,31 @@ class BatchedMPC:
     def set_auto_resolve(self, on: bool) -> None:
         _check(self.L.hmpc_set_auto_resolve(self.h, 1 if on else 0), "hmpc_set_auto_resolve")
 
+    def set_params(self, mass=None, inertia=None, mu=None, lt=None, lh=None, gravity=None) -> None:
+        """Robot / contact constants (include/hector_mpc.h struct hmpc_params); arguments left out keep the reference's literals
+        (mass 9.0, inertia diag (0.5413, 0.5200, 0.0691), mu 2.0, lt 0.09, lh 0.06, gravity 9.81); no arguments = all defaults."""
+        p = _lib.Params()
+        self.L.hmpc_default_params(C.byref(p))
+        if mass is not None:
+            p.mass = np.float32(mass)
+        if inertia is not None:
+            p.inertia[:] = [np.float32(v) for v in inertia]
+        if mu is not None:
+            p.mu = np.float32(mu)
+        if lt is not None:
+            p.lt = np.float32(lt)
+        if lh is not None:
+            p.lh = np.float32(lh)
+        if gravity is not None:
+            p.gravity = np.float32(gravity)
+        _check(self.L.hmpc_set_params(self.h, C.byref(p)), "hmpc_set_params")
+
+    def get_params(self) -> dict:
+        p = _lib.Params()
+        _check(self.L.hmpc_get_params(self.h, C.byref(p)), "hmpc_get_params")
+        return dict(mass=float(p.mass), inertia=[float(v) for v in p.inertia], mu=float(p.mu), lt=float(p.lt), lh=float(p.lh),
+                    gravity=float(p.gravity))
+
     def set_handover(self, on: bool) -> None:
         """Continue (default) or re-solve cold the instances whose working set outgrew the fast variant (hmpc_set_handover)."""
         _check(self.L.hmpc_set_handover(self.h, 1 if on else 0), "hmpc_set_handover")

@@ -119,6 +119,25 @@ int hmpc_pack_record(void *record, int horizon, const double *p, const double *v
 
 int hmpc_create(hmpc_handle **out, const struct problem_setup *setup, int max_batch, int device);
 
+/* Robot and contact constants of the formulation.  The reference hard-codes every one of them in its solver source (and ignores
+ * problem_setup.mu): a payload, friction or foot-geometry sweep needs a recompile there.  Here they are data of the handle; the
+ * defaults are the reference's literals, and a handle that was never given anything else assembles bit for bit the QP it
+ * assembled before the struct existed (tests/test_gpu_assembly.py).  The CPU oracle takes the same struct (orc_set_params), so
+ * non-default values are checked bitwise as well. */
+struct hmpc_params {
+  float mass;       /* 9.0                      SolverMPC.cpp:423  (B_ct: v' += F / mass) */
+  float inertia[3]; /* 0.5413, 0.5200, 0.0691   RobotState.cpp:45  (body inertia, diagonal) */
+  float mu;         /* 2.0                      SolverMPC.cpp:488  (friction pyramid rows 0-3; problem_setup.mu is ignored, as in the reference) */
+  float lt, lh;     /* 0.09, 0.06               SolverMPC.cpp:489-490 (toe / heel lever arms of the line-contact rows 5, 6) */
+  float gravity;    /* 9.81                     SolverMPC.cpp:420  (the constant 13th state) */
+};
+void hmpc_default_params(struct hmpc_params *p);
+/* takes effect with the next solve of the handle; p == NULL restores the defaults.  mass, inertia, mu > 0 and finite, else HMPC_E_ARG */
+int hmpc_set_params(hmpc_handle *h, const struct hmpc_params *p);
+int hmpc_get_params(const hmpc_handle *h, struct hmpc_params *p);
+/* ... for the process-global solver behind the reference interface (applies from the next setup_problem / solve on) */
+int hmpc_legacy_set_params(const struct hmpc_params *p);
+
 /* ---- extension beyond the reference: a third (hand) contact per horizon step -- BASELINE.json config 5, the
  * loco-manipulation shape 180 variables x 240 rows at h = 10.  The reference has no code for it;
  * the formulation is the reference's own with one more contact: B_ct gains the hand's force / moment columns
@@ -366,6 +385,8 @@ int hmpc_group_upload_records(hmpc_group *g, const void *host_records, int batch
  * answers agree with the 120-variable one's to solver precision); member sizes are the same either way; in striped mode row r of slot s
  * of the device-resident gathered block is instance s + r G, and hmpc_group_member_step returns G (1 for contiguous slices). */
 int hmpc_group_set_deal(hmpc_group *g, int deal);
+/* the same robot / contact constants on every member (hmpc_set_params) */
+int hmpc_group_set_params(hmpc_group *g, const struct hmpc_params *p);
 int hmpc_group_deal(const hmpc_group *g);
 int hmpc_group_member_step(const hmpc_group *g, int member);
 /* device_records[i] = member i's first record, resident on member i's device (slice sizes from hmpc_shard_bounds) */

@@ -253,6 +253,14 @@ static void foot_rotation(const float q[5], float Rf[9]) {
 static int g_dense_chain = 0;
 void orc_set_dense_chain(int on) { g_dense_chain = on; }
 
+/* Robot / contact constants: the reference's literals (SolverMPC.cpp:420, 423, 488-490; RobotState.cpp:45) unless a test sets
+ * others -- the same struct the product takes (include/hector_mpc.h struct hmpc_params), so that non-default values are checked
+ * bitwise as well.  Process-global like the study switches above; NULL restores the defaults. */
+static const orc_params_t ORC_DEFAULT_PARAMS = {9.0f, {0.5413f, 0.5200f, 0.0691f}, 2.0f, 0.09f, 0.06f, 9.81f};
+static orc_params_t g_params = {9.0f, {0.5413f, 0.5200f, 0.0691f}, 2.0f, 0.09f, 0.06f, 9.81f};
+void orc_set_params(const orc_params_t *p) { g_params = p ? *p : ORC_DEFAULT_PARAMS; }
+void orc_get_params(orc_params_t *p) { *p = g_params; }
+
 ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_qp_t *o) {
   const int h = st->horizon;
   o->horizon = h;
@@ -332,8 +340,8 @@ ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_q
     x0[6 + i] = u->w[i];
     x0[9 + i] = u->v[i];
   }
-  x0[12] = 9.81f;
-  const float Ib[3] = {0.5413f, 0.5200f, 0.0691f};
+  x0[12] = g_params.gravity;                                                       /* 9.81f (SolverMPC.cpp:420) */
+  const float Ib[3] = {g_params.inertia[0], g_params.inertia[1], g_params.inertia[2]}; /* 0.5413, 0.5200, 0.0691 (RobotState.cpp:45) */
   float RI[9], Rt[9], Iw[9], Iinv[9];
   for (int i = 0; i < 3; ++i)
     for (int k = 0; k < 3; ++k) {
@@ -351,7 +359,7 @@ ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_q
     for (int j = 0; j < 3; ++j) Act[i * 13 + 6 + j] = Rbi[i * 3 + j];
   for (int i = 0; i < 3; ++i) Act[(3 + i) * 13 + 9 + i] = 1.0f;
   Act[11 * 13 + 12] = -1.0f;
-  const float inv_m = 1.0f / 9.0f;
+  const float inv_m = 1.0f / g_params.mass; /* mass 9.0 (SolverMPC.cpp:423) */
   for (int leg = 0; leg < nc; ++leg) {
     float r0 = u->r[0 * nc + leg], r1 = u->r[1 * nc + leg], r2 = u->r[2 * nc + leg];
     float cm[9] = {0.0f, -r2, r1, r2, 0.0f, -r0, -r1, r0, 0.0f};
@@ -438,7 +446,7 @@ ORC_CLONES void orc_assemble(const orc_update_t *u, const orc_setup_t *st, orc_q
   foot_rotation(qj, o->Rfoot[0]);
   foot_rotation(qj + 5, o->Rfoot[1]);
   if (nc == 3) memcpy(o->Rfoot[2], u->Rhand, sizeof(float) * 9); /* extension: the hand contact frame is an input */
-  const float mu = 2.0f, lt = 0.09f, lh = 0.06f;
+  const float mu = g_params.mu, lt = g_params.lt, lh = g_params.lh; /* 2.0, 0.09, 0.06 (SolverMPC.cpp:488-490) */
   float *Fc = o->Fc;
   memset(Fc, 0, sizeof(float) * C8 * U);
   for (int leg = 0; leg < nc; ++leg) {

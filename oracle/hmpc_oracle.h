@@ -113,6 +113,12 @@ void orc_update_problem_data(double *p, double *v, double *q, double *w, double 
                              double *weights, double *state_trajectory, double *Alpha_K, int *gait);
 double orc_get_solution(int index);
 
+/* robot / contact constants, laid out as include/hector_mpc.h struct hmpc_params (defaults = the reference's literals) */
+typedef struct {
+  float mass, inertia[3], mu, lt, lh, gravity;
+} orc_params_t;
+void orc_set_params(const orc_params_t *p); /* NULL: defaults */
+void orc_get_params(orc_params_t *p);
 void orc_set_dense_chain(int on); /* 1: run every cost chain over all 13h rows (test of zero-block neutrality) */
 void orc_set_unfused_chain(int on); /* study switch, see hmpc_oracle.c */
 void orc_set_libm_trig(int on);     /* study switch, see hmpc_oracle.c */

@@ -50,6 +50,12 @@ class Red(C.Structure):
                 ("lb", C.POINTER(C.c_double)), ("ub", C.POINTER(C.c_double))]
 
 
+class Params(C.Structure):
+    """orc_params_t == include/hector_mpc.h struct hmpc_params"""
+    _fields_ = [("mass", C.c_float), ("inertia", C.c_float * 3), ("mu", C.c_float), ("lt", C.c_float), ("lh", C.c_float),
+                ("gravity", C.c_float)]
+
+
 class Tick(C.Structure):
     _fields_ = [("position", C.c_double * 3), ("vWorld", C.c_double * 3), ("omegaWorld", C.c_double * 3),
                 ("orientation", C.c_double * 4), ("rpy", C.c_double * 3), ("rBody", C.c_double * 9),
@@ -82,6 +88,8 @@ def lib():
         L.orc_asin.restype = C.c_double
         L.orc_asin.argtypes = [C.c_double]
         L.orc_set_dense_chain.argtypes = [C.c_int]
+        L.orc_set_params.argtypes = [C.POINTER(Params)]
+        L.orc_get_params.argtypes = [C.POINTER(Params)]
         L.orc_setup_problem.argtypes = [C.c_double, C.c_int, C.c_double, C.c_double]
         L.orc_update_problem_data.argtypes = [C.c_void_p] * 6 + [C.c_double] + [C.c_void_p] * 4
         L.orc_get_solution.restype = C.c_double
@@ -111,6 +119,30 @@ def lib():
 def _np(ptr, shape, dtype):
     n = int(np.prod(shape))
     return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype).reshape(shape).copy()
+
+
+def set_params(mass=None, inertia=None, mu=None, lt=None, lh=None, gravity=None) -> None:
+    """Robot / contact constants of the oracle (process-global); no arguments = the reference's literals."""
+    L = lib()
+    if all(v is None for v in (mass, inertia, mu, lt, lh, gravity)):
+        L.orc_set_params(None)
+        return
+    p = Params()
+    L.orc_set_params(None)
+    L.orc_get_params(C.byref(p))
+    if mass is not None:
+        p.mass = np.float32(mass)
+    if inertia is not None:
+        p.inertia[:] = [np.float32(v) for v in inertia]
+    if mu is not None:
+        p.mu = np.float32(mu)
+    if lt is not None:
+        p.lt = np.float32(lt)
+    if lh is not None:
+        p.lh = np.float32(lh)
+    if gravity is not None:
+        p.gravity = np.float32(gravity)
+    L.orc_set_params(C.byref(p))
 
 
 def update_from_record(rec_row: np.ndarray, horizon: int, nc: int = 2) -> Update:

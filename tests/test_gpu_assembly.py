@@ -49,3 +49,75 @@ def test_assembly_nominal_standing(oracle):
     o = oracle.assemble_record(rec[0], 10, synthetic.DT_MPC, synthetic.F_MAX)
     assert d["n"] == 120 and d["m"] == 160
     np.testing.assert_array_equal(d["H"].view(np.uint32), o["H_red"].astype(np.float32).view(np.uint32))
+
+
+# robot / contact constants as data (include/hector_mpc.h struct hmpc_params): a payload of +35 % with a
+# heavier, differently shaped torso on a slippery floor with short feet; and a light robot on a high-friction floor with long feet
+PARAM_SETS = [dict(mass=12.2, inertia=(0.71, 0.64, 0.093), mu=0.6, lt=0.07, lh=0.045, gravity=9.81),
+              dict(mass=6.5, inertia=(0.33, 0.41, 0.052), mu=3.5, lt=0.12, lh=0.08, gravity=9.78)]
+
+
+@pytest.mark.parametrize("pset", [0, 1])
+@pytest.mark.parametrize("gait,h,seed", [("standing", 10, 6), ("walking", 10, 2), ("single", 20, 4), ("standing", 20, 19)])
+def test_assembly_bitwise_with_non_default_params(oracle, gait, h, seed, pset):
+    """The same bit-exactness with NON-default robot constants on both sides (hmpc_set_params / orc_set_params take the same
+    struct): mass, body inertia, friction coefficient, toe / heel lever arms are data, not literals."""
+    nb = 4
+    prm = PARAM_SETS[pset]
+    f = synthetic.make_batch(nb, h, gait, seed=seed, phase="random", yaw_rate_cmd=True)
+    rec = records.pack_records(f, h)
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb)
+    mpc.set_params(**prm)
+    got = mpc.get_params()
+    assert abs(got["mass"] - prm["mass"]) < 1e-6 and abs(got["mu"] - prm["mu"]) < 1e-6
+    mpc.upload(rec)
+    try:
+        oracle.set_params(**prm)
+        differs = False
+        for k in range(nb):
+            o = oracle.assemble_record(rec[k], h, synthetic.DT_MPC, synthetic.F_MAX)
+            d = mpc.debug_assemble(k)
+            assert d["n"] == o["n"] and d["m"] == o["m"]
+            for name in ("x0", "Acd", "Bcd", "Fc"):
+                np.testing.assert_array_equal(d[name].view(np.uint32), o[name].view(np.uint32), err_msg=name)
+            np.testing.assert_array_equal(d["g"].view(np.uint32), o["g_red"].astype(np.float32).view(np.uint32), err_msg="g")
+            np.testing.assert_array_equal(d["H"].view(np.uint32), o["H_red"].astype(np.float32).view(np.uint32), err_msg="H")
+            oracle.set_params()
+            o0 = oracle.assemble_record(rec[k], h, synthetic.DT_MPC, synthetic.F_MAX)
+            oracle.set_params(**prm)
+            differs = differs or not np.array_equal(o0["H_red"], o["H_red"])
+        assert differs  # (the parameters really reach the QP)
+        # ... and the solve on that data agrees with qpOASES on the oracle's (bit-identical) QP
+        mpc.solve()
+        forces, status = mpc.download()
+        ref = oracle.solve_records(rec, h, synthetic.DT_MPC, synthetic.F_MAX)
+        q = ref["q_soln"]
+        err = np.abs(forces - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+        assert (interface.status_code(status) == 0).all() and ref["n_bad"] == 0 and err.max() < 1e-4, err.max()  # tolerance: north_star's 1e-4
+    finally:
+        oracle.set_params()
+        mpc.close()
+
+
+def test_default_params_are_the_reference_literals_bit_for_bit(oracle):
+    """A handle that is handed the default struct explicitly, one that never heard of it, and one that was set to other values
+    and back assemble the same bits (the goldens of tests/golden were generated before the struct existed)."""
+    h, nb = 10, 3
+    rec = records.pack_records(synthetic.make_batch(nb, h, "standing", seed=6, phase="random"), h)
+    outs = []
+    for mode in ("untouched", "explicit_default", "changed_and_restored"):
+        mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb)
+        if mode == "explicit_default":
+            mpc.set_params(mass=9.0, inertia=(0.5413, 0.5200, 0.0691), mu=2.0, lt=0.09, lh=0.06, gravity=9.81)
+        elif mode == "changed_and_restored":
+            mpc.set_params(mass=11.0, mu=0.7)
+            mpc.set_params()
+        mpc.upload(rec)
+        outs.append([mpc.debug_assemble(k) for k in range(nb)])
+        mpc.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            for name in ("H", "g", "Fc", "Acd", "Bcd", "x0"):
+                np.testing.assert_array_equal(a[name].view(np.uint32), b[name].view(np.uint32), err_msg=name)
+    o = oracle.assemble_record(rec[0], h, synthetic.DT_MPC, synthetic.F_MAX)
+    np.testing.assert_array_equal(outs[0][0]["H"].view(np.uint32), o["H_red"].astype(np.float32).view(np.uint32))
