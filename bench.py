@@ -987,6 +987,55 @@ def main() -> None:
                         "max_rel_force_err_vs_qpoases": float(ee[okc].max()) if okc.any() else None,
                         "qpoases_failed_in_checked": int(refq["n_bad"])}
 
+            # COMMAND SWEEPS: 128 robot states x 64 velocity / yaw-rate commands = 8 192 instances, the
+            # trajectories built from the commands as ConvexMPCLocomotion.cpp:351-406 builds them; H and its inverse formed once per
+            # state (hmpc_solve_command_sweep) against the same records as 8 192 independent instances (hmpc_solve) -- bit-identical
+            # outputs asserted, kernel times by HIP events, best of 4
+            def command_sweep(groups, kk, gait2):
+                basef = synthetic.make_batch(groups, h, gait2, seed=12, phase="random")
+                fs = {key: np.repeat(np.asarray(v), kk, axis=0) for key, v in basef.items()}
+                rng2 = np.random.default_rng(13)
+                bb = groups * kk
+                vx, vy, yr = rng2.uniform(-0.5, 0.5, bb), rng2.uniform(-0.2, 0.2, bb), rng2.uniform(-0.3, 0.3, bb)
+                tr = fs["traj"].reshape(bb, h, 12).copy()
+                stp = np.arange(h)[None, :]
+                tr[:, :, 9], tr[:, :, 10], tr[:, :, 8] = vx[:, None], vy[:, None], yr[:, None]
+                tr[:, :, 3] = fs["p"][:, 0:1] + stp * synthetic.DT_MPC * vx[:, None]
+                tr[:, :, 4] = fs["p"][:, 1:2] + stp * synthetic.DT_MPC * vy[:, None]
+                tr[:, 1:, 2] = tr[:, 0:1, 2] + stp[:, 1:] * synthetic.DT_MPC * yr[:, None]
+                fs["traj"] = tr.reshape(bb, 12 * h)
+                recs = records.pack_records(fs, h)
+                mi = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, bb, device=local_rank)
+                mi.upload(recs)
+                mi.solve(stream)
+                fi, si = mi.download()
+                t_ind = min(mi.time_solve(1, stream) for _ in range(4))
+                mi.close()
+                ms = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, bb, device=local_rank)
+                ms.upload(recs)
+                ts4 = []
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(5):
+                    with torch.cuda.stream(streams[0]):
+                        ev0.record()
+                        ms.solve_command_sweep(kk, streams[0].cuda_stream)
+                        ev1.record()
+                    torch.cuda.synchronize()
+                    ts4.append(ev0.elapsed_time(ev1))
+                fsw, ssw = ms.download()
+                ms.close()
+                return {"states": groups, "commands_per_state": kk, "instances": bb, "gait": gait2,
+                        "independent": {"solves_per_s": bb / (t_ind * 1e-3), "kernel_ms": t_ind},
+                        "sweep": {"solves_per_s": bb / (min(ts4[1:]) * 1e-3), "kernel_ms": min(ts4[1:]),
+                                  "note": "both launches (one workgroup per state forms H^-1, one per instance solves with it), torch events on the launch stream"},
+                        "speedup": t_ind / min(ts4[1:]),
+                        "bit_identical_forces": bool(np.array_equal(fsw.view(np.uint32), fi.view(np.uint32))),
+                        "identical_status_words": bool(np.array_equal(ssw, si)),
+                        "failed": int((interface.status_code(ssw) != 0).sum())}
+
+            extra["command_sweep_128_states_x_64_commands"] = command_sweep(128, 64, "standing")
+            extra["command_sweep_1024_states_x_8_commands"] = command_sweep(1024, 8, "standing")
+            extra["command_sweep_128_states_x_64_commands_walking"] = command_sweep(128, 64, "walking")
             rs = {f"range_scale_{sc}": range_scale(sc) for sc in (1, 3, 6)}
             for sc in (3, 6):
                 rs[f"range_scale_{sc}"]["fraction_of_range_scale_1"] = rs[f"range_scale_{sc}"]["solves_per_s"] / rs["range_scale_1"]["solves_per_s"]

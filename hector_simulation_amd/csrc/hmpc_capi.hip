@@ -46,7 +46,7 @@ const Variant *variants() {
   static const Variant v[] = {hmpc_variant_0(), hmpc_variant_1(), hmpc_variant_2(),  hmpc_variant_3(),
                               hmpc_variant_4(), hmpc_variant_5(), hmpc_variant_6(),  hmpc_variant_7(),
                               hmpc_variant_8(), hmpc_variant_9(), hmpc_variant_10(), hmpc_variant_11(),
-                              hmpc_variant_12(), hmpc_variant_13()};
+                              hmpc_variant_12(), hmpc_variant_13(), hmpc_variant_14(), hmpc_variant_15()};
   return v;
 }
 constexpr int N_FAST = 4;       // two-contact fast variants [0, N_FAST), their safe variants N_FAST + (h > 10)
@@ -62,7 +62,10 @@ constexpr int V2_WIDE_SAFE = 10, V3_SAFE_G = 11;
 // workgroups per CU; they take over -- state and all -- the solves whose working set outgrew the fast variants' 64 rows, run block
 // rounds of up to 96 rows on them, and leave what outgrows them in turn (HMPC_S_WORKSET again) to the 120-row safe variants
 constexpr int V2_CONT = 12;  // + (h > 10)
-constexpr int N_VARIANTS = 14;
+// command sweeps (MODE 1, hmpc_solve_command_sweep): a workgroup solves a chunk of instances that share state and gait on ONE
+// inverse -- the 120-variable h <= 10 shape and the 60-variable (single support) one
+constexpr int V2_SWEEP_120 = 14, V2_SWEEP_60 = 15;
+constexpr int N_VARIANTS = 16;
 constexpr int MAX_VARS_ANY = 240;
 constexpr int DBG_FLOATS_MAX = hmpc::DbgLayout<240, 2>::TOTAL > hmpc::DbgLayout<180, 3>::TOTAL
                                    ? hmpc::DbgLayout<240, 2>::TOTAL
@@ -132,6 +135,8 @@ struct hmpc_handle {
   int spill_cap;
   int handover;  // hmpc_set_handover (default on)
   hmpc_params params;  // robot / contact constants (hmpc_set_params; defaults = the reference's literals)
+  double *d_sweep_m;  // command sweeps: every group's M = H^-1, [groups][36][threads per workgroup] doubles (grown on demand)
+  size_t sweep_m_bytes;
 };
 // longest-first dispatch (hmpc_set_dispatch_order, on by default): only where a launch has a tail to shorten -- more instances
 // than the ~512-1536 workgroup slots of the chip -- and not beyond what the one-workgroup sort handles in a few microseconds
@@ -210,6 +215,7 @@ struct LaunchOpt {
   bool resume = false;     // safe pass over an index list: instances whose fast solve left its state in a hand-over slot continue from it
   bool continuation = false;  // list launch of the CONTINUATION variant (V2_CONT): only instances with a hand-over slot, everything else on the list is left alone
   bool skip_ok = false;    // list launch: instances an earlier pass over the same list solved are left alone
+  int sweep_k = 0, sweep_phase = 0;  // command sweep: group size; phase 0 = one workgroup per group forms M, 1 = one per instance solves with it (variant = a MODE 1 entry)
 };
 
 static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
@@ -225,7 +231,7 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
     pv = &variants()[vi];
   }
   const Variant &v = *pv;
-  const int grid_all = o.assemble_only ? 1 : (o.d_index_list ? o.n_list : h->batch);
+  const int grid_all = o.assemble_only ? 1 : (o.d_index_list ? o.n_list : ((o.sweep_k > 0 && o.sweep_phase == 0) ? h->batch / o.sweep_k : h->batch));
   if (grid_all < 1) return HMPC_OK;
   // EGLOBAL variants keep NMAX (NMAX + 1) / 2 doubles of global scratch per WORKGROUP (231 KB for 240 variables): a host-driven
   // safe pass over thousands of flagged instances goes through the list in chunks that reuse one bounded buffer (stream order
@@ -246,6 +252,8 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   // hand-over slots: allocated on the first launch of a variant that saves its state (one slot per instance of the handle).
   // The per-instance slot table is written by EVERY ordinary launch of such a variant (-1 where nothing was saved), also when
   // saving itself is off for the launch, so that a later safe pass never meets an entry of an earlier batch.
+  if (o.assemble_only && !v.assemble) return HMPC_E_ARG;
+  if ((v.mode == 1) != (o.sweep_k > 0)) return HMPC_E_ARG;
   const bool can_save = v.spill_stride > 0 && !o.assemble_only && !o.d_index_list;
   const bool saves = can_save && h->handover && !h->d_ext_H;
   if (can_save && !h->d_spill_slot) {
@@ -265,7 +273,7 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   kernel_fn fn = o.assemble_only ? v.assemble : v.solve;
   if (!h->attrs_set[vi]) {
     HIP_TRY(hipFuncSetAttribute((const void *)v.solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.smem));
-    HIP_TRY(hipFuncSetAttribute((const void *)v.assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.smem));
+    if (v.assemble) HIP_TRY(hipFuncSetAttribute((const void *)v.assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.smem));
     h->attrs_set[vi] = true;
   }
   hmpc::KernelArgs a;
@@ -310,6 +318,7 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
     return HMPC_OK;  // nothing was handed over (hand-over off / no slots): the continuation pass has nothing to do
   }
   a.skip_ok = o.skip_ok ? 1 : 0;
+  a.sweep_k = o.sweep_k > 0 ? o.sweep_k : 1, a.sweep_phase = o.sweep_phase, a.sweep_m = h->d_sweep_m;
   a.inv_mass = 1.0f / h->params.mass;  // (binary32 division, correctly rounded: the value the reference's 1.f / 9.f folds to for the default)
   a.Ib[0] = h->params.inertia[0], a.Ib[1] = h->params.inertia[1], a.Ib[2] = h->params.inertia[2];
   a.mu = h->params.mu, a.lt = h->params.lt, a.lh = h->params.lh, a.gravity = h->params.gravity;
@@ -564,6 +573,7 @@ int hmpc_destroy(hmpc_handle *h) {
   if (h->d_cls) hipFree(h->d_cls);
   if (h->d_order) hipFree(h->d_order);
   if (h->d_escratch) hipFree(h->d_escratch);
+  if (h->d_sweep_m) hipFree(h->d_sweep_m);
   if (h->d_spill) hipFree(h->d_spill);
   if (h->d_spill_slot) hipFree(h->d_spill_slot);
   delete h;
@@ -753,6 +763,50 @@ int hmpc_solve(hmpc_handle *h, void *stream) {
   HIP_TRY(hipSetDevice(h->device));
   h->last_stream = (hipStream_t)stream;
   return enqueue_solve(h, (hipStream_t)stream, /*carry_wset=*/true);
+}
+
+// Command sweeps (MODE 1 kernels): phase 0 forms every group's M = H^-1 once (one workgroup per group) and leaves it in HBM, phase 1
+// solves every instance with its group's M (one workgroup per instance, stages H and S skipped).
+int hmpc_solve_command_sweep(hmpc_handle *h, int group_size, void *stream) {
+  if (!h || group_size < 1) return HMPC_E_ARG;
+  if (h->nc != 2 || h->setup.horizon > 10) return HMPC_E_ARG;  // (the shapes the sweep kernels are built for)
+  if (h->batch == 0) return HMPC_OK;
+  if (h->batch % group_size != 0) return HMPC_E_ARG;
+  if (group_size == 1) return hmpc_solve(h, stream);
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  h->last_stream = st;
+  const bool small = h->max_stance >= 0 && h->max_stance <= 60;  // single-support sweeps: the 60-variable kernel (six workgroups per CU)
+  const int vi = small ? V2_SWEEP_60 : V2_SWEEP_120;
+  const int groups = h->batch / group_size;
+  const size_t need = (size_t)groups * 36 * (size_t)variants()[vi].nt * sizeof(double);
+  if (need > h->sweep_m_bytes) {
+    if (h->d_sweep_m) {
+      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipFree(h->d_sweep_m));
+      h->d_sweep_m = nullptr, h->sweep_m_bytes = 0;
+    }
+    HIP_TRY(hipMalloc(&h->d_sweep_m, need));
+    h->sweep_m_bytes = need;
+  }
+  const bool repair = h->device_repair != 0;
+  if (repair) HIP_TRY(hipMemsetAsync(h->d_flag_count, 0, sizeof(unsigned int), st));
+  h->order_valid = false, h->order_batch = 0;  // (natural order inside a sweep; the next ordinary solve starts from the predictor)
+  LaunchOpt o;
+  o.variant = vi, o.sweep_k = group_size, o.sweep_phase = 0;
+  int rc = launch(h, st, o);
+  if (rc != HMPC_OK) return rc;
+  o.sweep_phase = 1;
+  o.record_flagged = repair;
+  rc = launch(h, st, o);
+  if (rc != HMPC_OK || !repair) return rc;
+  // whatever a sweep flags is repaired as an independent instance (its record is complete): the cold safe pass
+  LaunchOpt s;
+  s.d_index_list = h->d_flag_list;
+  s.n_list = h->batch < REPAIR_GRID_CAP ? h->batch : REPAIR_GRID_CAP;
+  s.warm = 0;
+  s.d_list_count = h->d_flag_count;
+  return launch_safe(h, st, s);
 }
 
 int hmpc_set_device_repair(hmpc_handle *h, int on) {

@@ -1014,9 +1014,22 @@ constexpr bool fits_three_waves() {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC = 2, int BPT = 1>
+// MODE 0: the product path, one workgroup = one independent instance.
+// MODE 1: COMMAND SWEEPS (hmpc_solve_command_sweep).  The batch is groups of args.sweep_k consecutive records that share
+// everything but the reference trajectory -- state, feet, joints, weights, gait table (ConvexMPCLocomotion.cpp:351-406 builds the
+// trajectory from the commands; SolverMPC.cpp:398-447, 488-570 builds A_qp, B_qp, H and the constraint block from the state and
+// the gait alone) -- so H and its inverse M are a property of the GROUP.  Two launches of this kernel:
+//   phase 0 (args.sweep_phase == 0), one workgroup per group: stages A, H, S on the group's first record, M written to the
+//     group's slot in HBM (36 x NT doubles, the register blocks' own layout, coalesced), nothing else;
+//   phase 1, one workgroup per INSTANCE (the chip stays as full as for independent solves): stage A on the instance's own
+//     record (its own g, the same chains), M read from its group's slot instead of stages H and S (55 % of an independent solve),
+//     then stages W and Q as they stand.  Same operands, same instructions: forces and status words are bit-identical to MODE 0's.
+//   A record that differs from its group's first one anywhere but in the trajectory is not solved (HMPC_S_SWEEP_MISMATCH).
+template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC = 2, int BPT = 1, int MODE = 0>
 __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, QCAP, NC, BPT>()) ? (NT == 128 ? HMPC_WAVES_PER_EU_128 : HMPC_WAVES_PER_EU_256) : 2) void hmpc_kernel(KernelArgs args) {
   using SM = Smem<NMAX, HMAX, NT, QCAP, NC, BPT>;
+  constexpr bool SWEEP = (MODE == 1);
+  static_assert(!SWEEP || (!ASM_ONLY && BPT == 1 && NC == 2 && QCAP != 0), "command sweeps: the fast two-contact variants");
   using RL = RecLayout<NC>;
   constexpr int NG = SM::NG, NW = SM::NW, U = SM::U, PS = SM::PS, C8 = 8 * NC;
   static_assert(NC == 2 || (NC == 3 && NT * BPT >= 512), "contacts: two feet (reference) or two feet + hand (extension)");
@@ -1040,9 +1053,14 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   if (!ASM_ONLY && args.list_count && blockIdx.x >= *args.list_count) return;  // device-side safe pass: nothing (more) flagged
   // (uniform by construction -- but when it comes from the index list it arrives through a vector load: told to the compiler, so
   //  that the instance's base addresses are scalar arithmetic instead of register pairs that live for the whole kernel)
-  const int inst = uni(ASM_ONLY ? args.dbg_index : (args.index_list ? args.index_list[blockIdx.x] : (int)blockIdx.x));
+  const int inst = uni(ASM_ONLY ? args.dbg_index
+                                : ((SWEEP && args.sweep_phase == 0) ? (int)blockIdx.x * args.sweep_k  // the group's first record
+                                                                    : (args.index_list ? args.index_list[blockIdx.x] : (int)blockIdx.x)));
   const int h = args.horizon;
   if (inst >= args.batch) return;
+  // command sweeps: M comes from (phase 1) or goes to (phase 0) this group's slot
+  const bool sweep_prepare = SWEEP && args.sweep_phase == 0, sweep_given = SWEEP && args.sweep_phase != 0;
+  double *const sweep_m = SWEEP ? args.sweep_m + (size_t)(inst / (SWEEP ? args.sweep_k : 1)) * (size_t)(GS * GS * NT) : nullptr;
   if (!ASM_ONLY && args.cls) {  // uniform: this instance belongs to another variant's launch
     const int c = args.cls[inst];
     if (c < args.cls_lo || c > args.cls_hi) return;
@@ -1078,6 +1096,25 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     const uint32_t *src = reinterpret_cast<const uint32_t *>(args.records + (size_t)inst * args.stride);
     const int nwords = args.stride >> 2;
     for (int t = tid; t < nwords; t += NT) A.rec[t] = src[t];
+  }
+  if constexpr (SWEEP) {
+    if (sweep_given) {
+      // every word of the record but the trajectory must equal the group's first record's (whose M this solve uses)
+      const int first = (inst / args.sweep_k) * args.sweep_k;
+      const uint32_t *base = reinterpret_cast<const uint32_t *>(args.records + (size_t)first * args.stride);
+      const int nfix = RL::NF, ntraj = 12 * args.horizon, ngw = (NC * args.horizon + 3) >> 2;
+      const uint32_t *own = reinterpret_cast<const uint32_t *>(args.records + (size_t)inst * args.stride);
+      int bad = 0;
+      for (int t = tid; t < nfix + ngw; t += NT) {
+        const int w = t < nfix ? t : t + ntraj;
+        bad |= (own[w] != base[w]) ? 1 : 0;
+      }
+      if (__syncthreads_or(bad)) {  // uniform
+        for (int t = tid; t < 6 * NC * args.horizon; t += NT) args.forces[(size_t)inst * 6 * NC * args.horizon + t] = 0.0f;
+        if (tid == 0) args.status[inst] = S_SWEEP_MISMATCH;
+        return;
+      }
+    }
   }
   __syncthreads();
   PROF_MARK(P_A0);
@@ -1494,7 +1531,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     }
   };
   double a[BPT][GS][GS];
-  if (!(RESUMABLE && resumed)) {  // (a resumed solve takes M from its hand-over slot: no H, no sweeps)
+  if (!((RESUMABLE && resumed) || sweep_given)) {  // (a resumed solve takes M from its hand-over slot, a command-sweep solve from its group's: no H, no sweeps)
   if constexpr (SM::FULLBLK) {
     // H on the matrix cores, through the block-Toeplitz structure of B_qp.  With Phi_k = Acd^k Bcd,
     //     H(a,b) = 2 [ sum_{i >= b} Phi_{i-a}' S Phi_{i-b} + alpha delta_ab ]          (U x U block, steps a <= b)
@@ -1820,6 +1857,17 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // sweeps of a leg-step are statically unrolled (static register indices).
   const bool is_v = tid < n, is_c = tid < m;
   // (the register blocks were loaded from the staging area of H at the end of stage A5)
+  if (sweep_given) {
+    if constexpr (SWEEP) {
+      // ---- command sweep, phase 1: the group's M as phase 0 left it (the same threads own the same blocks)
+      __syncthreads();  // g has been formed from the staging of the assembly, which the solver state aliases
+      own_blocks();
+#pragma unroll
+      for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < GS; ++jj) a[0][ii][jj] = sweep_m[(ii * GS + jj) * NT + tid];
+    }
+  } else
   if (RESUMABLE && resumed) {
     if constexpr (RESUMABLE) {
       // ---- hand-over: M from the slot's tail (the layout the fast variant's threads left: same block ownership)
@@ -2024,6 +2072,15 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   }
   }  // scalar sweeps
   PROF_MARK(P_SWEEP);
+  if constexpr (SWEEP) {
+    if (sweep_prepare) {  // uniform.  Phase 0 of a command sweep: this group's M to its slot, nothing else
+#pragma unroll
+      for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < GS; ++jj) sweep_m[(ii * GS + jj) * NT + tid] = a[0][ii][jj];
+      return;
+    }
+  }
 
   // ---- products with the register blocks --------------------------------------------------------------------------
   auto blk_rows = [&](const int s, const double (&wj)[GS], double (&ra)[GS]) __attribute__((always_inline)) {  // ra = a[s] * wj   (result on leg-step e0)

@@ -79,6 +79,11 @@ struct KernelArgs {
   // robot / contact constants (struct hmpc_params; defaults = the reference's literals): 1 / mass as the host's binary32 quotient
   // (what the compiler folds 1.0f / 9.0f to), body inertia diagonal, friction coefficient, toe / heel lever arms, gravity state
   float inv_mass, Ib[3], mu, lt, lh, gravity;
+  // command sweeps (MODE 1 kernels, hmpc_solve_command_sweep): groups of sweep_k consecutive records that differ in the reference
+  // trajectory only; sweep_phase 0 = one workgroup per group forms M = H^-1 and writes it to sweep_m[group][36][NT], phase 1 =
+  // one workgroup per instance solves with its group's M
+  int sweep_k, sweep_phase;
+  double *sweep_m;
   int resume;       // continuation launch: 1 = instances with a valid slot resume from it, the others start cold; 2 = ... the others are left alone
   int skip_ok;      // list launch: instances whose status word says ok (an earlier pass over the same list solved them) are left alone
 };
@@ -92,6 +97,6 @@ struct DbgLayout {
                        X0 = UB + 8 * NC * 20, ACD = X0 + 16, BCD = ACD + 176, TOTAL = BCD + 80 * NC;
 };
 
-enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT = 4, S_WORKSET = 5, S_OK_RELAXED = 6 };
+enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT = 4, S_WORKSET = 5, S_OK_RELAXED = 6, S_SWEEP_MISMATCH = 7 };
 
 }  // namespace hmpc

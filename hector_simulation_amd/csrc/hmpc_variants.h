@@ -22,6 +22,7 @@ typedef void (*kernel_fn)(hmpc::KernelArgs);
 
 struct Variant {
   int nmax, hmax, nt, qcap, nc;
+  int mode;  // 0: a workgroup per instance; 1: command sweeps (a workgroup per chunk of instances sharing state and gait)
   kernel_fn solve, assemble;
   size_t smem;
   int dbg_floats;
@@ -31,25 +32,28 @@ struct Variant {
   bool resumes;
 };
 
-// index = position in hmpc_capi.hip's variants(); (NMAX, HMAX, NT, QCAP, NC, BPT), group = translation unit that builds it.
+// index = position in hmpc_capi.hip's variants(); (NMAX, HMAX, NT, QCAP, NC, BPT, MODE), group = translation unit that builds it.
+// MODE 1 = command sweeps (a workgroup solves a chunk of instances that share state and gait on one inverse, hmpc_kernel.h).
 // The groups are balanced by compile time (the two-blocks-per-thread and 512-thread variants are the slow ones).
-#define HMPC_VARIANT_TABLE(X)                          \
-  X(0, 0, 60, 10, 128, 60, 2, 1)                       \
-  X(1, 0, 120, 10, 256, HMPC_QCAP_FAST, 2, 1)          \
-  X(2, 0, 60, 20, 128, 60, 2, 1)                       \
-  X(3, 1, 120, 20, 256, HMPC_QCAP_FAST, 2, 1)          \
-  X(4, 1, 120, 10, 256, 120, 2, 1)                     \
-  X(5, 1, 120, 20, 256, 120, 2, 1)                     \
-  X(6, 2, 180, 10, 256, HMPC_QCAP_3C, 3, 2)            \
-  X(7, 3, 180, 10, 512, 140, 3, 1)                     \
-  X(8, 2, 180, 10, 512, 100, 3, 1)                     \
-  X(9, 3, 240, 20, 512, HMPC_QCAP_WIDE, 2, 2)          \
-  X(10, 3, 240, 20, 512, 0, 2, 2)                      \
-  X(11, 2, 180, 10, 512, 0, 3, 1)                      \
-  X(12, 0, 120, 10, 256, HMPC_QCAP_CONT, 2, 1)         \
-  X(13, 1, 120, 20, 256, HMPC_QCAP_CONT, 2, 1)
+#define HMPC_VARIANT_TABLE(X)                             \
+  X(0, 0, 60, 10, 128, 60, 2, 1, 0)                       \
+  X(1, 0, 120, 10, 256, HMPC_QCAP_FAST, 2, 1, 0)          \
+  X(2, 0, 60, 20, 128, 60, 2, 1, 0)                       \
+  X(3, 1, 120, 20, 256, HMPC_QCAP_FAST, 2, 1, 0)          \
+  X(4, 1, 120, 10, 256, 120, 2, 1, 0)                     \
+  X(5, 1, 120, 20, 256, 120, 2, 1, 0)                     \
+  X(6, 2, 180, 10, 256, HMPC_QCAP_3C, 3, 2, 0)            \
+  X(7, 3, 180, 10, 512, 140, 3, 1, 0)                     \
+  X(8, 2, 180, 10, 512, 100, 3, 1, 0)                     \
+  X(9, 3, 240, 20, 512, HMPC_QCAP_WIDE, 2, 2, 0)          \
+  X(10, 3, 240, 20, 512, 0, 2, 2, 0)                      \
+  X(11, 2, 180, 10, 512, 0, 3, 1, 0)                      \
+  X(12, 0, 120, 10, 256, HMPC_QCAP_CONT, 2, 1, 0)         \
+  X(13, 1, 120, 20, 256, HMPC_QCAP_CONT, 2, 1, 0)         \
+  X(14, 2, 120, 10, 256, HMPC_QCAP_FAST, 2, 1, 1)         \
+  X(15, 3, 60, 10, 128, 60, 2, 1, 1)
 constexpr int HMPC_VARIANT_GROUPS = 4;
 
-#define HMPC_DECLARE_VARIANT(IDX, GRP, NMAX, HMAX, NT, QCAP, NC, BPT) Variant hmpc_variant_##IDX();
+#define HMPC_DECLARE_VARIANT(IDX, GRP, NMAX, HMAX, NT, QCAP, NC, BPT, MODE) Variant hmpc_variant_##IDX();
 HMPC_VARIANT_TABLE(HMPC_DECLARE_VARIANT)
 #undef HMPC_DECLARE_VARIANT

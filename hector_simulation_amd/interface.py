@@ -18,7 +18,7 @@ TICK_DTYPE = np.dtype([("position", "f8", 3), ("vWorld", "f8", 3), ("omegaWorld"
                        ("world_position_desired", "f8", 2), ("gait_offsets", "i4", 2), ("gait_durations", "i4", 2),
                        ("gait_iteration", "i4"), ("flags", "i4")], align=True)
 
-STATUS_NAMES = {0: "ok", 1: "max_iter", 2: "infeasible", 3: "too_large", 4: "kkt", 5: "working_set_full", 6: "ok_relaxed"}
+STATUS_NAMES = {0: "ok", 1: "max_iter", 2: "infeasible", 3: "too_large", 4: "kkt", 5: "working_set_full", 6: "ok_relaxed", 7: "sweep_mismatch"}
 
 
 class HmpcError(RuntimeError):
@@ -196,6 +196,12 @@ class BatchedMPC:
 
     def solve(self, stream: int = 0) -> None:
         _check(self.L.hmpc_solve(self.h, C.c_void_p(stream)), "hmpc_solve")
+
+    def solve_command_sweep(self, group_size: int, stream: int = 0) -> None:
+        """The current batch as groups of ``group_size`` consecutive records that differ in the reference trajectory only: H is
+        assembled and inverted once per group, every instance solves with its group's inverse -- bit-identical results
+        (include/hector_mpc.h hmpc_solve_command_sweep)."""
+        _check(self.L.hmpc_solve_command_sweep(self.h, int(group_size), C.c_void_p(stream)), "hmpc_solve_command_sweep")
 
     def download(self):
         b = self.batch

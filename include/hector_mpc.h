@@ -104,6 +104,7 @@ enum hmpc_status_code {
   HMPC_S_WORKSET = 5,     /* more simultaneously active constraints than the FAST variant's on-chip working set holds (64 rows; 96
                              with three contacts, 152 in the wide variant).  The safe pass holds as many rows as there are
                              variables -- in LDS for 120 variables, in global memory for 180 / 240 -- and cannot overflow */
+  HMPC_S_SWEEP_MISMATCH = 7, /* hmpc_solve_command_sweep: the record differs from its chunk's first record outside the trajectory; not solved */
   HMPC_S_OK_RELAXED = 6   /* solved only after every bound was moved outward by <= 2e-5 (relative for the Fz cap) AND the exact
                              re-solve on the working set so found did not pass the exact KKT check: the last-resort pass of
                              hmpc_resolve_failed for instances cycling at a degenerate vertex.  (When the exact re-solve passes --
@@ -164,6 +165,20 @@ int hmpc_set_device_outputs(hmpc_handle *h, float *device_forces, uint32_t *devi
 int hmpc_solve(hmpc_handle *h, void *stream);
 /* waits for `stream` work, copies forces [batch][12h] float and status [batch] to host (either may be NULL) */
 int hmpc_download(hmpc_handle *h, float *forces, uint32_t *status);
+/* COMMAND SWEEPS (round 6): the current batch is B = G x group_size records in G groups of group_size CONSECUTIVE records that
+ * share the robot state, foot positions, joint angles, weights and gait table and differ in the reference trajectory only -- one
+ * state under many commands: ConvexMPCLocomotion.cpp:351-406 builds state_trajectory from the velocity / yaw-rate commands, while
+ * A_qp, B_qp, H = 2(B'SB + alpha) and the constraint block depend on the state and the gait alone (SolverMPC.cpp:398-447, 488-570),
+ * so only g = 2 B'S (A_qp x0 - X_d) changes inside a group and M = H^-1 is a property of the GROUP.  Two launches on `stream`:
+ * one workgroup per group forms M once and leaves it in HBM (74 KB per group; a per-handle buffer grown on demand), then one
+ * workgroup per instance -- the chip as full as for independent solves -- assembles its own g, takes M from its group's slot
+ * instead of assembling and inverting H (55 % of an independent solve) and runs the block start and the active-set iteration as
+ * they stand: forces and status words are BIT-IDENTICAL to hmpc_solve's.  A record that differs from its group's first record
+ * anywhere but in the trajectory is not solved: status HMPC_S_SWEEP_MISMATCH, forces 0 (checked on the device, word by word).
+ * Flagged instances are repaired as independent ones (hmpc_download / hmpc_set_device_repair).  Two-contact handles, horizon <= 10;
+ * batch % group_size must be 0; group_size 1 is hmpc_solve.  A per-call CPU solver has no counterpart: the reference assembles and
+ * factorises H for every command. */
+int hmpc_solve_command_sweep(hmpc_handle *h, int group_size, void *stream);
 /* hint for device-resident records: the widest reduced QP (6 x stance leg-steps) in the batch: one launch of the variant
  * that holds it.  -1 = unknown (the state after hmpc_set_device_records / hmpc_build_records_device): two-contact handles
  * then route every instance on the device -- its stance leg-steps are counted there (by the record builder, or from the

@@ -140,12 +140,12 @@ def test_wrong_numbers_switches_cannot_reach_the_product_library():
 
 
 def test_every_kernel_variant_is_built_by_exactly_one_translation_unit():
-    """csrc/hmpc_variants.h: fourteen variants over HMPC_VARIANT_GROUPS groups, build.py compiles one unit per group."""
+    """csrc/hmpc_variants.h: sixteen variants over HMPC_VARIANT_GROUPS groups, build.py compiles one unit per group."""
     from hector_simulation_amd import build
 
     hdr = open(os.path.join(ROOT, "hector_simulation_amd", "csrc", "hmpc_variants.h")).read()
     rows = re.findall(r"X\((\d+), (\d+),", hdr)
-    assert [int(i) for i, _ in rows] == list(range(14))
+    assert [int(i) for i, _ in rows] == list(range(16))
     groups = sorted({int(g) for _, g in rows})
     assert groups == list(range(build.VARIANT_GROUPS))
     assert f"HMPC_VARIANT_GROUPS = {build.VARIANT_GROUPS}" in hdr

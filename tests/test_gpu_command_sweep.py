@@ -1,0 +1,141 @@
+"""Command sweeps (hmpc_solve_command_sweep, round 6): groups of records that share state and gait and differ in the reference
+trajectory only are solved on ONE inverse per group -- the results must be the bits of independent solves (hmpc_solve), whose
+parity against qpOASES the rest of the suite establishes; records that do not belong to their group are reported, never solved
+with another record's Hessian.
+
+What changes inside a group is what ConvexMPCLocomotion.cpp:351-406 builds from the commands (the reference trajectory);
+A_qp, B_qp, H and the constraint block come from the state and the gait alone (SolverMPC.cpp:398-447, 488-570)."""
+import numpy as np
+import pytest
+
+from hector_simulation_amd import interface, records, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def sweep_fields(groups: int, k: int, h: int, gait: str, seed: int, scale: float = 1.0) -> dict:
+    """`groups` random states (synthetic.make_batch), each under `k` velocity / yaw-rate commands: every field repeated k times,
+    the reference trajectory rebuilt per command exactly as make_batch builds it."""
+    base = synthetic.make_batch(groups, h, gait, seed=seed, phase="random")
+    f = {key: np.repeat(np.asarray(v), k, axis=0) for key, v in base.items()}
+    rng = np.random.default_rng(seed + 99)
+    b = groups * k
+    vx = rng.uniform(-0.5 * scale, 0.5 * scale, b)
+    vy = rng.uniform(-0.2 * scale, 0.2 * scale, b)
+    yr = rng.uniform(-0.3 * scale, 0.3 * scale, b)
+    tr = f["traj"].reshape(b, h, 12).copy()
+    p = f["p"]
+    steps = np.arange(h)[None, :]
+    tr[:, :, 9], tr[:, :, 10], tr[:, :, 8] = vx[:, None], vy[:, None], yr[:, None]
+    tr[:, :, 3] = p[:, 0:1] + steps * synthetic.DT_MPC * vx[:, None]
+    tr[:, :, 4] = p[:, 1:2] + steps * synthetic.DT_MPC * vy[:, None]
+    tr[:, 1:, 2] = tr[:, 0:1, 2] + steps[:, 1:] * synthetic.DT_MPC * yr[:, None]
+    f["traj"] = tr.reshape(b, 12 * h)
+    return f
+
+
+@pytest.mark.parametrize("gait,h,groups,k", [("standing", 10, 24, 16), ("walking", 10, 16, 8), ("mixed", 10, 12, 5), ("standing", 7, 6, 3),
+                                             ("standing", 10, 3, 64)])
+def test_sweep_is_bitwise_the_independent_solve(oracle, gait, h, groups, k):
+    f = sweep_fields(groups, k, h, gait, seed=41)
+    rec = records.pack_records(f, h)
+    b = groups * k
+    ind = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, b)
+    ind.upload(rec)
+    ind.solve()
+    f0, s0 = ind.download()
+    ind.close()
+    sw = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, b)
+    sw.upload(rec)
+    sw.solve_command_sweep(k)
+    f1, s1 = sw.download()
+    sw.close()
+    assert (interface.status_code(s0) == 0).all()
+    np.testing.assert_array_equal(s1, s0)  # status words: code, iteration count and final |W| of every instance
+    np.testing.assert_array_equal(f1.view(np.uint32), f0.view(np.uint32))
+    # (and the independent solve is what qpOASES gives: a few instances of the sweep against the oracle)
+    idx = np.arange(0, b, max(1, b // 12))
+    ref = oracle.solve_records(np.ascontiguousarray(rec[idx]), h, synthetic.DT_MPC, synthetic.F_MAX)
+    q = ref["q_soln"]
+    err = np.abs(f1[idx] - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+    assert ref["n_bad"] == 0 and err.max() < 1e-4  # north_star's tolerance
+    # the commands really differ inside a group
+    assert np.abs(f1.reshape(groups, k, -1)[:, 0] - f1.reshape(groups, k, -1)[:, 1]).max() > 1e-3
+
+
+def test_sweep_reports_records_that_do_not_belong_to_their_group():
+    h, groups, k = 10, 8, 8
+    f = sweep_fields(groups, k, h, "standing", seed=43)
+    rec = records.pack_records(f, h)
+    bad_state, bad_gait, bad_weight = 3 * k + 5, 5 * k + 1, 6 * k + 7
+    f2 = {key: np.array(v, copy=True) for key, v in f.items()}
+    f2["v"][bad_state, 0] += 1e-3                     # another body velocity: another x0 (g would differ, H would not -- still refused)
+    f2["gait"][bad_gait, 4] = 0                       # another gait table: another reduced QP altogether
+    f2["weights"][bad_weight, 2] *= 1.5               # another weight: another H
+    rec2 = records.pack_records(f2, h)
+    m = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, groups * k)
+    m.set_auto_resolve(False)
+    m.upload(rec2)
+    m.solve_command_sweep(k)
+    forces, st = m.download()
+    code = interface.status_code(st)
+    bad = np.zeros(groups * k, dtype=bool)
+    bad[[bad_state, bad_gait, bad_weight]] = True
+    assert (code[bad] == 7).all() and (code[~bad] == 0).all()
+    assert (forces[bad] == 0).all()
+    # the other instances are the independent solves of THEIR records, bit for bit
+    m.upload(rec2)
+    m.solve()
+    f_ind, st_ind = m.download()
+    m.close()
+    np.testing.assert_array_equal(forces[~bad].view(np.uint32), f_ind[~bad].view(np.uint32))
+    np.testing.assert_array_equal(st[~bad], st_ind[~bad])
+
+
+def test_sweep_argument_errors_and_the_group_of_one():
+    h = 10
+    rec = records.pack_records(sweep_fields(4, 4, h, "standing", seed=44), h)
+    m = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, 16)
+    m.upload(rec)
+    with pytest.raises(interface.HmpcError):
+        m.solve_command_sweep(5)   # 16 % 5 != 0
+    with pytest.raises(interface.HmpcError):
+        m.solve_command_sweep(0)
+    m.solve_command_sweep(1)       # = hmpc_solve
+    f1, s1 = m.download()
+    m.solve()
+    f0, s0 = m.download()
+    m.close()
+    np.testing.assert_array_equal(f1.view(np.uint32), f0.view(np.uint32))
+    m3 = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, 4, contacts=3)
+    m3.upload(records.pack_records(synthetic.make_batch3(4, h, "standing", seed=5), h, 3))
+    with pytest.raises(interface.HmpcError):
+        m3.solve_command_sweep(2)  # two-contact handles only
+    m3.close()
+
+
+def test_sweep_flagged_instances_are_repaired_as_independent_ones(oracle):
+    """A sweep at 6x the nominal ranges: instances whose working set outgrows the fast variant are flagged by the sweep kernel and
+    repaired by the safe pass (no hand-over inside a sweep), on the device or by hmpc_download -- every instance ends ok and equals
+    qpOASES."""
+    h, groups, k = 10, 16, 8
+    base = synthetic.hard_batch(groups, h, "standing", 17, 6)
+    f = {key: np.repeat(np.asarray(v), k, axis=0) for key, v in base.items()}
+    rng = np.random.default_rng(5)
+    tr = f["traj"].reshape(groups * k, h, 12).copy()
+    tr[:, :, 9] += rng.uniform(-0.5, 0.5, groups * k)[:, None]
+    f["traj"] = tr.reshape(groups * k, -1)
+    rec = records.pack_records(f, h)
+    ref = oracle.solve_records(rec, h, synthetic.DT_MPC, synthetic.F_MAX)
+    q = ref["q_soln"]
+    for device_side in (False, True):
+        m = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, groups * k)
+        m.set_device_repair(device_side)
+        m.upload(rec)
+        m.solve_command_sweep(k)
+        forces, st = m.download()
+        m.close()
+        assert (interface.status_code(st) == 0).all()
+        assert (interface.status_nactive(st) > 64).any()   # the regime really leaves the fast variant's capacity
+        err = np.abs(forces - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+        assert err.max() < 2e-6, err.max()
