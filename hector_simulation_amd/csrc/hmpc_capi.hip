@@ -203,7 +203,7 @@ struct LaunchOpt {
   const int *d_index_list = nullptr;  // workgroup b solves instance d_index_list[b] with the SAFE variant (re-solve of flagged ones)
   int n_list = 0;
   double relax = 0.0;
-  int warm = -1;           // -1 = the handle's setting, 0/1 = override for this launch (the safe pass starts cold without touching the handle)
+  int warm = -1;           // -1 = the handle's setting, 0/1 = override for this launch (the safe pass chooses per pass without touching the handle)
   bool carry_wset = true;  // false keeps a repeated launch of the same batch from consuming/advancing the tick-to-tick working sets
   const unsigned int *d_list_count = nullptr;
   bool record_flagged = false;
@@ -420,7 +420,7 @@ static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
     (void)pick_variant(h, &vsel);
     if (vsel == V2_WIDE && s.n_list > REPAIR_GRID_CAP_WIDE) s.n_list = REPAIR_GRID_CAP_WIDE;  // (231 KB of global scratch per workgroup)
   }
-  s.warm = 0;
+  s.warm = 1;  // (the block start: what differs from the fast variant is capacity, periodic rebuild of E, in-kernel perturbation)
   s.carry_wset = carry_wset;
   s.d_list_count = h->d_flag_count;
   // (1) continuation: instances whose working set outgrew the fast variant go on, from the state it handed over, on the variant
@@ -435,6 +435,7 @@ static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
     static const bool cont_only = getenv("HMPC_DEBUG_CONT_ONLY") && getenv("HMPC_DEBUG_CONT_ONLY")[0] == '1';  // developer switch: what the continuation pass alone leaves
     if (cont_only) return HMPC_OK;
   }
+  if (h->device_repair == 2) return HMPC_OK;  // continuation only: the cold safe pass is left to hmpc_resolve_failed / hmpc_download
   return launch_safe(h, stream, s);
 }
 
@@ -828,7 +829,7 @@ int hmpc_set_device_repair(hmpc_handle *h, int on) {
     if (h->d_flag_count) (void)hipFree(h->d_flag_count);
     h->d_flag_list = list, h->d_flag_count = count;
   }
-  h->device_repair = on ? 1 : 0;
+  h->device_repair = (on == 2) ? 2 : (on ? 1 : 0);
   return HMPC_OK;
 }
 
@@ -864,9 +865,9 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
     d_idx = (int *)sp;
   }
   HIP_TRY(hipMemcpy(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
-  // the safe pass starts cold, as the reference does (launch parameter; the handle's own setting is not touched)
+  // (launch parameters; the handle's own warm-start setting is not touched)
   LaunchOpt so;
-  so.d_index_list = d_idx, so.n_list = (int)idx.size(), so.warm = 0;
+  so.d_index_list = d_idx, so.n_list = (int)idx.size(), so.warm = 1;  // (first pass: with the block start; the perturbed passes below start cold)
   int rc = HMPC_OK;
   if (h->nc == 2 && h->handover && h->d_spill) {
     // continuation first (see enqueue_solve): instances with a hand-over slot go on where the fast variant stopped
@@ -909,7 +910,7 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
     }
     if (still.empty()) break;
     HIP_TRY(hipMemcpy(d_idx, still.data(), still.size() * sizeof(int), hipMemcpyHostToDevice));
-    so.n_list = (int)still.size(), so.relax = relax_levels[lvl];
+    so.n_list = (int)still.size(), so.relax = relax_levels[lvl], so.warm = 0;
     rc = launch_safe(h, h->last_stream, so);
     if (rc != HMPC_OK) return rc;
     HIP_TRY(hipStreamSynchronize(h->last_stream));

@@ -283,11 +283,14 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #ifndef HMPC_BLOCK_MIN_NEW
 #define HMPC_BLOCK_MIN_NEW 3     // a further round needs at least this many newly violated rows (256-/128-thread variants; 5 until the Schur matrix went to the matrix cores: profiles/r05/block_round_ab.txt)
 #endif
+#ifndef HMPC_EARLY_HANDOVER_MARGIN
+#define HMPC_EARLY_HANDOVER_MARGIN 8  // fast variants: candidates beyond the block start's capacity that send an instance to the continuation variant at once
+#endif
 #ifndef HMPC_READD_LIMIT
 #define HMPC_READD_LIMIT 6  // continuation / safe variants: single-row additions of ONE row before it is set aside (0: off)
 #endif
 #ifndef HMPC_CONT_ITER_BUDGET
-#define HMPC_CONT_ITER_BUDGET 64  // continuation variant: iterations a resumed solve may add before it is left to the safe pass
+#define HMPC_CONT_ITER_BUDGET 128  // continuation variant: iterations a resumed solve may add before it is left to the safe pass
 #endif
 #ifndef HMPC_CONT_REFRESH
 #define HMPC_CONT_REFRESH 0      // continuation variant: 1 = E rebuilt from M every 48 working-set changes, as the safe variants do (measured: no difference in
@@ -1204,7 +1207,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     for (int t = tid; t < PS; t += NT) A.Bcd[t] = 0.0f;                           // fl(dt*0) = 0
     for (int t = tid; t < C8 * U; t += NT) A.Fc[t] = 0.0f;
     for (int t = tid; t < U * h; t += NT) S.rmap[t] = 255;
-    if (tid == 0) S.relax = args.relax;
+    if (tid == 0) S.relax = args.relax, S.pad0 = 0;  // (pad0: "a row keeps being re-added", the anti-cycling variants' flag)
   }
   __syncthreads();
   PROF_MARK(P_A1);
@@ -2292,6 +2295,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   const int itmax_v = (SAFE || QCAP >= 140) ? 10 * m + 64 : 4 * m + 16;  // the safe variants may take as long as a cold qpOASES run (nWSR up to ~330 seen)
   int itmax = (args.iter_cap > 0 && args.iter_cap < itmax_v) ? args.iter_cap : itmax_v;
   bool budgeted = false, budget_hit = false;  // (continuation variant only)
+  bool perturbed = false;                     // (anti-cycling variants: the bounds were moved outward in this pass)
+  const int itmax_full = itmax;
   if constexpr (CONT) {
     // a resumed solve gets a budget of its own: in exact arithmetic the hardest instances need ~50 more changes from the hand-over
     // (scripts/dev/emulate_rounds.py); one that is still going after HMPC_CONT_ITER_BUDGET is cycling at a degenerate vertex -- the
@@ -2429,6 +2434,12 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     // (a) rows 4-6 (foot-x moment window, toe and heel line contact) violated at x_u take consecutive slots.  The three
     //     rows of a leg-step are linearly independent, rows of different leg-steps touch disjoint variables, so the
     //     Schur matrix of any such set is positive definite.
+    // Early hand-over (fast variants that can hand over): a round that finds far more candidate rows than the block start can take
+    // (48) -- 8 more than the working set of any nominal instance ever holds -- belongs to an instance that will outgrow the 64-row
+    // working set anyway, after dozens of single-row iterations at 11 k cycles each.  It is handed to the continuation variant
+    // (96 rows per round, two per CU) right after the rounds instead.  Never at nominal inputs (|W| <= 51 there); at 6x the ranges
+    // it takes ~30 iterations off the fast pass for four instances in ten.
+    bool early_handover = false;
     double raw = INF;
     int side = 1;
     bool take = false;
@@ -2506,6 +2517,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       }
       count_candidates();
       HMPC_DBG(if (k0 > (LONGRUN ? SM::QMAX : KBMAX)) ++dbg_norounds_cap; else if (!refresh && k0 - q < BLOCK_MIN_NEW) ++dbg_norounds_few;)
+      if constexpr (SPILLS) {
+        if (k0 > KBMAX + HMPC_EARLY_HANDOVER_MARGIN) early_handover = true;
+      }
       if (ub((!refresh && k0 - q < BLOCK_MIN_NEW) || k0 > (LONGRUN ? SM::QMAX : KBMAX))) return false;  // not worth a round / does not fit: the iteration below goes on
       // (no barrier here: what follows writes act / slot / Wrow entries that nobody reads before the barrier behind the slot deal,
       //  and wcount is not written again before the release loop, several barriers on)
@@ -2542,6 +2556,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     }
     const int rlo = (tick || BLOCK_FRICTION) ? 0 : 4, rhi = tick ? 7 : 6;
     bool bad_start = false;
+    if constexpr (SPILLS) {
+      if (k0 > KBMAX + HMPC_EARLY_HANDOVER_MARGIN) early_handover = true;  // (uniform) far more candidates than this variant can take at once
+    }
     if (k0 > (LONGRUN ? SM::QMAX : KBMAX)) k0 = LONGRUN ? SM::QMAX : KBMAX;
     if (is_c) {  // slots are dealt afresh every round (E is rebuilt from scratch)
       const bool in = take && base + below < k0;
@@ -2881,7 +2898,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       static_assert(CONT_ROUNDS >= 0 && CONT_ROUNDS <= 4, "rounds are instantiated one by one");
     }
   }
-  if constexpr (!LONGRUN)  // (the safe-pass variants are only ever launched cold: the opening rounds are not even compiled for them)
+  // (the safe variants as well since round 6: their first pass over a flagged instance starts from the block start like any other
+  //  solve -- 40-60 iterations instead of the 150-250 of a cold run at 6x the input ranges, on ONE workgroup at the tail of the
+  //  stream --; the last-resort passes with perturbed bounds stay cold)
   if (args.warm && !(RESUMABLE && resumed)) {
     bool more = block_round(0, false);
     if constexpr (BLOCK_ROUNDS > 1) {
@@ -2906,8 +2925,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   //  variant's -- and rebuilds E periodically as well: on the matrix cores, a refresh costs about four single-row iterations)
   constexpr bool REFRESHES = LONGRUN || (CONT && HMPC_CONT_REFRESH);
   int since_refresh = 0;
-  for (int pass = 0; pass < 3 && code == S_OK; ++pass) {
+  for (int pass = 0; pass < (ANTICYCLE ? 8 : 3) && code == S_OK; ++pass) {
     const int iters_at_entry = uni(iters);  // (uniform: a scalar register)
+    if constexpr (ANTICYCLE) perturbed = false;
     // ---- main loop ----
     while (true) {
       if constexpr (REFRESHES) {
@@ -2952,6 +2972,37 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       }
       PROF_MARK(P_SEL);
       if (ub(!(pval < -FEAS_TOL))) break;
+      if constexpr (ANTICYCLE) {
+        // Degenerate vertices, handled where they occur (round 6; until then only the host's last-resort passes did this, after a
+        // cold re-solve had burnt its whole iteration bound).  When the re-addition counter of a row reaches its limit, or a
+        // resumed solve's budget runs out, the instance is cycling: every bound is moved outward by relax (1 + frac(0.618 row)) --
+        // a different amount per row, which separates the coinciding vertices --, the multipliers and the point are moved onto
+        // the perturbed problem's vertex by the refinement step below (u += E (b' - N x), x = x_u + M N'u: x(u) is linear in u),
+        // and the iteration goes on in the next pass.  Up to three levels, 1e-7 / 1e-6 / 1e-5.  The epilogue re-solves on the final
+        // working set with the EXACT bounds and repeats the exact KKT check: passed = HMPC_S_OK, exact.
+        // (safe variants only.  The continuation variant's long-runners were measured to run through every level's budget and end
+        //  flagged all the same -- 512 instead of 128 iterations at the tail of its launch --: there the budget and the KKT check decide,
+        //  and the safe pass, which starts cold, perturbs)
+        const bool cycling = LONGRUN && ub(S.pad0 != 0);
+        if (cycling) {
+          const double rl = uni_d(S.relax);
+          if (rl < 0.99e-5) {  // (uniform) another level left
+            __syncthreads();  // (everyone has read pad0 and relax)
+            if (tid == 0) S.relax = (rl == 0.0) ? 1e-7 : 10.0 * rl, S.pad0 = 0;
+            for (int t = tid; t < SM::MMAX; t += NT) Q.flpc[t] = (unsigned char)(Q.flpc[t] & 1);
+            __syncthreads();
+            if constexpr (!LAZY) {
+              if (is_c) c_ub_r = row_ub_calc();
+            }
+            if constexpr (CONT) {  // (a resumed solve's budget starts afresh)
+              if (budgeted) itmax = (iters + HMPC_CONT_ITER_BUDGET < itmax_full) ? iters + HMPC_CONT_ITER_BUDGET : itmax_full;
+            }
+            perturbed = true;
+            break;  // -> the refinement moves (x, u) onto the perturbed vertex, the next pass goes on from there
+          }
+          if (tid == 0) S.pad0 = 0;  // (no level left: the rows that hit the limit stay set aside, the KKT check decides)
+        }
+      }
       if (iters >= itmax) {
         if constexpr (CONT) {
           if (budgeted) {  // (uniform)
@@ -2966,7 +3017,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         // a violated row and a full working set: stop HERE, between two iterations, where (x, u, W, E) is a complete
         // Goldfarb-Idnani state that the continuation variant can take over (inside an iteration -- after partial steps for
         // the row being added -- it is not).  Conservative by at most one row: the step might have dropped a row first.
-        if (q >= SM::QMAX) {
+        if (q >= SM::QMAX || (early_handover && args.spill && inst < args.spill_cap)) {
           code = S_WORKSET;
           break;
         }
@@ -3109,6 +3160,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
             if constexpr (ANTICYCLE) {
               const unsigned fc = Q.flpc[p];
               if ((fc >> 1) < 127u) Q.flpc[p] = (unsigned char)(fc + 2u);
+              if ((fc >> 1) + 1u >= (unsigned)HMPC_READD_LIMIT) S.pad0 = 1;  // this row keeps coming back: the loop head reacts
             }
           }
           ++q;
@@ -3125,7 +3177,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     if (code != S_OK || q == 0) break;
     // nothing happened in this pass: either the refined point of the previous pass is feasible, or (first pass) the block
     // start already is the optimum -- its x, u, E come straight from the inversion, there is nothing to refine
-    if (iters == iters_at_entry && !(CONT && budget_hit)) break;
+    if (iters == iters_at_entry && !(CONT && budget_hit) && !(ANTICYCLE && perturbed)) break;
     if constexpr (LONGRUN) {
       if (ub(since_refresh >= REFRESH_FINAL)) {  // the answer is read off a freshly built E; the loop above then confirms it
         __syncthreads();
@@ -3232,7 +3284,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     return !(val < -KKT_TOL * xmax || umin < -1e-6 * xmax);  // relative to the force scale
   };
   if (code == S_OK && !ub(kkt_ok())) code = S_KKT;  // (the reductions leave the same values in every lane: a scalar decision)
-  if (ub(args.relax != 0.0) && code == S_OK) {
+  if ((ANTICYCLE ? ub(S.relax != 0.0) : ub(args.relax != 0.0)) && code == S_OK) {
     // Last-resort pass (bounds moved outward, hmpc_resolve_failed): the perturbation was only there to separate coinciding
     // vertices.  With the working set it ended on, the multipliers and the point are re-solved for the EXACT bounds
     // (x(u) is linear in u: one correction u += E (b_W - N_W x(u)) lands on the exact vertex) and the KKT check is repeated

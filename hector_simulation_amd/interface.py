@@ -168,9 +168,9 @@ class BatchedMPC:
         """Continue (default) or re-solve cold the instances whose working set outgrew the fast variant (hmpc_set_handover)."""
         _check(self.L.hmpc_set_handover(self.h, 1 if on else 0), "hmpc_set_handover")
 
-    def set_device_repair(self, on: bool) -> None:
-        """Device-side safe pass inside every solve (include/hector_mpc.h hmpc_set_device_repair)."""
-        _check(self.L.hmpc_set_device_repair(self.h, 1 if on else 0), "hmpc_set_device_repair")
+    def set_device_repair(self, on) -> None:
+        """Device-side safe pass inside every solve (include/hector_mpc.h hmpc_set_device_repair); 2 = continuation pass only."""
+        _check(self.L.hmpc_set_device_repair(self.h, 2 if on == 2 else (1 if on else 0)), "hmpc_set_device_repair")
 
     def set_max_iterations(self, max_iter: int) -> None:
         """Cap on the active-set iterations (0 = none); the nWSR analogue (include/hector_mpc.h hmpc_set_max_iterations)."""

@@ -259,7 +259,11 @@ int hmpc_set_handover(hmpc_handle *h, int on);
  * pass keeps 231 KB of global scratch per workgroup: the first 256 positions of the flagged list -- which it shares with the
  * <= 120-variable instances of an unsized h > 10 batch, so fewer than 256 wide ones may be reached), the rest stay flagged for
  * hmpc_resolve_failed / hmpc_download.  Instances whose working set merely outgrew the fast variant are CONTINUED, not
- * re-solved (hmpc_set_handover). */
+ * re-solved (hmpc_set_handover): first the continuation variant over the flagged list (96-row working set, two workgroups per
+ * CU), then the safe variant, cold, over what is still flagged.  on = 2: the continuation pass only -- what it does not finish
+ * (~0.5 % of the instances at 6x the nominal input ranges: degenerate vertices, working sets beyond 96 rows) stays FLAGGED in
+ * the status word for hmpc_resolve_failed / hmpc_download; a cold re-solve of such an instance takes hundreds of iterations on a
+ * single workgroup, milliseconds at the tail of the stream, which a device-resident pipeline may prefer not to wait for. */
 int hmpc_set_device_repair(hmpc_handle *h, int on);
 /* NOTE (device repair): the list of flagged instances and its counter belong to the handle -- keep the solves of ONE handle
  * on one stream at a time (use one handle per stream to overlap launches, as bench.py does). */

