@@ -28,12 +28,18 @@ EXTRA = os.environ.get("HMPC_EXTRA_FLAGS", "").split()  # developer A/B switches
 FLAGS = CFLAGS + EXTRA
 
 
+# developer switches that make the library WRONG for a user by design: -DHMPC_DEBUG_STATS writes per-solve debug counters where the
+# objective value goes (scripts/dev/cont_probe.py), -DHMPC_PROFILE adds clock reads to every phase
+DEV_ONLY_FLAGS = ("-DHMPC_DEBUG_STATS", "-DHMPC_PROFILE")
+
+
 def _check_flags() -> None:
-    """-DHMPC_DEV_TIMING unlocks switches that leave stages of the kernel out (wrong numbers, right timing): never for the
-    library the package loads, unless the developer says so explicitly (HMPC_ALLOW_DEV_TIMING=1, scripts/phase experiments)."""
-    if any(f.startswith("-DHMPC_DEV_TIMING") for f in EXTRA) and os.environ.get("HMPC_ALLOW_DEV_TIMING") != "1":
-        raise RuntimeError("HMPC_EXTRA_FLAGS contains -DHMPC_DEV_TIMING (wrong-numbers timing switches): refused for the product "
-                           "library; set HMPC_ALLOW_DEV_TIMING=1 for a throw-away timing build")
+    """Developer-only switches never reach the library the package loads, unless the developer says so explicitly
+    (HMPC_ALLOW_DEV_BUILD=1: the throw-away builds of scripts/gpu_*.sh, which restore the product library afterwards)."""
+    bad = [f for f in EXTRA if f.startswith(DEV_ONLY_FLAGS)]
+    if bad and os.environ.get("HMPC_ALLOW_DEV_BUILD") != "1":
+        raise RuntimeError(f"HMPC_EXTRA_FLAGS contains {bad} (developer-only: wrong outputs by design): refused for the product "
+                           "library; set HMPC_ALLOW_DEV_BUILD=1 for a throw-away build")
 
 
 def source_hash() -> str:
@@ -74,7 +80,8 @@ def build_to(out: str, extra_compile_flags: list | None = None, verbose: bool = 
     """A developer copy of the library (profiling / timing builds) at `out`; the product library and its stamp are not touched."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     with tempfile.TemporaryDirectory(prefix="hmpc_obj_") as objdir:
-        units = [(o, c[:1] + list(extra_compile_flags or []) + c[1:]) for o, c in compile_commands(objdir, hipcc)]
+        # (extra flags go AFTER the product's, so that a -D here overrides one in HMPC_EXTRA_FLAGS)
+        units = [(o, c[:-4] + list(extra_compile_flags or []) + c[-4:]) for o, c in compile_commands(objdir, hipcc)]  # (... -c src -o obj)
 
         def run(unit):
             if verbose:
@@ -89,9 +96,9 @@ def build_to(out: str, extra_compile_flags: list | None = None, verbose: bool = 
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    _check_flags()  # (before the staleness shortcut: a library built earlier with developer flags must not be loaded silently either)
     if not force and not needs_build():
         return LIB
-    _check_flags()
     lock_path = LIB + ".lock"
     with open(lock_path, "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)

@@ -4,7 +4,7 @@
 //   update_problem_data -> solve_mpc -> qpOASES::QProblem::init
 //   (ConvexMPC/convexMPC_interface.cpp:83-103, ConvexMPC/SolverMPC.cpp:371-738, third_party/qpOASES/src/QProblem.cpp:316).
 //
-// Compiled for three waves per SIMD where the LDS footprint allows it (168 VGPRs; see HMPC_WAVES_PER_EU_* below).
+// Compiled for three waves per SIMD where the LDS footprint allows it (168 VGPRs; see WAVES_PER_EU_* below).
 // Phases (all state lives in LDS / registers; HBM sees only the ~716 B record in and 12h floats + 1 word out):
 //   A  assembly in binary32 under the HMPC-A1 arithmetic contract (bit-identical to the CPU oracle):
 //      trig -> scalar algebra -> Acd^k, Phi_k = Acd^k Bcd -> tracking error -> swing elimination tables
@@ -34,9 +34,6 @@
 
 #include <type_traits>
 
-#ifndef HMPC_MFMA_SWEEP_WIDE
-#define HMPC_MFMA_SWEEP_WIDE 1  // stage S on the matrix cores for the fast wide variant (240 variables, 512 threads, two blocks per thread): 15 x 15 tiles on eight waves
-#endif
 #ifndef HMPC_QCAP_CONT
 #define HMPC_QCAP_CONT 96  // working-set capacity of the continuation variant of the 120-variable shapes (70 KB of LDS: two workgroups per CU)
 #endif
@@ -116,7 +113,7 @@ struct Smem {
   // conditioned than the raw ones, which is what the explicitly inverted pivot block needs)
   static constexpr bool MFS2 = (NMAX == 120 && NT == 256 && BPT == 1 && NC == 2);  // shapes whose fast variants sweep on the matrix cores
   static constexpr bool MFS3 = (NMAX == 180 && NT == 256 && BPT == 2 && NC == 3) ||
-                               (HMPC_MFMA_SWEEP_WIDE && NMAX == 240 && NT == 512 && BPT == 2 && NC == 2 && QCAP != 0);  // (round 5: the wide variant)
+                               (NMAX == 240 && NT == 512 && BPT == 2 && NC == 2 && QCAP != 0);  // (round 5: the wide variant, 15 x 15 tiles on eight waves)
   signed char kexp[(MFS2 || MFS3) ? 16 * ((NMAX + 15) / 16) : 1];
   unsigned char rmap[U * HMAX];            // original variable U*step+comp -> sweep index (255 = eliminated)
   unsigned char ls_leg[NG], ls_step[NG];
@@ -262,27 +259,21 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 //   variables: 26 KB LDS): THREE waves per SIMD = 168 VGPRs = three resp. six resident workgroups per CU.  The kernel is
 //   bound by dependent-instruction latency and barrier phases, not by issue: the third wave is worth +30 % (profiles/r02).
 //   Everything else (h = 20 scratch, safe variants, 512 threads): two.
-#ifndef HMPC_WAVES_PER_EU_256
-#define HMPC_WAVES_PER_EU_256 3
-#endif
-#ifndef HMPC_WAVES_PER_EU_128
-#define HMPC_WAVES_PER_EU_128 3
-#endif
-#ifndef HMPC_FLIP4
-#define HMPC_FLIP4 1  // block start: switch moment-window rows with a negative multiplier to their other bound (0: release them)
-#endif
-#ifndef HMPC_PIN_SWEEP
-#define HMPC_PIN_SWEEP 1
-#endif
-#ifndef HMPC_BLOCK_ROUNDS
-#define HMPC_BLOCK_ROUNDS 2      // block start: rounds at most (1 = a single block start), 120-variable variants
-#endif
-#ifndef HMPC_BLOCK_ROUNDS_3C
-#define HMPC_BLOCK_ROUNDS_3C 3   // ... three-contact variant
-#endif
-#ifndef HMPC_BLOCK_MIN_NEW
-#define HMPC_BLOCK_MIN_NEW 3     // a further round needs at least this many newly violated rows (256-/128-thread variants; 5 until the Schur matrix went to the matrix cores: profiles/r05/block_round_ab.txt)
-#endif
+// Tuning constants.  (Until round 6 this was a list of 29 `#ifndef HMPC_*` A/B switches; every one whose other side had been
+// measured worse -- profiles/r02 ... r05 keep the numbers -- is now simply the code: FLIP4, PIN_SWEEP, CHAIN_BALANCE,
+// MFS_PUBLISH_FIRST, S0_ACTIVE_ROWS, REFINE_FROM_X, MFS_DEAL_PAIRED, MFS_RCP_NEWTON = 2, MFS_PST_PAD = 18, SCHUR_MFMA*, BLOCK_FRICTION,
+// MFMA_SWEEP*, and the wrong-numbers timing switches MFS_NO_* / MFS_ONLY_WAVE.  What is left as a macro is compiled with a
+// non-default value by tests/test_switches_compile.py so that it cannot rot.)
+namespace hmpc {
+constexpr int WAVES_PER_EU_256 = 3, WAVES_PER_EU_128 = 3;  // fast variants: three waves per SIMD (168 VGPRs) where the LDS allows it
+constexpr int BLOCK_ROUNDS_2C = 2;     // block start: rounds at most, 120-variable variants (a third instantiation: 86 spilled registers)
+constexpr int BLOCK_ROUNDS_3C = 3;     // ... three-contact variant
+constexpr int BLOCK_MIN_NEW_2C = 3;    // a further round needs at least this many newly violated rows (5 until the Schur matrix went to the matrix cores: profiles/r05/block_round_ab.txt)
+constexpr int BLOCK_MIN_NEW_3C = 2;    // ... three-contact variant (its single-row iteration is dearer)
+constexpr int EPT_3C = 7;              // three-contact variant on 256 threads: packed-triangle entries per thread in the register-resident Schur inversion
+constexpr int MFS_GT = 4;              // matrix-core sweeps, 20 tiles per wave: tiles per group of operand reads (two groups in flight)
+constexpr int MFS_PST_PAD = 18;        // padding of a pivot-panel row in doubles (see MfsPanel; 16 was the round-4 layout: 4-way bank conflicts on the column publishes)
+}  // namespace hmpc
 #ifndef HMPC_EARLY_HANDOVER_MARGIN
 #define HMPC_EARLY_HANDOVER_MARGIN 8  // fast variants: candidates beyond the block start's capacity that send an instance to the continuation variant at once
 #endif
@@ -292,70 +283,8 @@ __device__ inline void quat_to_R(const float *q, float *R, float *Rt) {
 #ifndef HMPC_CONT_ITER_BUDGET
 #define HMPC_CONT_ITER_BUDGET 128  // continuation variant: iterations a resumed solve may add before it is left to the safe pass
 #endif
-#ifndef HMPC_CONT_REFRESH
-#define HMPC_CONT_REFRESH 0      // continuation variant: 1 = E rebuilt from M every 48 working-set changes, as the safe variants do (measured: no difference in
-                                 // iterations or time at 6x, and that seventh instantiation of the round costs 113 spilled registers: off)
-#endif
 #ifndef HMPC_CONT_ROUNDS
-#define HMPC_CONT_ROUNDS 4       // continuation variant: block rounds a resumed solve runs before its single-row iteration
-#endif
-#ifndef HMPC_BLOCK_MIN_NEW_3C
-#define HMPC_BLOCK_MIN_NEW_3C 2  // ... three-contact variant (its single-row iteration is dearer; 3 until round 5)
-#endif
-#ifndef HMPC_CHAIN_BALANCE
-#define HMPC_CHAIN_BALANCE 1     // H chains of the 120-variable h <= 10 variant: block-diagonals dealt to the waves by length
-#endif
-#ifndef HMPC_EPT_3C
-#define HMPC_EPT_3C 7            // three-contact variant on 256 threads: packed-triangle entries per thread in the block start
-#endif
-#ifndef HMPC_MFMA_SWEEP
-#define HMPC_MFMA_SWEEP 1  // 120-variable / 256-thread variants: stage S as 4 x 4 block pivots on v_mfma_f64_16x16x4_f64 (0: scalar sweeps)
-#endif
-#ifndef HMPC_MFS_GT
-#define HMPC_MFS_GT 4  // matrix-core sweeps, 20 tiles per wave: tiles per group of operand reads (two groups in flight)
-#endif
-#ifndef HMPC_MFMA_SWEEP3
-#define HMPC_MFMA_SWEEP3 1  // the same for the fast three-contact variant (180 variables, 256 threads, two blocks per thread)
-#endif
-// Developer switches that produce WRONG NUMBERS by design (they leave a stage of the matrix-core sweeps out to time the rest):
-// HMPC_MFS_NO_LDL, HMPC_MFS_NO_STEPS, HMPC_MFS_NO_LOAD, HMPC_MFS_NO_RELAYOUT, HMPC_MFS_ONLY_WAVE.  They compile only together
-// with -DHMPC_DEV_TIMING, which hector_simulation_amd/build.py refuses for the product library (tests/test_abi.py).
-#if (defined(HMPC_MFS_NO_LDL) || defined(HMPC_MFS_NO_STEPS) || defined(HMPC_MFS_NO_LOAD) || defined(HMPC_MFS_NO_RELAYOUT) || \
-     defined(HMPC_MFS_ONLY_WAVE)) && !defined(HMPC_DEV_TIMING)
-#error "HMPC_MFS_NO_* / HMPC_MFS_ONLY_WAVE give wrong results by design: timing builds only, add -DHMPC_DEV_TIMING"
-#endif
-#ifndef HMPC_MFS_PUBLISH_FIRST
-#define HMPC_MFS_PUBLISH_FIRST 1  // matrix-core steps: the pivot block's owner issues all its panel stores before it waits for the raw block
-#endif
-#ifndef HMPC_S0_ACTIVE_ROWS
-#define HMPC_S0_ACTIVE_ROWS 1  // block start, S0 = N M N': every lane iterates over its own active rows (0: all lanes count through rows rlo .. rhi)
-#endif
-#ifndef HMPC_REFINE_FROM_X
-#define HMPC_REFINE_FROM_X 1  // final refinement: residual at the loop's own iterate instead of a recomputed x(u) (fast variants; +0.8 ... 1.3 %, same soak: profiles/r05/block_round_ab.txt)
-#endif
-#ifndef HMPC_MFS_DEAL_PAIRED
-#define HMPC_MFS_DEAL_PAIRED 1  // 120-variable matrix-core sweeps: tile rows dealt to the waves in pairs (I, 7 - I) instead of contiguous runs (+1.0 ... 1.3 %, profiles/r05/block_round_ab.txt)
-#endif
-#ifndef HMPC_MFS_RCP_NEWTON
-#define HMPC_MFS_RCP_NEWTON 2  // Newton steps after v_rcp_f64 in the LDL' of a 4 x 4 pivot block (1 measured: see profiles/r05)
-#endif
-#ifndef HMPC_MFS_PST_PAD
-#define HMPC_MFS_PST_PAD 18  // padding of a pivot-panel row in doubles (16: the round-4 layout), see MfsPanel
-#endif
-#ifndef HMPC_SCHUR_MFMA
-#define HMPC_SCHUR_MFMA 1  // block start of the fast 256-thread two-contact variants: Schur matrix inverted by 4 x 4 block pivots on the matrix cores (0: two scalar pivots per barrier in registers)
-#endif
-#ifndef HMPC_SCHUR_MFMA_128
-#define HMPC_SCHUR_MFMA_128 0   // ... the 128-thread (single-support) variants: measured, see profiles/r05/schur_128_ab.txt
-#endif
-#ifndef HMPC_SCHUR_MFMA_3C
-#define HMPC_SCHUR_MFMA_3C 1    // ... the fast three-contact variant as well (4 x 4 tiles = 64 rows)
-#endif
-#ifndef HMPC_SCHUR_MFMA_WIDE
-#define HMPC_SCHUR_MFMA_WIDE 1  // ... and the wide variant (5 x 5 tiles on eight waves = 80 rows)
-#endif
-#ifndef HMPC_BLOCK_FRICTION
-#define HMPC_BLOCK_FRICTION 1  // block start also takes friction rows violated at the unconstrained minimiser
+#define HMPC_CONT_ROUNDS 4       // continuation variant: block rounds a resumed solve runs before its single-row iteration (0 .. 4)
 #endif
 namespace hmpc {
 
@@ -452,11 +381,9 @@ constexpr int mfs_owner(int ntg, int nwv, int I, int J) {
       default: return 3;
     }
   }
-#if HMPC_MFS_DEAL_PAIRED
   // 8 x 8 grid on four waves (120 variables): tile rows dealt in pairs I, 7 - I (8 + 1, 7 + 2, 6 + 3, 5 + 4 tiles): every wave
   // touches exactly two tile rows (two A operands per step instead of up to four) and owns two diagonal tiles
   if (ntg == 8 && nwv == 4) return I < 4 ? I : 7 - I;
-#endif
   const int ntiles = ntg * (ntg + 1) / 2, base = ntiles / nwv, rem = ntiles % nwv;
   int t = 0;  // index of (I, J) in block-row-major order
   for (int i = 0; i < I; ++i) t += ntg - i;
@@ -496,10 +423,10 @@ template <int NTG>
 struct MfsPanel {
   // panel row stride in doubles.  Round 4 used 16 NTG + 16 (= 0 mod 32 banks): the four rows of a B-operand read hit different
   // banks, but the column-tile publishes -- four lanes per 16-lane group writing the four panel ROWS at one column -- were 4-way
-  // bank conflicts (LDS conflict cycles 11 % -> 22 % of the LDS-active cycles).  HMPC_MFS_PST_PAD = 18 gives a row
+  // bank conflicts (LDS conflict cycles 11 % -> 22 % of the LDS-active cycles).  MFS_PST_PAD = 18 gives a row
   // stride of 4 mod 32 banks: those writes are conflict-free, a B-operand read costs one extra LDS cycle (two of its 32 lanes
   // meet on a bank).
-  static constexpr int PST = 16 * NTG + HMPC_MFS_PST_PAD;
+  static constexpr int PST = 16 * NTG + MFS_PST_PAD;
   double P[2][4][PST];   // pivot panel rows, double buffered; the K columns carry D - I
   double Dinv[2][4][4];  // inverse of the pivot block
   double Draw[4][4];     // the pivot block itself, as it is (recovering D from the panel's D - I would cost the small pivots --
@@ -560,11 +487,7 @@ __device__ __forceinline__ void mfs_load(MfsAcc<NTG, NWV> &acc, const int n, HIn
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-#ifdef HMPC_MFS_NO_LOAD  // developer switch (timing)
-      hv[t][r] = 0.0f;
-#else
       hv[t][r] = hval(rinf[t][r], cinf[t]);  // (symmetric in its arguments: the lower half of a diagonal tile reads the mirror)
-#endif
     }
   // scaled while still binary32: two multiplications by powers of two (exact; |H| <= 1e3 and |k| <= 12 keep clear of the
   // binary32 range on both sides), the row factors shared by the tiles of a tile row
@@ -674,9 +597,7 @@ __device__ __forceinline__ void mfs_steps(MfsPanel<NTG> &PN, MfsAcc<NTG, NWV> &a
   auto rcp1 = [](double d) __attribute__((always_inline)) -> double {  // v_rcp_f64 (2^-24) + Newton steps (two: last bit; one: 2e-15)
     double r = __builtin_amdgcn_rcp(d);
     r = dfma(dfma(-d, r, 1.0), r, r);
-#if HMPC_MFS_RCP_NEWTON >= 2
-    r = dfma(dfma(-d, r, 1.0), r, r);
-#endif
+    r = dfma(dfma(-d, r, 1.0), r, r);  // (one step measured no faster: profiles/r05/rcp_newton_ab.txt)
     return r;
   };
   // row g of D^-1 for the pivot block just published
@@ -728,14 +649,6 @@ __device__ __forceinline__ void mfs_steps(MfsPanel<NTG> &PN, MfsAcc<NTG, NWV> &a
             v -= (c == c0 + g) ? 1.0 : 0.0;
           }
           P[g][16 * T.j[t] + c] = v;
-#if !HMPC_MFS_PUBLISH_FIRST
-          if (T.j[t] == IK) {  // this wave owns the pivot block: its own LDS writes are visible to it after a wait
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-#ifndef HMPC_MFS_NO_LDL  // developer switch (register pressure)
-            publish_dinv(s);
-#endif
-          }
-#endif
         } else if (T.j[t] == IK) {
           if (c >= c0 && c < c0 + 4) {
 #pragma unroll
@@ -743,7 +656,6 @@ __device__ __forceinline__ void mfs_steps(MfsPanel<NTG> &PN, MfsAcc<NTG, NWV> &a
           }
         }
       }
-#if HMPC_MFS_PUBLISH_FIRST
       // the wave that owns the pivot block inverts it AFTER all of its panel stores are issued: their issue overlaps the LDS
       // round trip of the raw block (with the paired deal the owner publishes its whole tile row)
       {
@@ -752,12 +664,9 @@ __device__ __forceinline__ void mfs_steps(MfsPanel<NTG> &PN, MfsAcc<NTG, NWV> &a
         for (int t = 0; t < CNT; ++t) owner = owner || (T.i[t] == IK && T.j[t] == IK);
         if (owner) {
           __builtin_amdgcn_s_waitcnt(0xc07f);  // this wave's own LDS writes are visible to it after a wait
-#ifndef HMPC_MFS_NO_LDL  // developer switch (register pressure)
           publish_dinv(s);
-#endif
         }
       }
-#endif
     }
   };
   auto publish = [&](const int s) __attribute__((always_inline)) {
@@ -772,11 +681,7 @@ __device__ __forceinline__ void mfs_steps(MfsPanel<NTG> &PN, MfsAcc<NTG, NWV> &a
   };
   publish(0);
   __syncthreads();
-#ifdef HMPC_MFS_NO_STEPS  // developer switch: tile load + re-layout only (timing)
-  const int nsteps = 0;
-#else
   const int nsteps = (n + 3) >> 2;
-#endif
 #pragma unroll 1
   for (int s = 0; s < nsteps; ++s) {
     const int rr = s & 3, Ik = s >> 2;
@@ -784,7 +689,7 @@ __device__ __forceinline__ void mfs_steps(MfsPanel<NTG> &PN, MfsAcc<NTG, NWV> &a
     const double x0 = PN.Dinv[s & 1][g][0], x1 = PN.Dinv[s & 1][g][1], x2 = PN.Dinv[s & 1][g][2], x3 = PN.Dinv[s & 1][g][3];
     // tile(I,J) -= Q_I' P_J, Q = D^-1 P: A operand -Q[g][16 I + c], B operand P[g][16 J + c].
     // groups of GT tiles, the operands of group k+1 read while the matrix instructions of group k run
-    constexpr int GT = (TPW % 3 == 0) ? 3 : (TPW < HMPC_MFS_GT ? TPW : HMPC_MFS_GT), NGRP = (CNT + GT - 1) / GT;
+    constexpr int GT = (TPW % 3 == 0) ? 3 : (TPW < MFS_GT ? TPW : MFS_GT), NGRP = (CNT + GT - 1) / GT;
     double aop[2][GT], bop[2][GT];
     double alast = 0.0;
     auto fetch = [&](const int grp, double (&ao)[GT], double (&bo)[GT]) __attribute__((always_inline)) {
@@ -853,7 +758,6 @@ __device__ __forceinline__ void mfs_relayout(double *stage, MfsAcc<NTG, NWV> &ac
         }
       }
     };
-#ifndef HMPC_MFS_NO_RELAYOUT
     if (RC * p < n) {  // uniform
 #pragma unroll
       for (int t = 0; t < CNT; ++t)
@@ -892,9 +796,7 @@ __device__ __forceinline__ void mfs_relayout(double *stage, MfsAcc<NTG, NWV> &ac
         }
       }
       __syncthreads();
-    } else
-#endif
-    {
+    } else {
       birth();
     }
   }
@@ -1029,7 +931,7 @@ constexpr bool fits_three_waves() {
 //     then stages W and Q as they stand.  Same operands, same instructions: forces and status words are bit-identical to MODE 0's.
 //   A record that differs from its group's first one anywhere but in the trajectory is not solved (HMPC_S_SWEEP_MISMATCH).
 template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC = 2, int BPT = 1, int MODE = 0>
-__global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, QCAP, NC, BPT>()) ? (NT == 128 ? HMPC_WAVES_PER_EU_128 : HMPC_WAVES_PER_EU_256) : 2) void hmpc_kernel(KernelArgs args) {
+__global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, QCAP, NC, BPT>()) ? (NT == 128 ? WAVES_PER_EU_128 : WAVES_PER_EU_256) : 2) void hmpc_kernel(KernelArgs args) {
   using SM = Smem<NMAX, HMAX, NT, QCAP, NC, BPT>;
   constexpr bool SWEEP = (MODE == 1);
   static_assert(!SWEEP || (!ASM_ONLY && BPT == 1 && NC == 2 && QCAP != 0), "command sweeps: the fast two-contact variants");
@@ -1483,11 +1385,11 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // the nominal input ranges that showed as forces up to 9e-5 from qpOASES in the safe pass (7e-8 with scalar pivots), while
   // nominal inputs are unaffected (5.8e-8 either way) and whatever the fast variants get wrong beyond 2e-6 is caught by
   // their KKT check and handed to the safe pass anyway.
-  constexpr bool MFMA_SWEEP = !ASM_ONLY && QCAP != 0 && (HMPC_MFMA_SWEEP && SM::MFS2 && QCAP < NMAX);
+  constexpr bool MFMA_SWEEP = !ASM_ONLY && QCAP != 0 && (SM::MFS2 && QCAP < NMAX);
   // (the 60-variable variants are fast-pass only: the safe pass of two-contact batches runs on the 120-variable safe variants)
   // ... and the fast three-contact variant (180 variables, two blocks per thread): 78 tiles, 20 per wave.  Its staging of H holds
   // the block-diagonals in two passes, so the register blocks are filled as for the scalar sweeps and turned into tiles in stage S.
-  constexpr bool MFMA_SWEEP3 = HMPC_MFMA_SWEEP3 && SM::MFS3 && !ASM_ONLY && QCAP != 0 && QCAP < NMAX;
+  constexpr bool MFMA_SWEEP3 = SM::MFS3 && !ASM_ONLY && QCAP != 0 && QCAP < NMAX;
   constexpr int MFS3_NTG = (NMAX + 15) / 16;
   constexpr int NTILE = NG * (NG + 1) / 2;
   static_assert(NTILE <= BPT * NT && SM::MMAX <= NT && NMAX <= NT, "threads per block / constraint row / variable");
@@ -1561,7 +1463,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       int off[4], vm[4];  // staging offset of the four rows this lane holds inside a block (or its spare word), 1/0
       float al[4];        // alpha on the diagonal entries of the diagonal chain, else 0
     };
-    constexpr bool CHAIN_BALANCE = HMPC_CHAIN_BALANCE && TB == 1 && SM::HSP == 1 && NW == 4 && HMAX <= 10;
+    constexpr bool CHAIN_BALANCE = TB == 1 && SM::HSP == 1 && NW == 4 && HMAX <= 10;
     int chain_lim = nchain, chain_dlo = 0;  // the chains of the current staging pass: idx < chain_lim, diagonals from chain_dlo
     auto setup = [&](int idx, Chain &C) __attribute__((always_inline)) {
       int cidx = idx;
@@ -1941,9 +1843,6 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   double aw[BPT][GS][GS];                                                                  \
   mfs_relayout<MFS3_NTG, NW, W, NMAX, BPT, NT>(stage, acc, n, S.kexp, e0a, e1a, lva, aw);  \
   mfs_move_blocks<BPT>(a, aw);
-#ifdef HMPC_MFS_ONLY_WAVE  // developer switch (register pressure of one wave's code)
-      default: { HMPC_MFS3_WAVE(HMPC_MFS_ONLY_WAVE) } break;
-#else
       case 0: { HMPC_MFS3_WAVE(0) } break;
       case 1: { HMPC_MFS3_WAVE(1) } break;
       case 2: { HMPC_MFS3_WAVE(2) } break;
@@ -1952,7 +1851,6 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       case 5: { HMPC_MFS3_WAVE((NW > 4 ? 5 : 0)) } break;
       case 6: { HMPC_MFS3_WAVE((NW > 4 ? 6 : 0)) } break;
       default: { HMPC_MFS3_WAVE((NW > 4 ? 7 : 0)) } break;
-#endif
 #undef HMPC_MFS3_WAVE
     }
     pk_fence();
@@ -2046,14 +1944,12 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       // every update of this sweep is complete before the barrier: the pivot-row temporaries die here instead of
       // overlapping the next sweep's reads (the compiler would otherwise sink 30 of the 36 FMAs past the barrier and keep
       // two sets of pivot-row registers alive: +30 VGPRs, the difference between two and three workgroups per CU)
-#if HMPC_PIN_SWEEP
 #pragma unroll
       for (int s = 0; s < BPT; ++s)
 #pragma unroll
         for (int ii = 0; ii < GS; ++ii)
 #pragma unroll
           for (int jj = 0; jj < GS; ++jj) asm volatile("" : "+v"(a[s][ii][jj]));
-#endif
       }  // wave_owns
       __syncthreads();
     }
@@ -2193,7 +2089,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   constexpr bool LAZY = (BPT == 2);
   // (the fast 256-thread two-contact variants sit exactly on their 168-register budget: their integer roles are recomputed at
   //  every use as well -- one instruction each -- instead of being the allocator's first victims)
-  constexpr bool LAZY_IDX = LAZY || (NT == 256 && BPT == 1 && NC == 2 && QCAP != 0 && QCAP < NMAX) || (NT == 128 && HMPC_SCHUR_MFMA_128);
+  constexpr bool LAZY_IDX = LAZY || (NT == 256 && BPT == 1 && NC == 2 && QCAP != 0 && QCAP < NMAX);
   const auto c_e = lazy_int<LAZY_IDX>([](int t) { return t >> 3; });
   const auto c_rr = lazy_int<LAZY_IDX>([](int t) { return t & 7; });
   // the lower bound of a row is 0 -- except in the last-resort pass (args.relax != 0), where it is recomputed on use
@@ -2467,17 +2363,17 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     // walking: ~1.6 iterations per solve, nothing to gain; 120 variables: two rounds (a third one is worth <1 % there and its
     // third copy of the phase tips the register allocation of the 168-VGPR variant over: 86 spilled registers, 1.43 -> 1.78 ms);
     // three contacts: three (1.13 -> 1.18 M solves/s over two)
-    constexpr int BLOCK_ROUNDS = (NC == 3) ? HMPC_BLOCK_ROUNDS_3C : ((NT >= 256) ? HMPC_BLOCK_ROUNDS : 1);
+    constexpr int BLOCK_ROUNDS = (NC == 3) ? BLOCK_ROUNDS_3C : ((NT >= 256) ? BLOCK_ROUNDS_2C : 1);
     constexpr int CONT_ROUNDS = HMPC_CONT_ROUNDS;  // block rounds of a resumed solve (the continuation variant: 256 VGPRs, a loop fits)
-    constexpr bool BLOCK_FRICTION = HMPC_BLOCK_FRICTION && NT >= 256;
-    constexpr int BLOCK_MIN_NEW = (NC == 3) ? HMPC_BLOCK_MIN_NEW_3C : HMPC_BLOCK_MIN_NEW;
-    constexpr int EPT = (NC == 3 && NT < 512) ? HMPC_EPT_3C : 5;  // packed-triangle entries per thread during the Schur inversion
-    constexpr int KBMAX_3C = (HMPC_EPT_3C >= 8) ? 63 : ((HMPC_EPT_3C == 7) ? 59 : 54);
+    constexpr bool BLOCK_FRICTION = NT >= 256;
+    constexpr int BLOCK_MIN_NEW = (NC == 3) ? BLOCK_MIN_NEW_3C : BLOCK_MIN_NEW_2C;
+    constexpr int EPT = (NC == 3 && NT < 512) ? EPT_3C : 5;  // packed-triangle entries per thread during the Schur inversion
+    constexpr int KBMAX_3C = (EPT_3C >= 8) ? 63 : ((EPT_3C == 7) ? 59 : 54);
     // Schur matrix of the fast variants on the matrix cores (schur_invert): 3 x 3 tiles = 48 rows for the 120-variable variants,
     // 4 x 4 = 64 rows with three contacts, 5 x 5 = 80 rows for the wide variant (eight waves)
     constexpr int NTGS = (NT >= 512) ? 5 : (NC == 3 ? 4 : (CONT ? 6 : 3));  // (continuation variant: 6 x 6 tiles = its 96 rows)
-    constexpr bool SCHUR_MFMA = HMPC_SCHUR_MFMA && !LONGRUN && (NT >= 256 || HMPC_SCHUR_MFMA_128) && SM::QMAX >= 16 * NTGS &&
-                                (NC == 2 || HMPC_SCHUR_MFMA_3C) && (NT < 512 || HMPC_SCHUR_MFMA_WIDE);
+    // (not the 128-thread variants: measured slower there, profiles/r05/schur_128_ab.txt; not the safe variants: register budget)
+    constexpr bool SCHUR_MFMA = !LONGRUN && NT >= 256 && SM::QMAX >= 16 * NTGS;
     constexpr int KBMAX = SCHUR_MFMA ? 16 * NTGS
                                      : ((NT >= 512) ? 71 : ((NT >= 256) ? (NC == 3 ? (KBMAX_3C < SM::QMAX ? KBMAX_3C : SM::QMAX) : 45) : 34));  // KBMAX(KBMAX+1)/2 <= EPT*NT
     static_assert((SCHUR_MFMA || KBMAX * (KBMAX + 1) / 2 <= EPT * NT) && KBMAX <= SM::QMAX, "block start capacity");
@@ -2578,7 +2474,6 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         const unsigned long long am1 = *reinterpret_cast<const unsigned long long *>(&Q.act[8 * E1(s)]);
         if (am0 != 0ull && am1 != 0ull) {
           const int leg0 = S.ls_leg[E0(s)], leg1 = S.ls_leg[E1(s)];
-#if HMPC_S0_ACTIVE_ROWS
           // Every lane walks over ITS OWN active rows (bit scan of the 8 activity bytes of a leg-step).  Counting r1 and r0 through
           // rlo .. rhi instead made each wave execute the union of its lanes' rows -- nearly all 7 x 7 combinations, a 36-FMA block
           // product each, for the 1-2 rows a leg-step really has (blk:S0 14 k cycles per workgroup).  Same arithmetic per entry.
@@ -2609,25 +2504,6 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
               Eat(Q.slot[8 * E0(s) + r0], s1) = v;
             }
           }
-#else
-          for (int r1 = rlo; r1 <= rhi; ++r1) {
-            const int ac1 = (int)(signed char)((am1 >> (8 * r1)) & 0xff);
-            if (ac1 == 0) continue;
-            double cn1[GS], t6[GS];
-#pragma unroll
-            for (int k = 0; k < GS; ++k) cn1[k] = (double)ac1 * S.Cn[leg1][r1][k];
-            blk_rows(s, cn1, t6);  // (a diagonal block is stored as the full symmetric 6x6)
-            const int s1 = Q.slot[8 * E1(s) + r1];
-            for (int r0 = rlo; r0 <= (DIAG(s) ? r1 : rhi); ++r0) {
-              const int ac0 = (int)(signed char)((am0 >> (8 * r0)) & 0xff);
-              if (ac0 == 0) continue;
-              double v = 0.0;
-#pragma unroll
-              for (int k = 0; k < GS; ++k) v = dfma((double)ac0 * S.Cn[leg0][r0][k], t6[k], v);
-              Eat(Q.slot[8 * E0(s) + r0], s1) = v;
-            }
-          }
-#endif
         }
       }
       if constexpr (SCHUR_MFMA) {  // (cleared before the barrier that ends the formation of S0: the mat-vec staging is free here)
@@ -2810,7 +2686,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         bool cand = false;
         if (tid < q && um < -1e-12) {
           const int c = Q.Wrow[tid];
-          cand = HMPC_FLIP4 && ((c & 7) == 4) && (ANTICYCLE ? (Q.flpc[c] & 1) == 0 : Q.flpc[c] == 0);
+          cand = ((c & 7) == 4) && (ANTICYCLE ? (Q.flpc[c] & 1) == 0 : Q.flpc[c] == 0);
         }
         const double wmin = wave_min(um);
         const unsigned long long b2 = __ballot(um == wmin);
@@ -2923,7 +2799,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   constexpr int REFRESH_EVERY = 48, REFRESH_FINAL = 12;
   // (the continuation variant runs the hard instances -- dozens to hundreds of further working-set changes on top of the fast
   //  variant's -- and rebuilds E periodically as well: on the matrix cores, a refresh costs about four single-row iterations)
-  constexpr bool REFRESHES = LONGRUN || (CONT && HMPC_CONT_REFRESH);
+  constexpr bool REFRESHES = LONGRUN;  // (the continuation variant: measured no difference at 6x, and a seventh instantiation of the round costs it 113 spilled registers)
   int since_refresh = 0;
   for (int pass = 0; pass < (ANTICYCLE ? 8 : 3) && code == S_OK; ++pass) {
     const int iters_at_entry = uni(iters);  // (uniform: a scalar register)
@@ -3189,10 +3065,10 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
 
     // ---- refinement of the multipliers on the final working set: u += E (b_W - N_W x(u)), x(u) = x_u + M N_W' u ----
     for (int it = 0; it <= HMPC_REFINE; ++it) {
-      // (HMPC_REFINE_FROM_X: the first correction takes its residual at the iterate the loop above left -- x was moved along with u
+      // (the first correction takes its residual at the iterate the loop above left -- x was moved along with u
       //  step by step, and what the correction is there to remove is the drift of E's rank-one updates, orders of magnitude above
       //  the difference between that x and x(u) -- instead of recomputing x(u) first: one gather + one product with M less)
-      if (!(HMPC_REFINE_FROM_X && !LONGRUN && it == 0 && HMPC_REFINE > 0)) {
+      if (!(!LONGRUN && it == 0 && HMPC_REFINE > 0)) {
       gather_w(Q.u, 1.0, 0.0);
       __syncthreads();
       rmatvec(Q.w);

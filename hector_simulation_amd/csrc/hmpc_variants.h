@@ -11,12 +11,11 @@
 #ifndef HMPC_QCAP_CONT
 #define HMPC_QCAP_CONT 96  // ... of the CONTINUATION variant of the 120-variable shapes (70 KB LDS: two per CU): takes over the solves whose working set outgrew the fast variant's
 #endif
-#ifndef HMPC_QCAP_WIDE
-#define HMPC_QCAP_WIDE 152 // ... of the 240-variable variant (double support over h = 11 .. 20)
-#endif
-#ifndef HMPC_QCAP_3C
-#define HMPC_QCAP_3C 96    // ... of the fast three-contact variant (256 threads, two register blocks each, <= 80 KB LDS: two per CU)
-#endif
+// (not switches: each is pinned from both sides by the LDS budget and the staging areas that alias the solver state --
+//  static_asserts in hmpc_kernel.h / hmpc_variants.hip -- 152 rows are what 160 KB leave next to the wide variant's mat-vec staging,
+//  96 what 80 KB, two workgroups per CU, leave the three-contact one)
+constexpr int HMPC_QCAP_WIDE = 152;  // ... of the 240-variable variant (double support over h = 11 .. 20)
+constexpr int HMPC_QCAP_3C = 96;     // ... of the fast three-contact variant (256 threads, two register blocks each, <= 80 KB LDS: two per CU)
 
 typedef void (*kernel_fn)(hmpc::KernelArgs);
 

@@ -109,34 +109,33 @@ def test_shard_bounds_in_c_matches_the_python_sharding():
         interface.shard_bounds(10, 2, 2)
 
 
-def test_wrong_numbers_switches_cannot_reach_the_product_library():
-    """The timing switches that leave a stage of the matrix-core sweeps out (HMPC_MFS_NO_LDL & co: wrong results by design) only
-    compile together with -DHMPC_DEV_TIMING, and build.py refuses that flag for the library the package loads."""
-    import subprocess
-
+def test_developer_switches_cannot_reach_the_product_library():
+    """-DHMPC_DEBUG_STATS (debug counters written where the objective value goes) and -DHMPC_PROFILE are developer builds: build.py
+    refuses them for the library the package loads -- also when a library built with them is already there -- unless
+    HMPC_ALLOW_DEV_BUILD=1.  The timing switches of rounds 4-5 that left stages of the kernel out (HMPC_MFS_NO_*) are gone."""
     from hector_simulation_amd import build
 
-    src = os.path.join(ROOT, "hector_simulation_amd", "csrc", "hmpc_variants.hip")
-    base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-E", "-DHMPC_VARIANT_GROUP=0", src, "-o", "/dev/null"]
-    for sw in ("HMPC_MFS_NO_LDL", "HMPC_MFS_NO_STEPS", "HMPC_MFS_NO_LOAD", "HMPC_MFS_NO_RELAYOUT", "HMPC_MFS_ONLY_WAVE=1"):
-        r = subprocess.run(base + ["-D" + sw], capture_output=True, text=True)
-        assert r.returncode != 0 and "HMPC_DEV_TIMING" in r.stderr, sw
-    r = subprocess.run(base + ["-DHMPC_MFS_NO_LDL", "-DHMPC_DEV_TIMING"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-500:]
-    saved, saved_env = build.EXTRA[:], os.environ.pop("HMPC_ALLOW_DEV_TIMING", None)
+    saved, saved_env = build.EXTRA[:], os.environ.pop("HMPC_ALLOW_DEV_BUILD", None)
     try:
-        build.EXTRA[:] = ["-DHMPC_DEV_TIMING", "-DHMPC_MFS_NO_LDL"]
-        with pytest.raises(RuntimeError):
-            build._check_flags()
-        build.EXTRA[:] = ["-DHMPC_MFMA_SWEEP=0"]  # a same-results A/B switch is fine
+        for flag in ("-DHMPC_DEBUG_STATS", "-DHMPC_PROFILE"):
+            build.EXTRA[:] = [flag]
+            with pytest.raises(RuntimeError):
+                build._check_flags()
+            with pytest.raises(RuntimeError):
+                build.build()  # (checked before the "library is up to date" shortcut)
+        build.EXTRA[:] = ["-DHMPC_CONT_ROUNDS=2"]  # a same-results tuning switch is fine
+        build._check_flags()
+        os.environ["HMPC_ALLOW_DEV_BUILD"] = "1"
+        build.EXTRA[:] = ["-DHMPC_DEBUG_STATS"]
         build._check_flags()
     finally:
         build.EXTRA[:] = saved
+        os.environ.pop("HMPC_ALLOW_DEV_BUILD", None)
         if saved_env is not None:
-            os.environ["HMPC_ALLOW_DEV_TIMING"] = saved_env
-    # the removed 60-variable matrix-core path has left no plumbing behind
+            os.environ["HMPC_ALLOW_DEV_BUILD"] = saved_env
     ksrc = open(os.path.join(ROOT, "hector_simulation_amd", "csrc", "hmpc_kernel.h")).read()
-    assert "HMPC_MFMA_SWEEP1" not in ksrc and "MFS1" not in ksrc
+    for gone in ("HMPC_MFS_NO_", "HMPC_MFS_ONLY_WAVE", "HMPC_DEV_TIMING", "HMPC_MFMA_SWEEP1", "HMPC_FLIP4", "HMPC_PIN_SWEEP", "HMPC_S0_ACTIVE_ROWS"):
+        assert gone not in ksrc, gone
 
 
 def test_every_kernel_variant_is_built_by_exactly_one_translation_unit():
