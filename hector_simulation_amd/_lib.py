@@ -69,10 +69,11 @@ def load():
     path = _build.build()
     if not os.path.exists(path):
         raise RuntimeError("libhector_mpc_hip.so is missing and could not be built; the solver has no fallback path")
-    # PyTorch-ROCm ships its own libamdhip64; this library links the system one.  When both end up in one Python process
-    # the order matters: torch's runtime first is the combination that works (bench.py's order); ours first has been seen
-    # to leave torch with "no ROCm-capable device".  So if torch is installed, let it come up first.  (A C++ host such as
-    # the reference controller has no torch in the process and none of this applies.)
+    # ONE HIP runtime per process: PyTorch-ROCm bundles a libamdhip64.so.7 and this library's DT_NEEDED names the same SONAME, so the
+    # copy the loader maps first serves both.  torch first = torch's bundled runtime for both (works; bench.py's order); this library
+    # first = the system runtime for both, on which torch has been seen to report "no ROCm-capable device".  So if torch is installed,
+    # let it come up first.  (A C++ host such as the reference controller has no torch in the process: the system runtime, the one the
+    # library was built against, serves it.  tests/test_gpu_runtime.py asserts the single mapping.)
     if os.environ.get("HMPC_NO_TORCH_PRELOAD") != "1":
         try:
             import torch

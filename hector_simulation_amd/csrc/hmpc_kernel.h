@@ -45,15 +45,35 @@
 
 #include "hmpc_kernel_args.h"
 
+namespace hmpc {
+// per-phase shader-clock profile of developer builds (-DHMPC_PROFILE, scripts/phase_profile.py); an empty object otherwise
 #ifdef HMPC_PROFILE
-#define PROF_DECL long long _pt = clock64(), _pt0 = _pt; long long _pacc[NPROF] = {0}
-#define PROF_MARK(ph) do { long long _n = clock64(); _pacc[ph] += _n - _pt; _pt = _n; } while (0)
-#define PROF_FLUSH() do { if (threadIdx.x == 0 && args.prof) { _pacc[P_TOTAL] = clock64() - _pt0; for (int _i = 0; _i < NPROF; ++_i) args.prof[(size_t)inst * NPROF + _i] = _pacc[_i]; } } while (0)
+struct Prof {
+  long long pt, pt0, acc[NPROF];
+  __device__ __forceinline__ Prof() : pt(clock64()), pt0(pt) {
+    for (int i = 0; i < NPROF; ++i) acc[i] = 0;
+  }
+  __device__ __forceinline__ void mark(int ph) {
+    const long long n = clock64();
+    acc[ph] += n - pt;
+    pt = n;
+  }
+  __device__ __forceinline__ void flush(const KernelArgs &args, int inst) {
+    if (threadIdx.x == 0 && args.prof) {
+      acc[P_TOTAL] = clock64() - pt0;
+      for (int i = 0; i < NPROF; ++i) args.prof[(size_t)inst * NPROF + i] = acc[i];
+    }
+  }
+};
+#define PROF_MARK(ph) prof.mark(ph)
+#define PROF_FLUSH() prof.flush(args, inst)
 #else
-#define PROF_DECL
+struct Prof {};
 #define PROF_MARK(ph)
 #define PROF_FLUSH()
 #endif
+#define PROF_DECL Prof prof
+}  // namespace hmpc
 
 namespace hmpc {
 
@@ -919,117 +939,25 @@ constexpr bool fits_three_waves() {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// MODE 0: the product path, one workgroup = one independent instance.
-// MODE 1: COMMAND SWEEPS (hmpc_solve_command_sweep).  The batch is groups of args.sweep_k consecutive records that share
-// everything but the reference trajectory -- state, feet, joints, weights, gait table (ConvexMPCLocomotion.cpp:351-406 builds the
-// trajectory from the commands; SolverMPC.cpp:398-447, 488-570 builds A_qp, B_qp, H and the constraint block from the state and
-// the gait alone) -- so H and its inverse M are a property of the GROUP.  Two launches of this kernel:
-//   phase 0 (args.sweep_phase == 0), one workgroup per group: stages A, H, S on the group's first record, M written to the
-//     group's slot in HBM (36 x NT doubles, the register blocks' own layout, coalesced), nothing else;
-//   phase 1, one workgroup per INSTANCE (the chip stays as full as for independent solves): stage A on the instance's own
-//     record (its own g, the same chains), M read from its group's slot instead of stages H and S (55 % of an independent solve),
-//     then stages W and Q as they stand.  Same operands, same instructions: forces and status words are bit-identical to MODE 0's.
-//   A record that differs from its group's first one anywhere but in the trajectory is not solved (HMPC_S_SWEEP_MISMATCH).
-template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC = 2, int BPT = 1, int MODE = 0>
-__global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, QCAP, NC, BPT>()) ? (NT == 128 ? WAVES_PER_EU_128 : WAVES_PER_EU_256) : 2) void hmpc_kernel(KernelArgs args) {
+// ---------------------------------------------------------------------------------------------------------------
+// Stage A1 + A2 of the kernel as a function.  In: the instance's packed record in S.u.a.rec (stage A0), the robot constants in
+// args.  Out, in LDS: the trigonometric tables, x0, Acd, Bcd, the weights W and the per-step constraint block Fc (Smem::Asm);
+// the per-contact constraint normals Cn, the stance prefix counts and every index table of the swing elimination, ub7 / sc7, n, m,
+// nls (Smem's persistent part); the identity power Apow[0].  Ends with a barrier.
+template <int NMAX, int HMAX, int NT, int QCAP, int NC, int BPT>
+__device__ __forceinline__ void stage_a_scalars(Smem<NMAX, HMAX, NT, QCAP, NC, BPT> &S, const KernelArgs &args, const int inst, const int h, Prof &prof) {
   using SM = Smem<NMAX, HMAX, NT, QCAP, NC, BPT>;
-  constexpr bool SWEEP = (MODE == 1);
-  static_assert(!SWEEP || (!ASM_ONLY && BPT == 1 && NC == 2 && QCAP != 0), "command sweeps: the fast two-contact variants");
   using RL = RecLayout<NC>;
-  constexpr int NG = SM::NG, NW = SM::NW, U = SM::U, PS = SM::PS, C8 = 8 * NC;
-  static_assert(NC == 2 || (NC == 3 && NT * BPT >= 512), "contacts: two feet (reference) or two feet + hand (extension)");
-  static_assert(BPT == 1 || BPT == 2, "register blocks per thread");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  SM &S = *reinterpret_cast<SM *>(smem_raw);
+  constexpr int NG = SM::NG, U = SM::U, PS = SM::PS, C8 = 8 * NC;
   auto &A = S.u.a;
-  auto &Q = S.u.s;
-  // the packed Schur inverse: LDS, or this workgroup's slice of the global scratch
-  double *const Ep = [&]() __attribute__((always_inline)) -> double * {
-    if constexpr (SM::EGLOBAL) return args.e_scratch + (size_t)blockIdx.x * (size_t)(NMAX * (NMAX + 1) / 2);
-    else return S.u.s.Ep;
-  }();
-  auto Eat = [&](int i, int j) __attribute__((always_inline)) -> double & {
-    const int lo = i < j ? i : j, hi = i < j ? j : i;
-    return Ep[(unsigned)(hi * (hi + 1) / 2 + lo)];  // (unsigned: a scalar base + 32-bit lane offset when E is in global memory)
-  };
-
-  const int tid = threadIdx.x, wv = uni(tid >> 6);
-  const auto ln = lazy_int<(BPT == 2)>([](int t) { return t & 63; });  // lane (recomputed at every use in the two-block variants)
-  if (!ASM_ONLY && args.list_count && blockIdx.x >= *args.list_count) return;  // device-side safe pass: nothing (more) flagged
-  // (uniform by construction -- but when it comes from the index list it arrives through a vector load: told to the compiler, so
-  //  that the instance's base addresses are scalar arithmetic instead of register pairs that live for the whole kernel)
-  const int inst = uni(ASM_ONLY ? args.dbg_index
-                                : ((SWEEP && args.sweep_phase == 0) ? (int)blockIdx.x * args.sweep_k  // the group's first record
-                                                                    : (args.index_list ? args.index_list[blockIdx.x] : (int)blockIdx.x)));
-  const int h = args.horizon;
-  if (inst >= args.batch) return;
-  // command sweeps: M comes from (phase 1) or goes to (phase 0) this group's slot
-  const bool sweep_prepare = SWEEP && args.sweep_phase == 0, sweep_given = SWEEP && args.sweep_phase != 0;
-  double *const sweep_m = SWEEP ? args.sweep_m + (size_t)(inst / (SWEEP ? args.sweep_k : 1)) * (size_t)(GS * GS * NT) : nullptr;
-  if (!ASM_ONLY && args.cls) {  // uniform: this instance belongs to another variant's launch
-    const int c = args.cls[inst];
-    if (c < args.cls_lo || c > args.cls_hi) return;
-  }
-  PROF_DECL;
-  // Hand-over of a full working set (KernelArgs::spill, SpillLayout): the fast 120-variable variants SAVE their state, the safe
-  // variants of the same shape (working set = variable count, in LDS) RESUME from it -- they assemble the instance again (index
-  // tables, constraint normals, g: cheap and bit-identical), then take M, E and the Goldfarb-Idnani state from the slot instead of
-  // running stages H, S and the start
-  constexpr bool SHAPE_HANDOVER = !ASM_ONLY && NMAX == 120 && NT == 256 && NC == 2 && BPT == 1 && !SM::EGLOBAL;
-  constexpr bool SPILLS = SHAPE_HANDOVER && QCAP < HMPC_QCAP_CONT;      // the fast variants (working set of 64 rows, three per CU)
-  // the continuation variant (96 rows, two per CU): takes over what the fast variants hand over, with block rounds of its own (up to
-  // its 96 rows at once, the Schur matrix as 6 x 6 tiles on the matrix cores), and flags what outgrows it in turn for the safe variant
-  constexpr bool RESUMABLE = SHAPE_HANDOVER && QCAP >= HMPC_QCAP_CONT && QCAP < NMAX;
-  constexpr bool CONT = RESUMABLE;
-  using SPL = SpillLayout<SM, NT, BPT>;
-  bool resumed = false;
-  if constexpr (RESUMABLE) {
-    // (the slot must be this instance's own and its status word must still say "working set full": both are written by the fast
-    //  variant in the same solve; anything else -- a stale entry of an earlier batch -- starts cold)
-    if (args.resume) resumed = ub(args.spill_slot[inst] == inst && inst < args.spill_cap && (args.status[inst] & 0xffu) == (uint32_t)S_WORKSET);
-    if (args.resume == 2 && !resumed) return;  // a continuation-only launch: everything else on the list is the safe variant's
-  }
-  if constexpr (!ASM_ONLY && (SM::EGLOBAL || (QCAP >= NMAX && NMAX >= 120))) {  // (the safe-pass variants)
-    if (args.skip_ok) {  // second pass over a list of flagged instances: what the pass before it solved is left alone
-      const uint32_t c0 = args.status[inst] & 0xffu;
-      if (c0 == (uint32_t)S_OK || c0 == (uint32_t)S_OK_RELAXED) return;
-    }
-  }
-
-  // ---------------- A0: one coalesced burst brings the instance's record into LDS ----------------
-  {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(args.records + (size_t)inst * args.stride);
-    const int nwords = args.stride >> 2;
-    for (int t = tid; t < nwords; t += NT) A.rec[t] = src[t];
-  }
-  if constexpr (SWEEP) {
-    if (sweep_given) {
-      // every word of the record but the trajectory must equal the group's first record's (whose M this solve uses)
-      const int first = (inst / args.sweep_k) * args.sweep_k;
-      const uint32_t *base = reinterpret_cast<const uint32_t *>(args.records + (size_t)first * args.stride);
-      const int nfix = RL::NF, ntraj = 12 * args.horizon, ngw = (NC * args.horizon + 3) >> 2;
-      const uint32_t *own = reinterpret_cast<const uint32_t *>(args.records + (size_t)inst * args.stride);
-      int bad = 0;
-      for (int t = tid; t < nfix + ngw; t += NT) {
-        const int w = t < nfix ? t : t + ntraj;
-        bad |= (own[w] != base[w]) ? 1 : 0;
-      }
-      if (__syncthreads_or(bad)) {  // uniform
-        for (int t = tid; t < 6 * NC * args.horizon; t += NT) args.forces[(size_t)inst * 6 * NC * args.horizon + t] = 0.0f;
-        if (tid == 0) args.status[inst] = S_SWEEP_MISMATCH;
-        return;
-      }
-    }
-  }
-  __syncthreads();
-  PROF_MARK(P_A0);
+  const int tid = threadIdx.x;
+  (void)prof;
   const float *rf = reinterpret_cast<const float *>(A.rec);
   const unsigned char *gait = reinterpret_cast<const unsigned char *>(A.rec + RL::NF + 12 * h);
   const float *in_p = rf + RL::P, *in_v = rf + RL::V, *in_q = rf + RL::Q, *in_w = rf + RL::W, *in_r = rf + RL::R,
-              *in_ja = rf + RL::JA, *in_wt = rf + RL::WT, *in_al = rf + RL::AL, *in_traj = rf + RL::NF;
+              *in_ja = rf + RL::JA, *in_wt = rf + RL::WT;
   // Fz cap of a contact: f_max for the feet; the hand's own cap travels in the extension record
   auto fz_cap = [&](int c) __attribute__((always_inline)) -> float { return (NC == 3 && c == 2) ? rf[RL::FMH] : args.f_max; };
-
   // ---------------- A1: trigonometry, one lane per angle (SolverMPC.cpp:374-393, 333-342, 74-85); a lane of another
   // wave builds the swing-leg elimination tables meanwhile (SolverMPC.cpp:589-637)
   {
@@ -1279,22 +1207,21 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   // identity power
   for (int t = tid; t < 169; t += NT) A.Apow[t] = (t % 14 == 0) ? 1.0f : 0.0f;
   __syncthreads();
-  PROF_MARK(P_A2);
+}
 
-  const int n = uni(S.n), m = uni(S.m), ng = uni(S.nls);
-  if (ng > NG) {  // uniform
-    if (!ASM_ONLY) {
-      for (int t = tid; t < U * h; t += NT) args.forces[(size_t)inst * U * h + t] = 0.0f;
-      if (args.wset)  // nothing to carry to the next tick from an instance that was not solved
-        for (int t = tid; t < C8 * h; t += NT) args.wset[(size_t)inst * C8 * h + t] = 0;
-      if (tid == 0) args.status[inst] = S_TOO_LARGE;
-    } else if (tid == 0) {
-      args.dbg_i[0] = n;
-      args.dbg_i[1] = m;
-    }
-    return;
-  }
-
+// ---------------------------------------------------------------------------------------------------------------
+// Stages A3 / A4 and the gradient as a function.  In (LDS, Smem::Asm): Acd, Bcd, x0, W, the identity in Apow[0], the record's
+// trajectory; the reference-order index tables vstep / vcomp / o2s.  Out: Phi_k = Acd^k Bcd for k < h, the tracking error e
+// (Smem::Asm) and g in sweep order (Smem::g, binary64 copy of the binary32 value).  n = reduced variables of the instance.
+template <int NMAX, int HMAX, int NT, int QCAP, int NC, int BPT>
+__device__ __forceinline__ void stage_a_chains(Smem<NMAX, HMAX, NT, QCAP, NC, BPT> &S, const KernelArgs &args, const int inst, const int h, const int n, Prof &prof) {
+  using SM = Smem<NMAX, HMAX, NT, QCAP, NC, BPT>;
+  using RL = RecLayout<NC>;
+  constexpr int U = SM::U, PS = SM::PS;
+  auto &A = S.u.a;
+  const int tid = threadIdx.x;
+  (void)prof;
+  const float *in_traj = reinterpret_cast<const float *>(A.rec) + RL::NF;
   // ---------------- A3/A4: Acd^k by repeated right-multiplication from the identity (SolverMPC.cpp:148-158), and from each
   // power as it appears: Phi_k = Acd^k Bcd (:161-178), SPhi = fl(w_s Phi) (B'S first, as B'*S*B evaluates left to right),
   // tracking error e_i = Acd^(i+1) x0 - X_d (:457-461, :570).  Only two powers are kept (ping-pong).
@@ -1377,6 +1304,138 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     S.g[S.o2s[tid]] = args.ext_g ? (double)args.ext_g[(size_t)inst * args.ext_ld + tid] : (double)(2.0f * acc);
   }
   PROF_MARK(P_G);
+}
+
+// MODE 0: the product path, one workgroup = one independent instance.
+// MODE 1: COMMAND SWEEPS (hmpc_solve_command_sweep).  The batch is groups of args.sweep_k consecutive records that share
+// everything but the reference trajectory -- state, feet, joints, weights, gait table (ConvexMPCLocomotion.cpp:351-406 builds the
+// trajectory from the commands; SolverMPC.cpp:398-447, 488-570 builds A_qp, B_qp, H and the constraint block from the state and
+// the gait alone) -- so H and its inverse M are a property of the GROUP.  Two launches of this kernel:
+//   phase 0 (args.sweep_phase == 0), one workgroup per group: stages A, H, S on the group's first record, M written to the
+//     group's slot in HBM (36 x NT doubles, the register blocks' own layout, coalesced), nothing else;
+//   phase 1, one workgroup per INSTANCE (the chip stays as full as for independent solves): stage A on the instance's own
+//     record (its own g, the same chains), M read from its group's slot instead of stages H and S (55 % of an independent solve),
+//     then stages W and Q as they stand.  Same operands, same instructions: forces and status words are bit-identical to MODE 0's.
+//   A record that differs from its group's first one anywhere but in the trajectory is not solved (HMPC_S_SWEEP_MISMATCH).
+template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC = 2, int BPT = 1, int MODE = 0>
+__global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, QCAP, NC, BPT>()) ? (NT == 128 ? WAVES_PER_EU_128 : WAVES_PER_EU_256) : 2) void hmpc_kernel(KernelArgs args) {
+  using SM = Smem<NMAX, HMAX, NT, QCAP, NC, BPT>;
+  constexpr bool SWEEP = (MODE == 1);
+  static_assert(!SWEEP || (!ASM_ONLY && BPT == 1 && NC == 2 && QCAP != 0), "command sweeps: the fast two-contact variants");
+  using RL = RecLayout<NC>;
+  constexpr int NG = SM::NG, NW = SM::NW, U = SM::U, PS = SM::PS, C8 = 8 * NC;
+  static_assert(NC == 2 || (NC == 3 && NT * BPT >= 512), "contacts: two feet (reference) or two feet + hand (extension)");
+  static_assert(BPT == 1 || BPT == 2, "register blocks per thread");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  SM &S = *reinterpret_cast<SM *>(smem_raw);
+  auto &A = S.u.a;
+  auto &Q = S.u.s;
+  // the packed Schur inverse: LDS, or this workgroup's slice of the global scratch
+  double *const Ep = [&]() __attribute__((always_inline)) -> double * {
+    if constexpr (SM::EGLOBAL) return args.e_scratch + (size_t)blockIdx.x * (size_t)(NMAX * (NMAX + 1) / 2);
+    else return S.u.s.Ep;
+  }();
+  auto Eat = [&](int i, int j) __attribute__((always_inline)) -> double & {
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    return Ep[(unsigned)(hi * (hi + 1) / 2 + lo)];  // (unsigned: a scalar base + 32-bit lane offset when E is in global memory)
+  };
+
+  const int tid = threadIdx.x, wv = uni(tid >> 6);
+  const auto ln = lazy_int<(BPT == 2)>([](int t) { return t & 63; });  // lane (recomputed at every use in the two-block variants)
+  if (!ASM_ONLY && args.list_count && blockIdx.x >= *args.list_count) return;  // device-side safe pass: nothing (more) flagged
+  // (uniform by construction -- but when it comes from the index list it arrives through a vector load: told to the compiler, so
+  //  that the instance's base addresses are scalar arithmetic instead of register pairs that live for the whole kernel)
+  const int inst = uni(ASM_ONLY ? args.dbg_index
+                                : ((SWEEP && args.sweep_phase == 0) ? (int)blockIdx.x * args.sweep_k  // the group's first record
+                                                                    : (args.index_list ? args.index_list[blockIdx.x] : (int)blockIdx.x)));
+  const int h = args.horizon;
+  if (inst >= args.batch) return;
+  // command sweeps: M comes from (phase 1) or goes to (phase 0) this group's slot
+  const bool sweep_prepare = SWEEP && args.sweep_phase == 0, sweep_given = SWEEP && args.sweep_phase != 0;
+  double *const sweep_m = SWEEP ? args.sweep_m + (size_t)(inst / (SWEEP ? args.sweep_k : 1)) * (size_t)(GS * GS * NT) : nullptr;
+  if (!ASM_ONLY && args.cls) {  // uniform: this instance belongs to another variant's launch
+    const int c = args.cls[inst];
+    if (c < args.cls_lo || c > args.cls_hi) return;
+  }
+  PROF_DECL;
+  // Hand-over of a full working set (KernelArgs::spill, SpillLayout): the fast 120-variable variants SAVE their state, the safe
+  // variants of the same shape (working set = variable count, in LDS) RESUME from it -- they assemble the instance again (index
+  // tables, constraint normals, g: cheap and bit-identical), then take M, E and the Goldfarb-Idnani state from the slot instead of
+  // running stages H, S and the start
+  constexpr bool SHAPE_HANDOVER = !ASM_ONLY && NMAX == 120 && NT == 256 && NC == 2 && BPT == 1 && !SM::EGLOBAL;
+  constexpr bool SPILLS = SHAPE_HANDOVER && QCAP < HMPC_QCAP_CONT;      // the fast variants (working set of 64 rows, three per CU)
+  // the continuation variant (96 rows, two per CU): takes over what the fast variants hand over, with block rounds of its own (up to
+  // its 96 rows at once, the Schur matrix as 6 x 6 tiles on the matrix cores), and flags what outgrows it in turn for the safe variant
+  constexpr bool RESUMABLE = SHAPE_HANDOVER && QCAP >= HMPC_QCAP_CONT && QCAP < NMAX;
+  constexpr bool CONT = RESUMABLE;
+  using SPL = SpillLayout<SM, NT, BPT>;
+  bool resumed = false;
+  if constexpr (RESUMABLE) {
+    // (the slot must be this instance's own and its status word must still say "working set full": both are written by the fast
+    //  variant in the same solve; anything else -- a stale entry of an earlier batch -- starts cold)
+    if (args.resume) resumed = ub(args.spill_slot[inst] == inst && inst < args.spill_cap && (args.status[inst] & 0xffu) == (uint32_t)S_WORKSET);
+    if (args.resume == 2 && !resumed) return;  // a continuation-only launch: everything else on the list is the safe variant's
+  }
+  if constexpr (!ASM_ONLY && (SM::EGLOBAL || (QCAP >= NMAX && NMAX >= 120))) {  // (the safe-pass variants)
+    if (args.skip_ok) {  // second pass over a list of flagged instances: what the pass before it solved is left alone
+      const uint32_t c0 = args.status[inst] & 0xffu;
+      if (c0 == (uint32_t)S_OK || c0 == (uint32_t)S_OK_RELAXED) return;
+    }
+  }
+
+  // ---------------- A0: one coalesced burst brings the instance's record into LDS ----------------
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(args.records + (size_t)inst * args.stride);
+    const int nwords = args.stride >> 2;
+    for (int t = tid; t < nwords; t += NT) A.rec[t] = src[t];
+  }
+  if constexpr (SWEEP) {
+    if (sweep_given) {
+      // every word of the record but the trajectory must equal the group's first record's (whose M this solve uses)
+      const int first = (inst / args.sweep_k) * args.sweep_k;
+      const uint32_t *base = reinterpret_cast<const uint32_t *>(args.records + (size_t)first * args.stride);
+      const int nfix = RL::NF, ntraj = 12 * args.horizon, ngw = (NC * args.horizon + 3) >> 2;
+      const uint32_t *own = reinterpret_cast<const uint32_t *>(args.records + (size_t)inst * args.stride);
+      int bad = 0;
+      for (int t = tid; t < nfix + ngw; t += NT) {
+        const int w = t < nfix ? t : t + ntraj;
+        bad |= (own[w] != base[w]) ? 1 : 0;
+      }
+      if (__syncthreads_or(bad)) {  // uniform
+        for (int t = tid; t < 6 * NC * args.horizon; t += NT) args.forces[(size_t)inst * 6 * NC * args.horizon + t] = 0.0f;
+        if (tid == 0) args.status[inst] = S_SWEEP_MISMATCH;
+        return;
+      }
+    }
+  }
+  __syncthreads();
+  PROF_MARK(P_A0);
+  const float *rf = reinterpret_cast<const float *>(A.rec);
+  const unsigned char *gait = reinterpret_cast<const unsigned char *>(A.rec + RL::NF + 12 * h);
+  const float *in_al = rf + RL::AL;  // (alpha: the diagonal of H, stage A5)
+  // Fz cap of a contact: f_max for the feet; the hand's own cap travels in the extension record (the assembly-only dump's bounds)
+  auto fz_cap = [&](int c) __attribute__((always_inline)) -> float { return (NC == 3 && c == 2) ? rf[RL::FMH] : args.f_max; };
+
+  // ---------------- A1 + A2: trigonometry, scalar algebra, constraint block, elimination tables (stage_a_scalars above)
+  stage_a_scalars<NMAX, HMAX, NT, QCAP, NC, BPT>(S, args, inst, h, prof);
+  PROF_MARK(P_A2);
+
+  const int n = uni(S.n), m = uni(S.m), ng = uni(S.nls);
+  if (ng > NG) {  // uniform
+    if (!ASM_ONLY) {
+      for (int t = tid; t < U * h; t += NT) args.forces[(size_t)inst * U * h + t] = 0.0f;
+      if (args.wset)  // nothing to carry to the next tick from an instance that was not solved
+        for (int t = tid; t < C8 * h; t += NT) args.wset[(size_t)inst * C8 * h + t] = 0;
+      if (tid == 0) args.status[inst] = S_TOO_LARGE;
+    } else if (tid == 0) {
+      args.dbg_i[0] = n;
+      args.dbg_i[1] = m;
+    }
+    return;
+  }
+
+  // ---------------- A3/A4 + g: powers of Acd, Phi_k, tracking error, gradient (stage_a_chains above)
+  stage_a_chains<NMAX, HMAX, NT, QCAP, NC, BPT>(S, args, inst, h, n, prof);
   // ---- register blocks of the sweeps (stage S): thread t owns the 6x6 blocks number t, t + NT, ... (< NG(NG+1)/2) of the
   // symmetric matrix in sweep order, block-row-major: (e0, e1), e0 <= e1.  Declared here because the blocks are filled
   // straight from the staging area of H, pass by pass where that area holds only part of the block-diagonals at a time.

@@ -128,7 +128,8 @@ int hmpc_create(hmpc_handle **out, const struct problem_setup *setup, int max_ba
 struct hmpc_params {
   float mass;       /* 9.0                      SolverMPC.cpp:423  (B_ct: v' += F / mass) */
   float inertia[3]; /* 0.5413, 0.5200, 0.0691   RobotState.cpp:45  (body inertia, diagonal) */
-  float mu;         /* 2.0                      SolverMPC.cpp:488  (friction pyramid rows 0-3; problem_setup.mu is ignored, as in the reference) */
+  float mu;         /* 2.0                      SolverMPC.cpp:488  (friction pyramid rows 0-3 are (-+mu, 0, 1) F >= 0, i.e. |F_t| <= F_z / mu: the
+                                                 reference's 2.0 is a friction coefficient of 0.5 -- convention kept; problem_setup.mu is ignored, as there) */
   float lt, lh;     /* 0.09, 0.06               SolverMPC.cpp:489-490 (toe / heel lever arms of the line-contact rows 5, 6) */
   float gravity;    /* 9.81                     SolverMPC.cpp:420  (the constant 13th state) */
 };

@@ -34,7 +34,7 @@ python scripts/stress.py 2>/dev/null | grep -v amdgpu > $O/stress.txt
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/gpu_tests.txt
 # (1) last: the bench lines read profiles/hbm_traffic.json, which only counts for the build it was taken on -- refresh it
 # from the PMC passes above first (on this box's copy of the tree; the caller runs the summary again on its own copy)
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 python scripts/summarize_rocprof.py $ROUND > /dev/null 2>&1
 python bench.py --steps 20 --warmup 3 > $O/bench_standing.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 3 --gait walking --no-cpu-baseline > $O/bench_walking.json 2>> $O/bench.err
@@ -47,10 +47,8 @@ find $O -name '*_agent_info.csv' -delete
 cat $O/bench_standing.json | cut -c1-600
 head -3 $O/kt/kt_kernel_stats.csv
 ls $O
-# A/B kept for the record: one Newton step instead of two after v_rcp_f64 in the pivot block's LDL' (timing + accuracy at 10x)
-cp hector_simulation_amd/libhector_mpc_hip.so /tmp/keep.so; cp hector_simulation_amd/libhector_mpc_hip.so.srchash /tmp/keep.hash
-( echo "== product build"; python scripts/quick_times.py standing_b8192 h20_single_b4096 3contact_b8192 2>&1 | grep -v amdgpu
-  echo "== -DHMPC_MFS_RCP_NEWTON=1"; HMPC_EXTRA_FLAGS="-DHMPC_MFS_RCP_NEWTON=1" python scripts/quick_times.py standing_b8192 h20_single_b4096 3contact_b8192 2>&1 | grep -v amdgpu
-  HMPC_EXTRA_FLAGS="-DHMPC_MFS_RCP_NEWTON=1" python scripts/dev/stress_120.py 512 2>/dev/null | grep -v amdgpu ) > $O/rcp_newton_ab.txt
-cp /tmp/keep.so hector_simulation_amd/libhector_mpc_hip.so; cp /tmp/keep.hash hector_simulation_amd/libhector_mpc_hip.so.srchash
+# round 6: what an off-nominal batch costs (fast pass, device repair with / without the hand-over), what the continuation pass alone leaves
+python scripts/dev/range_scale.py 2>/dev/null | grep -v amdgpu > $O/range_scale.txt
+python scripts/dev/range_scale.py 4096 single 20 2>/dev/null | grep -v amdgpu >> $O/range_scale.txt
+( python scripts/dev/cont_probe.py 3; python scripts/dev/cont_probe.py 6; python scripts/dev/cont_probe.py 10 ) 2>/dev/null | grep -v amdgpu > $O/continuation_pass.txt
 ls $O

@@ -10,10 +10,19 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 OUT=gpurun_out/sanitize; mkdir -p $OUT
 RT=$(find /opt/rocm/lib/llvm -name 'libclang_rt.asan-x86_64.so' | head -1)
 SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g"
-hipcc --offload-arch=gfx950 -O1 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -Wno-pass-failed $SAN -fno-gpu-sanitize \
-  -shared-libsan hector_simulation_amd/csrc/hmpc_capi.hip hector_simulation_amd/csrc/hmpc_group.hip \
-  $(for g in 0 1 2 3; do hipcc --offload-arch=gfx950 -O1 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value -Wno-pass-failed -DHMPC_VARIANT_GROUP=$g -c hector_simulation_amd/csrc/hmpc_variants.hip -o $OUT/hmpc_variants_$g.o && echo $OUT/hmpc_variants_$g.o; done) \
-  -ldl -o $OUT/libhector_mpc_hip.so || exit 2
+# (every translation unit to an object first: handed to one hipcc command together with .hip sources, the objects would be parsed as HIP)
+CF="--offload-arch=gfx950 -O1 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value -Wno-pass-failed"
+pids=""
+for src in hmpc_capi hmpc_group; do
+  hipcc $CF $SAN -fno-gpu-sanitize -c hector_simulation_amd/csrc/$src.hip -o $OUT/$src.o & pids="$pids $!"
+done
+for g in 0 1 2 3; do
+  hipcc $CF -DHMPC_VARIANT_GROUP=$g -c hector_simulation_amd/csrc/hmpc_variants.hip -o $OUT/hmpc_variants_$g.o & pids="$pids $!"
+done
+for p in $pids; do wait $p || exit 2; done
+hipcc --offload-arch=gfx950 -shared -fPIC $SAN -fno-gpu-sanitize -shared-libsan $OUT/hmpc_capi.o $OUT/hmpc_group.o $OUT/hmpc_variants_0.o $OUT/hmpc_variants_1.o \
+  $OUT/hmpc_variants_2.o $OUT/hmpc_variants_3.o -ldl -o $OUT/libhector_mpc_hip.so || exit 2
+rm -f $OUT/*.o
 CLANG=$(dirname $(dirname "$RT"))/../../../bin/clang
 [ -x "$CLANG" ] || CLANG=/opt/rocm/lib/llvm/bin/clang
 fail=0
@@ -44,6 +53,7 @@ run legacy_tick "-x c++ -std=c++17" examples/legacy_tick.cpp
 run batched "-x c -std=c11" examples/batched.c
 run batched_multi "-x c -std=c11" examples/batched_multi.c 3 p2p
 run batched_multi_3contact "-x c -std=c11" examples/batched_multi.c 4 p2p 3
+run friction_sweep "-x c -std=c11" examples/friction_sweep.c
 # The RCCL transport (group of one).  Since round 3 this build of ROCm's ASan runtime trips over one of ITS OWN internal
 # checks while the process exits -- "sanitizer_allocator_device.h:125 CHECK failed: !dev_runtime_unloaded_", raised under
 # __cxa_finalize -> libamdhip64 -> libhsa-runtime64 with no frame of this library -- whenever librccl is loaded next to the

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 def main():
     from hector_simulation_amd import build as hip_build
 
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
     dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
     shutil.copy(os.path.join(SRC, "kt", "kt_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
@@ -82,7 +82,7 @@ def main():
         }, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
     for r in rows:
         print("%-10s %-28s n=%3d mean %.4g" % r)
-    for name in ("phase_cycles.txt", "latency_vs_batch.txt", "soak.txt", "dispatch_order.txt", "stress.txt", "gpu_tests.txt", "rcp_newton_ab.txt"):
+    for name in ("phase_cycles.txt", "latency_vs_batch.txt", "soak.txt", "dispatch_order.txt", "stress.txt", "gpu_tests.txt", "range_scale.txt", "continuation_pass.txt"):
         if os.path.exists(os.path.join(SRC, name)):
             shutil.copy(os.path.join(SRC, name), os.path.join(dst, name))
     extra = []

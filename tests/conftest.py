@@ -14,9 +14,13 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _torch_hip_runtime_first():
-    """PyTorch-ROCm bundles its own libamdhip64 while libhector_mpc_hip.so links the system one: two HIP runtimes in one
-    process.  That works when torch's runtime comes up first (the order bench.py uses) -- initialising it after ours has
-    been observed to fail with "no ROCm-capable device".  So on a GPU box the test session brings torch.cuda up first."""
+    """ONE HIP runtime serves the whole Python process: PyTorch-ROCm bundles a libamdhip64.so.7 (ROCm 7.0) and libhector_mpc_hip.so
+    names the same SONAME in its DT_NEEDED (it is built against the ROCm 7.2 headers of /opt/rocm), so whichever copy the dynamic
+    loader maps FIRST is the one both use.  torch first (the order bench.py uses) = torch's bundled runtime for both, which works;
+    our library first = the system runtime for both, and torch on a runtime it was not built with has been observed to fail with
+    "no ROCm-capable device".  So on a GPU box the test session brings torch.cuda up first; tests/test_gpu_runtime.py asserts
+    that exactly one libamdhip64 is mapped and that it is torch's.  (A C++ host such as the reference controller has no torch in
+    the process: the library then runs on the system runtime it was built against.)"""
     try:
         import torch
 

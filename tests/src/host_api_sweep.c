@@ -316,6 +316,68 @@ int main(void) {
     free(r3), free(w3), free(f3);
   }
 
+  /* round 6: robot constants as data, the hand-over of full working sets (host- and device-driven, continuation only), command sweeps */
+  {
+    hmpc_handle *h6 = NULL;
+    CHECK(hmpc_create(&h6, &ps, N, 0) == HMPC_OK);
+    struct hmpc_params prm, got;
+    hmpc_default_params(&prm);
+    CHECK(prm.mass == 9.0f && prm.mu == 2.0f && prm.lt == 0.09f && prm.lh == 0.06f && prm.inertia[2] == 0.0691f);
+    CHECK(hmpc_set_params(NULL, &prm) == HMPC_E_ARG && hmpc_get_params(h6, NULL) == HMPC_E_ARG);
+    struct hmpc_params neg = prm;
+    neg.mass = -1.f;
+    CHECK(hmpc_set_params(h6, &neg) == HMPC_E_ARG);
+    make_records(recs, stride, 0.05);
+    CHECK(hmpc_upload_records(h6, recs, N) == HMPC_OK && hmpc_solve(h6, NULL) == HMPC_OK && hmpc_download(h6, forces, st) == HMPC_OK);
+    prm.mass = 11.5f, prm.mu = 0.8f;
+    CHECK(hmpc_set_params(h6, &prm) == HMPC_OK && hmpc_get_params(h6, &got) == HMPC_OK && got.mass == 11.5f && got.mu == 0.8f);
+    CHECK(hmpc_solve(h6, NULL) == HMPC_OK && hmpc_download(h6, forces2, st) == HMPC_OK);
+    double dmax = 0;
+    for (int k = 0; k < N * 12 * H; ++k) dmax = fmax(dmax, fabs((double)forces2[k] - (double)forces[k]));
+    CHECK(dmax > 1e-3); /* a heavier robot on a slipperier floor gets other forces */
+    CHECK(hmpc_set_params(h6, NULL) == HMPC_OK && hmpc_get_params(h6, &got) == HMPC_OK && got.mass == 9.0f);
+    CHECK(hmpc_legacy_set_params(&neg) == HMPC_E_ARG && hmpc_legacy_set_params(NULL) == HMPC_OK);
+    /* hard inputs: working sets beyond the fast variant's 64 rows, continued (default) and re-solved (hand-over off); device repair 1, 2 */
+    make_records(recs, stride, 1.1);
+    int flagged[4] = {0, 0, 0, 0}, left[4] = {0, 0, 0, 0};
+    for (int mode = 0; mode < 4; ++mode) {
+      CHECK(hmpc_set_handover(h6, mode != 1) == HMPC_OK && hmpc_set_device_repair(h6, mode >= 2 ? mode - 1 : 0) == HMPC_OK);
+      CHECK(hmpc_set_auto_resolve(h6, 0) == HMPC_OK);
+      CHECK(hmpc_upload_records(h6, recs, N) == HMPC_OK && hmpc_solve(h6, NULL) == HMPC_OK && hmpc_download(h6, forces2, st) == HMPC_OK);
+      for (int k = 0; k < N; ++k) flagged[mode] += HMPC_STATUS_CODE(st[k]) != HMPC_S_OK;
+      CHECK(hmpc_set_auto_resolve(h6, 1) == HMPC_OK && hmpc_download(h6, forces2, st) == HMPC_OK);
+      for (int k = 0; k < N; ++k) left[mode] += HMPC_STATUS_CODE(st[k]) != HMPC_S_OK && HMPC_STATUS_CODE(st[k]) != HMPC_S_OK_RELAXED;
+      if (mode == 0) memcpy(forces, forces2, sizeof(float) * (size_t)N * 12 * H);
+      else
+        for (int k = 0; k < N * 12 * H; ++k) CHECK(fabs((double)forces2[k] - (double)forces[k]) <= 2e-5 * (1.0 + fabs((double)forces[k])));
+    }
+    printf("hard inputs, flagged before the host's safe pass: hand-over %d, cold %d, device repair %d, continuation only %d; left after it: %d %d %d %d\n",
+           flagged[0], flagged[1], flagged[2], flagged[3], left[0], left[1], left[2], left[3]);
+    CHECK(left[0] == 0 && left[1] == 0 && left[2] == 0 && left[3] == 0 && flagged[2] <= flagged[3] && flagged[3] <= flagged[0]);
+    CHECK(hmpc_set_device_repair(h6, 0) == HMPC_OK);
+    /* command sweeps: 12 groups of 8 records that differ in the trajectory only == the independent solves, bit for bit */
+    make_records(recs, stride, 0.05);
+    for (int k = 0; k < N; ++k) {
+      if (k % 8 == 0) continue;
+      unsigned char *dst = recs + k * stride, *src = recs + (k - k % 8) * stride;
+      float trj[12 * H];
+      memcpy(trj, dst + 4 * 54, sizeof trj);          /* keep this record's trajectory ... */
+      memcpy(dst, src, stride);                       /* ... on the group's first record */
+      for (int i = 0; i < H; ++i) trj[12 * i + 10] = 0.01f * (float)(k % 8);
+      memcpy(dst + 4 * 54, trj, sizeof trj);
+    }
+    CHECK(hmpc_upload_records(h6, recs, N) == HMPC_OK && hmpc_solve(h6, NULL) == HMPC_OK && hmpc_download(h6, forces, st) == HMPC_OK);
+    uint32_t *st2 = (uint32_t *)calloc(N, sizeof(uint32_t));
+    CHECK(hmpc_solve_command_sweep(h6, 7, NULL) == HMPC_E_ARG && hmpc_solve_command_sweep(h6, 0, NULL) == HMPC_E_ARG);
+    CHECK(hmpc_solve_command_sweep(h6, 8, NULL) == HMPC_OK && hmpc_download(h6, forces2, st2) == HMPC_OK);
+    CHECK(memcmp(forces, forces2, sizeof(float) * (size_t)N * 12 * H) == 0 && memcmp(st, st2, sizeof(uint32_t) * N) == 0);
+    recs[5 * stride + 4 * 3] ^= 1; /* one bit of v of record 5: no longer its group's state */
+    CHECK(hmpc_upload_records(h6, recs, N) == HMPC_OK && hmpc_solve_command_sweep(h6, 8, NULL) == HMPC_OK && hmpc_download(h6, forces2, st2) == HMPC_OK);
+    CHECK(HMPC_STATUS_CODE(st2[5]) == HMPC_S_SWEEP_MISMATCH && HMPC_STATUS_CODE(st2[4]) == HMPC_S_OK && forces2[5 * 12 * H] == 0.f);
+    free(st2);
+    CHECK(hmpc_destroy(h6) == HMPC_OK);
+  }
+
   free(recs), free(forces), free(forces2), free(st), free(x64), free(obj), free(ticks), free(wpd), free(rb), free(lq), free(fff), free(tau), free(wrench);
   printf("host API sweep ok\n");
   fflush(stdout); /* (so that the line survives a tool that aborts the process during runtime teardown, e.g. a sanitizer) */

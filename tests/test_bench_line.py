@@ -49,7 +49,7 @@ def test_bench_line_contract():
     assert abs(d["value"] - 2048 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6  # value = units / timed seconds
     assert d["parity"]["max_rel_force_err_vs_qpoases"] < 1e-4 and d["solver"]["failed"] == 0
     e2e = d["parity"]["vs_reference_source_end_to_end"]  # measured in this run, not a prose string
-    assert e2e["checked"] == 16 and 0 < e2e["max_rel_force_err"] < 1.1e-3 and 0 <= e2e["fraction_above_1e-4"] <= 1
+    assert e2e["checked"] == 16 and 0 < e2e["max_rel_force_err"] < 7.2e-4 and 0 <= e2e["fraction_above_1e-4"] <= 1
     assert len(cb["process_sweep"]) >= 2 and cb["process_sweep"][0]["processes"] == 1 and cb["host"]["nproc_affinity"] >= 1
     assert cb["saturation_processes"] >= 1 and "scaling_note" in cb
     # quotable: the value is the median of three timed-to-target runs, the spread is in the line
@@ -103,7 +103,7 @@ def test_bench_two_ranks_on_one_gpu(name, extra, batch):
     """Rank > 0 code on hardware: bench.py launched exactly as the driver launches N = 2 (torch.distributed.run, one
     process per rank), both ranks on the one GPU of the test box, the exchange over the gloo TEST transport (RCCL refuses
     two ranks on one device).  Everything but the collective's transport is the N > 1 path of the driver's scaling run:
-    per-rank seed / shard, two HIP runtimes per process x 2, the lock-protected library load, the posted exchange per solve
+    per-rank seed / shard, one HIP runtime per process (torch's, loaded first) x 2 processes, the lock-protected library load, the posted exchange per solve
     with its double buffering, barriers, all_reduce(MAX) of the elapsed time -- for the headline config, BASELINE config 3
     (walking sweep) and config 5 (three contacts) -- and EVERY rank checks its own shard against the oracle."""
     d = _torchrun(2, 29531, "--steps", "4", "--warmup", "1", "--batch", str(batch), "--check", "24", "--backend", "gloo",
@@ -121,7 +121,7 @@ def test_bench_two_ranks_on_one_gpu(name, extra, batch):
     assert d["solver"]["failed_over_all_ranks"] == 0 and len(d["solver"]["kernel_ms_per_rank"]) == 2
     if name == "headline_2contact":
         e2e = p["vs_reference_source_end_to_end"]
-        assert e2e["checked"] == 48 and e2e["max_rel_force_err"] < 1.1e-3  # cond(H) x binary32 round-off (test_reference_source.py)
+        assert e2e["checked"] == 48 and e2e["max_rel_force_err"] < 7.2e-4  # cond(H) x binary32 round-off (test_reference_source.py)
     if name == "cfg5_three_contact":
         assert p["vs_reference_source_end_to_end"] is None  # the reference has no code for this shape
         assert "180x240" in d["config"]["workload"]

@@ -28,7 +28,7 @@ def _has_gpu():
 
 
 @pytest.mark.parametrize("src,cc,std", [("legacy_tick.cpp", "g++", "-std=c++17"), ("batched.c", "gcc", "-std=c11"),
-                                        ("batched_multi.c", "gcc", "-std=c11")])
+                                        ("batched_multi.c", "gcc", "-std=c11"), ("friction_sweep.c", "gcc", "-std=c11")])
 def test_examples_compile_and_fail_loudly_without_gpu(tmp_path, src, cc, std):
     exe = _compile(tmp_path, src, cc, std)
     if _has_gpu():
@@ -39,11 +39,14 @@ def test_examples_compile_and_fail_loudly_without_gpu(tmp_path, src, cc, std):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("src,cc,std", [("legacy_tick.cpp", "g++", "-std=c++17"), ("batched.c", "gcc", "-std=c11")])
+@pytest.mark.parametrize("src,cc,std", [("legacy_tick.cpp", "g++", "-std=c++17"), ("batched.c", "gcc", "-std=c11"),
+                                        ("friction_sweep.c", "gcc", "-std=c11")])
 def test_examples_run_on_gpu(tmp_path, src, cc, std):
     exe = _compile(tmp_path, src, cc, std)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    if src == "friction_sweep.c":  # hmpc_set_params sweep + command sweep (round 6)
+        assert "bit-identical to the independent solves" in r.stdout and r.stdout.count("friction pyramid") == 8
     if src == "legacy_tick.cpp":
         u0 = [float(x) for x in r.stdout.split("u0 =")[1].split()]
         assert abs(u0[2] - 47.84) < 0.05 and abs(u0[5] - 47.84) < 0.05  # the nominal standing tick (tests/test_gpu_solve.py)

@@ -177,9 +177,10 @@ def _end_to_end(ref, f, nb, x_of, obj_of=None):
     return np.array(err), np.array(gap), np.array(sub), np.array(viol)
 
 
-# end-to-end bounds = ~2x the maxima measured over all 1 024 instances of the metric's 2-contact case / BASELINE config 2
-# and the 96-instance sets below (3.5e-4 .. 5.5e-4 / 4.7e-5; 29-39 % / 0 % of the instances above 1e-4)
-E2E_FORCE = {"standing": (1.1e-3, 2e-4, 0.6), "walking": (1.2e-4, 2e-5, 0.01)}  # max, median, fraction above 1e-4
+# end-to-end bounds = 1.3x the maxima measured over all 1 024 instances of the metric's 2-contact case / BASELINE config 2 (GPU leg:
+# 3.5e-4 max / 7.4e-5 median / 29 % above 1e-4 standing, 4.7e-5 max walking) and the 96-instance sets of the CPU leg below
+# (5.53e-4 / 9.1e-5 / 38.5 % standing, 2.6e-5 / 7.0e-6 / 0 % walking) -- round 5 asserted ~2x, loose enough for a 2x regression to pass
+E2E_FORCE = {"standing": (7.2e-4, 1.2e-4, 0.50), "walking": (6.1e-5, 1.0e-5, 0.002)}  # max, median, fraction above 1e-4
 E2E_OBJ_GAP = 1e-4      # north_star's tolerance; measured <= 2.4e-6
 E2E_SUBOPT = 5e-8       # measured <= 5e-9 (and >= -1.1e-8: the reference's own q is qpOASES-accurate, not exact)
 E2E_VIOLATION = 1e-7    # measured <= 1.3e-8
@@ -341,7 +342,7 @@ def test_hip_against_reference_source_goldens(gold):
             _biteq(d["ub"][: 16 * H][gold[p + "con_ind"]], gold[p + "ub_red"], "ub")
             q = gold[p + "q_soln"]
             err = np.abs(forces[k] - q).max() / max(1.0, np.abs(q).max())
-            assert err < (E2E_FORCE["standing"][0] if d["n"] > 60 else 2.5 * E2E_FORCE["walking"][0]), (name, k, err)
+            assert err < (E2E_FORCE["standing"][0] if d["n"] > 60 else 3e-4), (name, k, err)
         mpc.close()
 
 
