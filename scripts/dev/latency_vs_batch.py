@@ -11,7 +11,7 @@ import torch  # noqa: E402
 torch.zeros(1, device="cuda")
 from hector_simulation_amd import interface, records, synthetic  # noqa: E402
 
-print(f"{'batch':>6s} {'natural':>22s} {'predicted order':>24s} {'previous-solve order':>24s}")
+print(f"{'batch':>6s} {'natural':>22s} {'predicted order':>24s} {'previous-solve order':>24s}   active-set iterations of the batch")
 for nb in (64, 256, 512, 768, 1024, 1536, 2304):
     f = synthetic.make_batch(nb, 10, "standing", seed=2, phase="random")
     rec = records.pack_records(f, 10)
@@ -21,7 +21,10 @@ for nb in (64, 256, 512, 768, 1024, 1536, 2304):
         m.set_dispatch_order(mode)
         m.upload(rec)
         m.solve()
-        m.download()
+        _, st = m.download()
+        itmax, itmean = int(interface.status_iters(st).max()), float(interface.status_iters(st).mean())
         row.append(min(m.time_solve(20) for _ in range(3)))
         m.close()
-    print(f"b{nb:5d} " + "   ".join(f"{ms:.4f} ms {nb / ms / 1e3:6.3f} M/s" for ms in row), flush=True)
+    # (up to 768 instances are ONE round of workgroups: the launch lasts as long as its slowest instance's dependency chain, i.e. it
+    #  follows the batch's LARGEST iteration count -- every batch size is its own random draw -- not the batch size)
+    print(f"b{nb:5d} " + "   ".join(f"{ms:.4f} ms {nb / ms / 1e3:6.3f} M/s" for ms in row) + f"   iterations mean {itmean:.2f} max {itmax}", flush=True)
