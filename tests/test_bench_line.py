@@ -212,3 +212,36 @@ def test_self_launch_builds_the_torchrun_command(monkeypatch):
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     assert bench.self_launch(argparse.Namespace(gpus=4, backend="nccl"), argv) == 2 and not seen
     assert bench.self_launch(argparse.Namespace(gpus=4, backend="gloo"), argv) == 7 and seen
+
+
+def test_rank_bring_up_fails_with_diagnostics_within_its_timeout(tmp_path):
+    """a rank that cannot bring its process group up (here: WORLD_SIZE = 2 with only rank 0 ever started, so
+    the rendezvous never completes) must not sit in the default 10-minute time-outs: bench.py's bring_up_process_group prints the
+    rank's device list, the RCCL version and the HSA_* / NCCL_* / MASTER_* environment to stderr and the PROCESS exits 3 -- within
+    the bring-up time-out plus the watchdog's margin.  Runs without a GPU (gloo control plane, the function under test is the same)."""
+    import socket
+    import time
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = (
+        "import importlib.util, os, sys\n"
+        f"spec = importlib.util.spec_from_file_location('bench_under_test', {os.path.join(ROOT, 'bench.py')!r})\n"
+        "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "import torch, torch.distributed as dist\n"
+        "b.bring_up_process_group(torch, dist, 'gloo', 0, 0, 4.0)\n"
+        "print('UNEXPECTED: bring-up returned')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", RANK="0", LOCAL_RANK="0",
+               NCCL_DEBUG="WARN", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    took = time.time() - t0
+    assert r.returncode == 3, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    assert took < 60, took
+    assert "UNEXPECTED" not in r.stdout
+    err = r.stderr
+    assert "[bench] rank 0 (LOCAL_RANK 0): ERROR" in err and "process group" in err
+    assert "device(s) visible" in err or "device query failed" in err
+    assert "NCCL_DEBUG=WARN" in err and "HSA_ENABLE_IPC_MODE_LEGACY=0" in err and f"MASTER_PORT={port}" in err and "WORLD_SIZE=2" in err
+    assert "--exchange none" in err  # (the hint at the diagnostic mode)
