@@ -1306,6 +1306,67 @@ __device__ __forceinline__ void stage_a_chains(Smem<NMAX, HMAX, NT, QCAP, NC, BP
   PROF_MARK(P_G);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The epilogue as a function.  In (LDS): the solution x in sweep order, the working set (act / slot / Wrow, multipliers u), rmap (original
+// variable -> sweep index, 255 = eliminated), g, the Fz caps.  Out (HBM): forces in the reference's 12h layout with eliminated variables
+// exactly 0 (SolverMPC.cpp:720-732), optionally the binary64 copy, the tick-to-tick working set, the status word (code | iterations << 8 |
+// |W| << 20), the flag counter / list of the safe pass, the objective through the KKT identity.
+template <int NMAX, int HMAX, int NT, int QCAP, int NC, int BPT>
+__device__ __forceinline__ void stage_output(Smem<NMAX, HMAX, NT, QCAP, NC, BPT> &S, const KernelArgs &args, const int inst, const int h, const int n,
+                                             const int q, const int iters, const int code, const bool capped, const bool slot_consumed) {
+  using SM = Smem<NMAX, HMAX, NT, QCAP, NC, BPT>;
+  constexpr int U = SM::U, C8 = 8 * NC;
+  auto &Q = S.u.s;
+  const int tid = threadIdx.x;
+  int t_out = tid;
+  if constexpr (BPT == 2) asm volatile("" : "+v"(t_out));  // (or 8 * tid is formed at the top of the kernel, kept for the whole solve, and spilled)
+  for (int t = t_out; t < U * h; t += NT) {
+    const int rmp = S.rmap[t];
+    const double xv = (rmp == 255) ? 0.0 : Q.x[rmp];
+    args.forces[(size_t)inst * U * h + t] = (float)xv;
+    if (args.x64) args.x64[(size_t)inst * U * h + t] = xv;
+  }
+  if (args.wset) {
+    // the final working set in original row numbering (rows of eliminated leg-steps and failed solves: 0)
+    for (int t = tid; t < C8 * h; t += NT) {
+      const int st = t / C8, cc = (t % C8) >> 3, rr = t & 7;
+      const int rmp = S.rmap[U * st + 3 * cc];
+      signed char av = 0;
+      if (rmp != 255 && code == S_OK) av = Q.act[8 * (rmp / GS) + rr];
+      args.wset[(size_t)inst * C8 * h + t] = av;
+    }
+  }
+  if (tid == 0) {
+    if (slot_consumed) args.spill_slot[inst] = -1;  // the hand-over slot is consumed: a later pass over this instance starts cold
+    args.status[inst] = (uint32_t)code | ((uint32_t)(iters & 0xfff) << 8) | ((uint32_t)(q & 0xfff) << 20);
+    if ((code == S_WORKSET || code == S_MAXITER || code == S_INFEASIBLE || code == S_KKT) && !capped) {
+      if (args.flagged) atomicAdd(args.flagged, 1u);
+      if (args.flag_count) {
+        const unsigned int k = atomicAdd(args.flag_count, 1u);
+        if ((int)k < args.flag_cap) args.flag_list[k] = inst;
+      }
+    }
+    if (args.obj64) {
+      // objective through the KKT identity  0.5 x'Hx + g'x = 0.5 g'x + 0.5 u'b_W  (H itself was consumed by the sweeps)
+      double o = 0.0;
+      for (int i = 0; i < n; ++i) o = dfma(0.5 * S.g[i], Q.x[i], o);
+      for (int j = 0; j < q; ++j) {
+        const int c = Q.Wrow[j], rr = c & 7;
+        const double sj = (double)Q.act[c];
+        double bnd = (sj > 0) ? 0.0 : ((rr == 4) ? (double)0.01f : (rr == 7 ? S.ub7[c >> 3] : 0.0));
+        const double rl = S.relax;  // != 0 only for an HMPC_S_OK_RELAXED answer: its bounds are the perturbed ones (row_lo / row_ub_calc)
+        if (rl != 0.0) {
+          const double fr = 0.6180339887498949 * (double)(c + 1);
+          const double dl = rl * (1.0 + (fr - __builtin_floor(fr)));
+          bnd = (sj > 0) ? -dl : bnd + dl * ((rr == 7 && bnd > 1.0) ? bnd : 1.0);
+        }
+        o = dfma(0.5 * Q.u[j], sj * bnd, o);
+      }
+      args.obj64[inst] = o;
+    }
+  }
+}
+
 // MODE 0: the product path, one workgroup = one independent instance.
 // MODE 1: COMMAND SWEEPS (hmpc_solve_command_sweep).  The batch is groups of args.sweep_k consecutive records that share
 // everything but the reference trajectory -- state, feet, joints, weights, gait table (ConvexMPCLocomotion.cpp:351-406 builds the
@@ -2201,6 +2262,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   int q = 0, iters = 0, code = S_OK;
 #ifdef HMPC_DEBUG_STATS  // developer build (scripts/dev/cont_probe.py): what happened inside a solve, packed into obj64
   int dbg_bad = 0, dbg_rounds = 0, dbg_norounds_cap = 0, dbg_norounds_few = 0, dbg_dep = 0;
+  double dbg_viol = 0.0;  // largest (unit-scaled) violation left when a resumed solve's budget ran out
 #define HMPC_DBG(x) x
 #else
 #define HMPC_DBG(x)
@@ -2908,6 +2970,12 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       PROF_MARK(P_SEL);
       if (ub(!(pval < -FEAS_TOL))) break;
       if constexpr (ANTICYCLE) {
+        if (ub(pval < -1e8)) {  // the iterate has left the problem's scale (an ill-conditioned working set blew E up): flagged at once
+          code = S_KKT;
+          break;
+        }
+      }
+      if constexpr (ANTICYCLE) {
         // Degenerate vertices, handled where they occur (round 6; until then only the host's last-resort passes did this, after a
         // cold re-solve had burnt its whole iteration bound).  When the re-addition counter of a row reaches its limit, or a
         // resumed solve's budget runs out, the instance is cycling: every bound is moved outward by relax (1 + frac(0.618 row)) --
@@ -2942,6 +3010,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         if constexpr (CONT) {
           if (budgeted) {  // (uniform)
             budget_hit = true;
+            HMPC_DBG(dbg_viol = -pval;)
             break;
           }
         }
@@ -3050,6 +3119,8 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         }
         l = uni(l);
         t1 = uni_d(t1);
+        // n+' (M - M N'E N M) n+ against n+' M n+: the part of the new row's normal that is NOT in the span of the working set's
+        // (1e-10 and 1e-8 measured on the continuation variant at 6x the input ranges: 20 -> 18 unfinished of 2 081, no difference in time)
         const bool dep = ub(!(delta > 1e-12 * gamma));
         const double t2 = dep ? INF : -sp / delta;
         const double t = (t1 < t2) ? t1 : t2;
@@ -3260,62 +3331,15 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     }
   }
 
-  // ---------------- output: scatter to the reference's 12h layout, eliminated variables exactly 0 (SolverMPC.cpp:720-732)
-  int t_out = tid;
-  if constexpr (BPT == 2) asm volatile("" : "+v"(t_out));  // (or 8 * tid is formed at the top of the kernel, kept for the whole solve, and spilled)
-  for (int t = t_out; t < U * h; t += NT) {
-    const int rmp = S.rmap[t];
-    const double xv = (rmp == 255) ? 0.0 : Q.x[rmp];
-    args.forces[(size_t)inst * U * h + t] = (float)xv;
-    if (args.x64) args.x64[(size_t)inst * U * h + t] = xv;
-  }
-  if (args.wset) {
-    // the final working set in original row numbering (rows of eliminated leg-steps and failed solves: 0)
-    for (int t = tid; t < C8 * h; t += NT) {
-      const int st = t / C8, cc = (t % C8) >> 3, rr = t & 7;
-      const int rmp = S.rmap[U * st + 3 * cc];
-      signed char av = 0;
-      if (rmp != 255 && code == S_OK) av = Q.act[8 * (rmp / GS) + rr];
-      args.wset[(size_t)inst * C8 * h + t] = av;
-    }
-  }
-  if (tid == 0) {
-    if constexpr (RESUMABLE) {
-      if (resumed) args.spill_slot[inst] = -1;  // the slot is consumed: a later pass over this instance starts cold
-    }
-    args.status[inst] = (uint32_t)code | ((uint32_t)(iters & 0xfff) << 8) | ((uint32_t)(q & 0xfff) << 20);
+  // ---------------- output: forces, working set, status word, flag lists, objective (stage_output above)
+  {
     // (an instance that ran into the CALLER'S iteration cap is the caller's answer: it is neither counted nor listed for the
     //  safe pass -- the device-side repair would otherwise re-solve it cold and overwrite its last iterate)
     const bool capped = (code == S_MAXITER) && (args.iter_cap > 0 && args.iter_cap < itmax_v);
-    if ((code == S_WORKSET || code == S_MAXITER || code == S_INFEASIBLE || code == S_KKT) && !capped) {
-      if (args.flagged) atomicAdd(args.flagged, 1u);
-      if (args.flag_count) {
-        const unsigned int k = atomicAdd(args.flag_count, 1u);
-        if ((int)k < args.flag_cap) args.flag_list[k] = inst;
-      }
-    }
+    stage_output<NMAX, HMAX, NT, QCAP, NC, BPT>(S, args, inst, h, n, q, iters, code, capped, RESUMABLE && resumed);
 #ifdef HMPC_DEBUG_STATS
-    if (args.obj64) args.obj64[inst] = (double)(dbg_bad + 10 * dbg_rounds + 1000 * dbg_norounds_cap + 10000 * dbg_norounds_few + 100000 * dbg_dep);
-    if (false)
+    if (tid == 0 && args.obj64) args.obj64[inst] = (dbg_viol > 0.0) ? -dbg_viol : (double)(dbg_bad + 10 * dbg_rounds + 1000 * dbg_norounds_cap + 10000 * dbg_norounds_few + 100000 * dbg_dep);
 #endif
-    if (args.obj64) {
-      // objective through the KKT identity  0.5 x'Hx + g'x = 0.5 g'x + 0.5 u'b_W  (H itself was consumed by the sweeps)
-      double o = 0.0;
-      for (int i = 0; i < n; ++i) o = dfma(0.5 * S.g[i], Q.x[i], o);
-      for (int j = 0; j < q; ++j) {
-        const int c = Q.Wrow[j], rr = c & 7;
-        const double sj = (double)Q.act[c];
-        double bnd = (sj > 0) ? 0.0 : ((rr == 4) ? (double)0.01f : (rr == 7 ? S.ub7[c >> 3] : 0.0));
-        const double rl = S.relax;  // != 0 only for an HMPC_S_OK_RELAXED answer: its bounds are the perturbed ones (row_lo / row_ub_calc)
-        if (rl != 0.0) {
-          const double fr = 0.6180339887498949 * (double)(c + 1);
-          const double dl = rl * (1.0 + (fr - __builtin_floor(fr)));
-          bnd = (sj > 0) ? -dl : bnd + dl * ((rr == 7 && bnd > 1.0) ? bnd : 1.0);
-        }
-        o = dfma(0.5 * Q.u[j], sj * bnd, o);
-      }
-      args.obj64[inst] = o;
-    }
   }
   PROF_MARK(P_FINAL);
   PROF_FLUSH();

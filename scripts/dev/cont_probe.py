@@ -46,7 +46,12 @@ it0, it1 = interface.status_iters(st0)[full], interface.status_iters(st1)[full]
 print(f"  handed over: {full.sum()}; iterations at hand-over mean {it0.mean():.1f}; after continuation mean {it1.mean():.1f} (added {np.mean(it1 - it0):.1f}, p50 {np.median(it1 - it0):.0f}, p90 {np.percentile(it1 - it0, 90):.0f}, max {(it1 - it0).max()})")
 print(f"  |W| after continuation: mean {interface.status_nactive(st1)[full].mean():.1f} max {interface.status_nactive(st1)[full].max()}; codes of the handed-over {cnt(interface.status_code(st1)[full])}")
 if dbg is not None:
-    d = dbg[full].astype(np.int64)
+    hit = dbg[full] < 0
+    if hit.any():
+        v = -dbg[full][hit]
+        print(f"  budget ran out in {hit.sum()} resumed solves; most violated row (unit scale) at that point: min {v.min():.1e} p25 {np.percentile(v, 25):.1e} "
+              f"median {np.median(v):.1e} p75 {np.percentile(v, 75):.1e} max {v.max():.1e}; their final codes {cnt(interface.status_code(st1)[full][hit])}")
+    d = np.where(dbg[full] < 0, 0, dbg[full]).astype(np.int64)
     bad, rounds, nocap, nofew, dep = d % 10, (d // 10) % 100, (d // 1000) % 10, (d // 10000) % 10, d // 100000
     added = it1 - it0
     for name, sel in (("all handed over", np.ones_like(added, dtype=bool)), ("added > 60", added > 60), ("not ok", interface.status_code(st1)[full] != 0)):
