@@ -1033,7 +1033,7 @@ def main() -> None:
             # trajectories built from the commands as ConvexMPCLocomotion.cpp:351-406 builds them; H and its inverse formed once per
             # state (hmpc_solve_command_sweep) against the same records as 8 192 independent instances (hmpc_solve) -- bit-identical
             # outputs asserted, kernel times by HIP events, best of 4
-            def command_sweep(groups, kk, gait2):
+            def command_sweep(groups, kk, gait2, floors=0):
                 basef = synthetic.make_batch(groups, h, gait2, seed=12, phase="random")
                 fs = {key: np.repeat(np.asarray(v), kk, axis=0) for key, v in basef.items()}
                 rng2 = np.random.default_rng(13)
@@ -1047,13 +1047,20 @@ def main() -> None:
                 tr[:, 1:, 2] = tr[:, 0:1, 2] + stp[:, 1:] * synthetic.DT_MPC * yr[:, None]
                 fs["traj"] = tr.reshape(bb, 12 * h)
                 recs = records.pack_records(fs, h)
+                d_mu = None
+                if floors:  # terrain sweep: a friction parameter per instance (hmpc_set_instance_mu), `floors` values inside every group
+                    d_mu = torch.from_numpy(np.array([0.8, 1.25, 2.0, 3.0], dtype=np.float32)[np.arange(bb) % floors]).to(dev)
                 mi = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, bb, device=local_rank)
+                if d_mu is not None:
+                    mi.set_instance_mu(d_mu.data_ptr(), keepalive=d_mu)
                 mi.upload(recs)
                 mi.solve(stream)
                 fi, si = mi.download()
                 t_ind = min(mi.time_solve(1, stream) for _ in range(4))
                 mi.close()
                 ms = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, bb, device=local_rank)
+                if d_mu is not None:
+                    ms.set_instance_mu(d_mu.data_ptr(), keepalive=d_mu)
                 ms.upload(recs)
                 ts4 = []
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1067,6 +1074,7 @@ def main() -> None:
                 fsw, ssw = ms.download()
                 ms.close()
                 return {"states": groups, "commands_per_state": kk, "instances": bb, "gait": gait2,
+                        **({"floors_per_state": floors, "commands_per_floor": kk // floors} if floors else {}),
                         "independent": {"solves_per_s": bb / (t_ind * 1e-3), "kernel_ms": t_ind},
                         "sweep": {"solves_per_s": bb / (min(ts4[1:]) * 1e-3), "kernel_ms": min(ts4[1:]),
                                   "note": "both launches (one workgroup per state forms H^-1, one per instance solves with it), torch events on the launch stream"},
@@ -1077,6 +1085,7 @@ def main() -> None:
 
             extra["command_sweep_128_states_x_64_commands"] = command_sweep(128, 64, "standing")
             extra["command_sweep_1024_states_x_8_commands"] = command_sweep(1024, 8, "standing")
+            extra["terrain_command_sweep_128_states_x_4_floors_x_16_commands"] = command_sweep(128, 64, "standing", floors=4)
             extra["command_sweep_128_states_x_64_commands_walking"] = command_sweep(128, 64, "walking")
             rs = {f"range_scale_{sc}": range_scale(sc) for sc in (1, 3, 6)}
             for sc in (3, 6):

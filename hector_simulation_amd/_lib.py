@@ -25,7 +25,7 @@ EXPORTS = [
     "hmpc_group_create_ex", "hmpc_group_contacts", "hmpc_group_set_deal", "hmpc_group_deal", "hmpc_group_member_step",
     "hmpc_upload_records_strided_async", "hmpc_set_max_iterations", "hmpc_legacy_set_max_iterations", "hmpc_tick_solve_device", "hmpc_set_dispatch_order",
     "hmpc_set_handover", "hmpc_default_params", "hmpc_set_params", "hmpc_get_params", "hmpc_legacy_set_params", "hmpc_group_set_params",
-    "hmpc_solve_command_sweep",
+    "hmpc_solve_command_sweep", "hmpc_set_instance_mu", "hmpc_group_solve_command_sweep",
 ]
 
 
@@ -130,6 +130,8 @@ def load():
     L.hmpc_set_device_outputs.argtypes = [vp, vp, vp]
     L.hmpc_solve.argtypes = [vp, vp]
     L.hmpc_solve_command_sweep.argtypes = [vp, ci, vp]
+    L.hmpc_set_instance_mu.argtypes = [vp, vp]
+    L.hmpc_group_solve_command_sweep.argtypes = [vp, ci]
     L.hmpc_download.argtypes = [vp, vp, vp]
     L.hmpc_get_device_outputs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.hmpc_batch.argtypes = [vp]

@@ -135,6 +135,7 @@ struct hmpc_handle {
   int spill_cap;
   int handover;  // hmpc_set_handover (default on)
   hmpc_params params;  // robot / contact constants (hmpc_set_params; defaults = the reference's literals)
+  const float *d_mu_inst;  // hmpc_set_instance_mu: per-instance friction parameter in HBM (caller-owned), nullptr = params.mu for all
   double *d_sweep_m;  // command sweeps: every group's M = H^-1, [groups][36][threads per workgroup] doubles (grown on demand)
   size_t sweep_m_bytes;
 };
@@ -322,6 +323,7 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   a.inv_mass = 1.0f / h->params.mass;  // (binary32 division, correctly rounded: the value the reference's 1.f / 9.f folds to for the default)
   a.Ib[0] = h->params.inertia[0], a.Ib[1] = h->params.inertia[1], a.Ib[2] = h->params.inertia[2];
   a.mu = h->params.mu, a.lt = h->params.lt, a.lh = h->params.lh, a.gravity = h->params.gravity;
+  a.mu_inst = h->d_mu_inst;
   for (int off = 0; off < grid_all; off += chunk) {
     const int grid = (grid_all - off < chunk) ? grid_all - off : chunk;
     if (off > 0) a.index_list = o.d_index_list + off;  // (only list launches are ever chunked)
@@ -702,6 +704,12 @@ int hmpc_set_params(hmpc_handle *h, const struct hmpc_params *p) {
   }
   if (!params_ok(*p)) return HMPC_E_ARG;
   h->params = *p;
+  return HMPC_OK;
+}
+
+int hmpc_set_instance_mu(hmpc_handle *h, const float *device_mu) {
+  if (!h) return HMPC_E_ARG;
+  h->d_mu_inst = device_mu;
   return HMPC_OK;
 }
 

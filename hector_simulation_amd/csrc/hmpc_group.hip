@@ -409,6 +409,20 @@ int hmpc_group_solve(hmpc_group *g) {
   return HMPC_OK;
 }
 
+int hmpc_group_solve_command_sweep(hmpc_group *g, int group_size) {
+  GENTER();
+  if (!g || group_size < 1) return HMPC_E_ARG;
+  if (g->deal != HMPC_DEAL_CONTIGUOUS) return HMPC_E_ARG;  // a striped deal would tear the groups apart
+  for (Member &mb : g->m)
+    if (mb.n % group_size != 0) return HMPC_E_ARG;         // every slice: whole groups only
+  for (Member &mb : g->m) {
+    GHIP(hipSetDevice(mb.device));
+    const int rc = hmpc_solve_command_sweep(mb.h, group_size, mb.solve_stream);
+    if (rc != HMPC_OK) return rc;
+  }
+  return HMPC_OK;
+}
+
 // The exchange carries repaired rows (default on): every member's solve is followed, on the same stream and without a
 // host round trip, by the safe variant over the instances the fast variant flagged (hmpc_set_device_repair), so what
 // pack_step0_kernel reads is the repaired wrench and status.  Off = the fast pass's results as they are (a flagged

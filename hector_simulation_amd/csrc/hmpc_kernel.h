@@ -1099,7 +1099,8 @@ __device__ __forceinline__ void stage_a_scalars(Smem<NMAX, HMAX, NT, QCAP, NC, B
       const int leg = (tid == leg_lane0) ? 0 : (tid == leg_lane1 ? 1 : 2);
       float R[9], Rt[9];
       quat_to_R(in_q, R, Rt);
-      const float mu = args.mu, lt = args.lt, lh = args.lh;  // 2.0, 0.09, 0.06 in the reference (SolverMPC.cpp:488-490)
+      const float mu = args.mu_inst ? args.mu_inst[inst] : args.mu;  // 2.0 in the reference (SolverMPC.cpp:488); per instance for terrain sweeps
+      const float lt = args.lt, lh = args.lh;                         // 0.09, 0.06 (SolverMPC.cpp:489-490)
       const int b = (leg < 2) ? 5 * leg : 0;
       const float s0 = A.sc[b][0], c0 = A.sc[b][1], s1 = A.sc[b + 1][0], c1 = A.sc[b + 1][1];
       const float s2 = A.sc[b + 2][0], c2 = A.sc[b + 2][1], s3 = A.sc[b + 3][0], c3 = A.sc[b + 3][1];

@@ -79,6 +79,9 @@ struct KernelArgs {
   // robot / contact constants (struct hmpc_params; defaults = the reference's literals): 1 / mass as the host's binary32 quotient
   // (what the compiler folds 1.0f / 9.0f to), body inertia diagonal, friction coefficient, toe / heel lever arms, gravity state
   float inv_mass, Ib[3], mu, lt, lh, gravity;
+  // optional per-INSTANCE friction parameter (hmpc_set_instance_mu: terrain sweeps): mu_inst[inst] replaces mu; nullptr = off.  H does
+  // not depend on it (only the friction rows of the constraint block do), so instances of one command-sweep group may differ in it
+  const float *mu_inst;
   // command sweeps (MODE 1 kernels, hmpc_solve_command_sweep): groups of sweep_k consecutive records that differ in the reference
   // trajectory only; sweep_phase 0 = one workgroup per group forms M = H^-1 and writes it to sweep_m[group][36][NT], phase 1 =
   // one workgroup per instance solves with its group's M

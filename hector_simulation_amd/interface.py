@@ -158,6 +158,12 @@ class BatchedMPC:
             p.gravity = np.float32(gravity)
         _check(self.L.hmpc_set_params(self.h, C.byref(p)), "hmpc_set_params")
 
+    def set_instance_mu(self, device_ptr: int, keepalive=None) -> None:
+        """Per-instance friction parameter (float32[batch] in HBM; 0 / None = off): terrain sweeps, also inside a command-sweep group
+        (include/hector_mpc.h hmpc_set_instance_mu)."""
+        self._keep_mu = keepalive
+        _check(self.L.hmpc_set_instance_mu(self.h, C.c_void_p(int(device_ptr or 0))), "hmpc_set_instance_mu")
+
     def get_params(self) -> dict:
         p = _lib.Params()
         _check(self.L.hmpc_get_params(self.h, C.byref(p)), "hmpc_get_params")
@@ -361,6 +367,10 @@ class DeviceGroup:
 
     def solve(self) -> None:
         self._check(self.L.hmpc_group_solve(self.g), "hmpc_group_solve")
+
+    def solve_command_sweep(self, group_size: int) -> None:
+        """hmpc_solve_command_sweep on every member (slices must consist of whole groups)."""
+        self._check(self.L.hmpc_group_solve_command_sweep(self.g, int(group_size)), "hmpc_group_solve_command_sweep")
 
     def set_deal(self, striped: bool) -> None:
         """Contiguous slices (default) or round-robin: member i holds instances i, i + G, ... (hmpc_group_set_deal)."""

@@ -137,6 +137,12 @@ void hmpc_default_params(struct hmpc_params *p);
 /* takes effect with the next solve of the handle; p == NULL restores the defaults.  mass, inertia, mu > 0 and finite, else HMPC_E_ARG */
 int hmpc_set_params(hmpc_handle *h, const struct hmpc_params *p);
 int hmpc_get_params(const hmpc_handle *h, struct hmpc_params *p);
+/* TERRAIN SWEEPS: a friction parameter per INSTANCE -- device_mu[batch] floats in HBM, caller-owned, read by every later solve of the
+ * handle in place of hmpc_params.mu until it is set to NULL again (instance i of the current batch uses device_mu[i]; values must
+ * be > 0).  H and its inverse do not depend on mu -- only the friction rows (-+mu, 0, 1) of the constraint block do -- so the
+ * records of one hmpc_solve_command_sweep group may differ in their mu as well as in their trajectory: one state under many commands
+ * on many floors, one inverse. */
+int hmpc_set_instance_mu(hmpc_handle *h, const float *device_mu);
 /* ... for the process-global solver behind the reference interface (applies from the next setup_problem / solve on) */
 int hmpc_legacy_set_params(const struct hmpc_params *p);
 
@@ -412,6 +418,9 @@ int hmpc_group_member_step(const hmpc_group *g, int member);
 /* device_records[i] = member i's first record, resident on member i's device (slice sizes from hmpc_shard_bounds) */
 int hmpc_group_set_device_records(hmpc_group *g, const void *const *device_records, int batch, int max_reduced_vars);
 int hmpc_group_solve(hmpc_group *g);       /* asynchronous on every member */
+/* hmpc_solve_command_sweep on every member: every member's slice must consist of whole groups (contiguous deal, and
+ * slice sizes that are multiples of group_size -- e.g. batch = members x k x group_size), else HMPC_E_ARG and nothing is enqueued */
+int hmpc_group_solve_command_sweep(hmpc_group *g, int group_size);
 int hmpc_group_post_gather(hmpc_group *g); /* asynchronous: the exchange step for the solves enqueued so far */
 int hmpc_group_wait_gather(hmpc_group *g);
 /* member's gathered copy in HBM: [group size][slot_rows][6 nc + 1] 32-bit words (13 for two contacts), slot s = member s's

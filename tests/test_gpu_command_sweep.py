@@ -139,3 +139,50 @@ def test_sweep_flagged_instances_are_repaired_as_independent_ones(oracle):
         assert (interface.status_nactive(st) > 64).any()   # the regime really leaves the fast variant's capacity
         err = np.abs(forces - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
         assert err.max() < 2e-6, err.max()
+
+
+def test_terrain_sweep_per_instance_friction_on_a_shared_inverse(oracle):
+    """hmpc_set_instance_mu: one friction parameter per instance.  (1) It is the hmpc_params path per instance: the instances that
+    share a value come out bit for bit as a handle whose hmpc_params.mu is that value gives them (and that path is checked against
+    the oracle in tests/test_gpu_assembly.py); spot-checked against qpOASES with the oracle's parameters set accordingly.  (2) H does
+    not depend on mu, so a command-sweep group may mix floors: states x (commands x floors) on one inverse per state, bit-identical
+    to the independent solves."""
+    import torch
+
+    h, groups, k = 10, 12, 12
+    f = sweep_fields(groups, k, h, "standing", seed=47)
+    rec = records.pack_records(f, h)
+    b = groups * k
+    mus = np.array([0.8, 1.25, 2.0, 3.0], dtype=np.float32)
+    mu_i = mus[np.arange(b) % 4]                       # inside every group: four floors x three commands
+    d_mu = torch.from_numpy(mu_i).cuda()
+    m = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, b)
+    m.upload(rec)
+    m.set_instance_mu(d_mu.data_ptr(), keepalive=d_mu)
+    m.solve()
+    f_ind, s_ind = m.download()
+    m.solve_command_sweep(k)
+    f_sw, s_sw = m.download()
+    assert (interface.status_code(s_ind) == 0).all()
+    np.testing.assert_array_equal(f_sw.view(np.uint32), f_ind.view(np.uint32))
+    np.testing.assert_array_equal(s_sw, s_ind)
+    m.set_instance_mu(0)
+    for j, mu in enumerate(mus):
+        m.set_params(mu=float(mu))
+        m.solve()
+        f_p, s_p = m.download()
+        sel = (np.arange(b) % 4) == j
+        np.testing.assert_array_equal(f_p[sel].view(np.uint32), f_ind[sel].view(np.uint32))
+        np.testing.assert_array_equal(s_p[sel], s_ind[sel])
+        try:                                            # ... and what qpOASES gives for that floor
+            oracle.set_params(mu=float(mu))
+            idx = np.flatnonzero(sel)[:6]
+            ref = oracle.solve_records(np.ascontiguousarray(rec[idx]), h, synthetic.DT_MPC, synthetic.F_MAX)
+        finally:
+            oracle.set_params()
+        q = ref["q_soln"]
+        err = np.abs(f_ind[idx] - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+        assert ref["n_bad"] == 0 and err.max() < 1e-4, (mu, err.max())
+    m.close()
+    # the floors really matter
+    assert np.abs(f_ind[0::4] - f_ind[3::4]).max() > 1e-3

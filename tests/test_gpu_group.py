@@ -298,3 +298,29 @@ def test_striped_deal_ragged_batches_equal_a_single_handle(nb, G):
         np.testing.assert_array_equal(forces.view(np.uint32), ref_f.view(np.uint32))
         np.testing.assert_array_equal(wrench.view(np.uint32), ref_f[:, :12].view(np.uint32))
         np.testing.assert_array_equal(wstat, ref_s)
+
+
+def test_group_command_sweep_equals_a_single_handle():
+    """hmpc_group_solve_command_sweep: every member runs the command sweep on its slice (whole groups per slice) -- the gathered
+    wrench and the full download are the bits of the independent solves of a single handle; slices that would tear a group apart,
+    and the striped deal, are refused before anything is enqueued."""
+    from tests.test_gpu_command_sweep import sweep_fields
+
+    groups, k = 12, 8                      # 96 instances: three members x four groups x eight commands
+    rec = records.pack_records(sweep_fields(groups, k, H, "standing", seed=51), H)
+    ref_f, ref_s = _single(rec)
+    grp = interface.DeviceGroup(synthetic.DT_MPC, H, synthetic.F_MAX, groups * k, [0, 0, 0], "p2p")
+    grp.upload(rec)
+    grp.solve_command_sweep(k)
+    wrench, status = grp.gather_wrench()
+    np.testing.assert_array_equal(status, ref_s)
+    np.testing.assert_array_equal(wrench.view(np.uint32), ref_f[:, :12].view(np.uint32))
+    full_f, full_s = grp.download()
+    np.testing.assert_array_equal(full_f.view(np.uint32), ref_f.view(np.uint32))
+    with pytest.raises(interface.HmpcError):
+        grp.solve_command_sweep(5)         # 32 instances per member are not whole groups of five
+    grp.set_deal(True)
+    grp.upload(rec)
+    with pytest.raises(interface.HmpcError):
+        grp.solve_command_sweep(k)         # a striped deal scatters every group over the members
+    grp.close()
