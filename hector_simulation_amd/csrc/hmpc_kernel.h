@@ -940,6 +940,55 @@ constexpr bool fits_three_waves() {
 
 // ---------------------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------------------
+// Which 6 x 6 leg-step blocks of the symmetric matrix a thread holds in registers: thread t owns blocks number t, t + NT, ... (< NG (NG + 1) / 2)
+// of the sweep order, block-row-major: (e0, e1), e0 <= e1.  BPT == 1: plain registers.  BPT == 2 (256 VGPRs, 144 of them the two
+// blocks): the coordinates of a slot travel PACKED in one register (bits 0-5 e0, 6-11 e1, 12 owner) and are unpacked where they are
+// used, behind an opaque copy (fence) so that the compiler cannot hoist the unpacked values back into registers that live -- and
+// spill -- for the rest of the kernel: fence() at the head of a phase makes what the phase unpacks live for that phase only.
+template <int NG, int NT, int BPT>
+struct BlockOwner {
+  static constexpr int NTILE = NG * (NG + 1) / 2;
+  int e0_r[BPT], e1_r[BPT], i0_r[BPT], j0_r[BPT];
+  bool owner_r[BPT], diag_r[BPT];
+  unsigned pk[BPT];
+  __device__ __forceinline__ void fence() {
+    if constexpr (BPT == 2) {
+#pragma unroll
+      for (int s = 0; s < BPT; ++s) asm volatile("" : "+v"(pk[s]));
+    }
+  }
+  __device__ __forceinline__ int E0(const int s) const { if constexpr (BPT == 1) return e0_r[s]; else return (int)(pk[s] & 63u); }
+  __device__ __forceinline__ int E1(const int s) const { if constexpr (BPT == 1) return e1_r[s]; else return (int)((pk[s] >> 6) & 63u); }
+  __device__ __forceinline__ int I0(const int s) const { if constexpr (BPT == 1) return i0_r[s]; else return GS * (int)(pk[s] & 63u); }
+  __device__ __forceinline__ int J0(const int s) const { if constexpr (BPT == 1) return j0_r[s]; else return GS * (int)((pk[s] >> 6) & 63u); }
+  __device__ __forceinline__ bool OWN(const int s) const { if constexpr (BPT == 1) return owner_r[s]; else return ((pk[s] >> 12) & 1u) != 0; }
+  __device__ __forceinline__ bool DIAG(const int s) const {
+    if constexpr (BPT == 1) return diag_r[s];
+    else { const unsigned v = pk[s]; return (v & 63u) == ((v >> 6) & 63u); }
+  }
+  // (called right before the first load of the blocks: nothing of it is live during the chains of H)
+  __device__ __forceinline__ void assign() {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < BPT; ++s) {
+      const int t = tid + s * NT;
+      int ea = 0;
+      while (ea < NG - 1 && (ea + 1) * NG - (ea + 1) * ea / 2 <= t) ++ea;
+      const bool ow = t < NTILE;
+      const int eb = ow ? ea + (t - (ea * NG - ea * (ea - 1) / 2)) : 0;
+      ea = ow ? ea : 0;
+      if constexpr (BPT == 1) {
+        owner_r[s] = ow, e1_r[s] = eb, e0_r[s] = ea;
+        diag_r[s] = (ea == eb);
+        i0_r[s] = GS * ea, j0_r[s] = GS * eb;
+      } else {
+        pk[s] = (unsigned)ea | ((unsigned)eb << 6) | (ow ? 4096u : 0u);
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
 // Stage A1 + A2 of the kernel as a function.  In: the instance's packed record in S.u.a.rec (stage A0), the robot constants in
 // args.  Out, in LDS: the trigonometric tables, x0, Acd, Bcd, the weights W and the per-step constraint block Fc (Smem::Asm);
 // the per-contact constraint normals Cn, the stance prefix counts and every index table of the swing elimination, ub7 / sc7, n, m,
@@ -1368,196 +1417,30 @@ __device__ __forceinline__ void stage_output(Smem<NMAX, HMAX, NT, QCAP, NC, BPT>
   }
 }
 
-// MODE 0: the product path, one workgroup = one independent instance.
-// MODE 1: COMMAND SWEEPS (hmpc_solve_command_sweep).  The batch is groups of args.sweep_k consecutive records that share
-// everything but the reference trajectory -- state, feet, joints, weights, gait table (ConvexMPCLocomotion.cpp:351-406 builds the
-// trajectory from the commands; SolverMPC.cpp:398-447, 488-570 builds A_qp, B_qp, H and the constraint block from the state and
-// the gait alone) -- so H and its inverse M are a property of the GROUP.  Two launches of this kernel:
-//   phase 0 (args.sweep_phase == 0), one workgroup per group: stages A, H, S on the group's first record, M written to the
-//     group's slot in HBM (36 x NT doubles, the register blocks' own layout, coalesced), nothing else;
-//   phase 1, one workgroup per INSTANCE (the chip stays as full as for independent solves): stage A on the instance's own
-//     record (its own g, the same chains), M read from its group's slot instead of stages H and S (55 % of an independent solve),
-//     then stages W and Q as they stand.  Same operands, same instructions: forces and status words are bit-identical to MODE 0's.
-//   A record that differs from its group's first one anywhere but in the trajectory is not solved (HMPC_S_SWEEP_MISMATCH).
-template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC = 2, int BPT = 1, int MODE = 0>
-__global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, QCAP, NC, BPT>()) ? (NT == 128 ? WAVES_PER_EU_128 : WAVES_PER_EU_256) : 2) void hmpc_kernel(KernelArgs args) {
+// ---------------------------------------------------------------------------------------------------------------
+// Stage A5 (H) as a function.  In (LDS, Smem::Asm): Phi_k, the weights W, alpha (the record), the reference-order index tables.  Out: H in
+// binary32 in the staging area Smem::Asm::Hs -- exact, every block of a block-diagonal a prefix of ONE fmaf chain on
+// v_mfma_f32_16x16x4_f32 (FULLBLK variants), 16 x 16 tiles over the reduced variables otherwise -- and, unless stage S reads the staging
+// itself (TILES_FROM_STAGING: the matrix-core sweeps of the 120-variable variants), the 6 x 6 register blocks `a` filled from it, pass by
+// pass where the staging holds only part of the block-diagonals at a time.  Assembly-only kernels dump H instead.  `bo` is assigned here.
+template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC, int BPT, bool TILES_FROM_STAGING>
+__device__ __forceinline__ void stage_h(Smem<NMAX, HMAX, NT, QCAP, NC, BPT> &S, const KernelArgs &args, const int inst, const int h, const int n, const int ng,
+                                        BlockOwner<Smem<NMAX, HMAX, NT, QCAP, NC, BPT>::NG, NT, BPT> &bo, double (&a)[BPT][GS][GS]) {
   using SM = Smem<NMAX, HMAX, NT, QCAP, NC, BPT>;
-  constexpr bool SWEEP = (MODE == 1);
-  static_assert(!SWEEP || (!ASM_ONLY && BPT == 1 && NC == 2 && QCAP != 0), "command sweeps: the fast two-contact variants");
   using RL = RecLayout<NC>;
-  constexpr int NG = SM::NG, NW = SM::NW, U = SM::U, PS = SM::PS, C8 = 8 * NC;
-  static_assert(NC == 2 || (NC == 3 && NT * BPT >= 512), "contacts: two feet (reference) or two feet + hand (extension)");
-  static_assert(BPT == 1 || BPT == 2, "register blocks per thread");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  SM &S = *reinterpret_cast<SM *>(smem_raw);
+  constexpr int NW = SM::NW, U = SM::U, PS = SM::PS;
+  constexpr bool MFMA_SWEEP = TILES_FROM_STAGING;
   auto &A = S.u.a;
-  auto &Q = S.u.s;
-  // the packed Schur inverse: LDS, or this workgroup's slice of the global scratch
-  double *const Ep = [&]() __attribute__((always_inline)) -> double * {
-    if constexpr (SM::EGLOBAL) return args.e_scratch + (size_t)blockIdx.x * (size_t)(NMAX * (NMAX + 1) / 2);
-    else return S.u.s.Ep;
-  }();
-  auto Eat = [&](int i, int j) __attribute__((always_inline)) -> double & {
-    const int lo = i < j ? i : j, hi = i < j ? j : i;
-    return Ep[(unsigned)(hi * (hi + 1) / 2 + lo)];  // (unsigned: a scalar base + 32-bit lane offset when E is in global memory)
-  };
-
   const int tid = threadIdx.x, wv = uni(tid >> 6);
-  const auto ln = lazy_int<(BPT == 2)>([](int t) { return t & 63; });  // lane (recomputed at every use in the two-block variants)
-  if (!ASM_ONLY && args.list_count && blockIdx.x >= *args.list_count) return;  // device-side safe pass: nothing (more) flagged
-  // (uniform by construction -- but when it comes from the index list it arrives through a vector load: told to the compiler, so
-  //  that the instance's base addresses are scalar arithmetic instead of register pairs that live for the whole kernel)
-  const int inst = uni(ASM_ONLY ? args.dbg_index
-                                : ((SWEEP && args.sweep_phase == 0) ? (int)blockIdx.x * args.sweep_k  // the group's first record
-                                                                    : (args.index_list ? args.index_list[blockIdx.x] : (int)blockIdx.x)));
-  const int h = args.horizon;
-  if (inst >= args.batch) return;
-  // command sweeps: M comes from (phase 1) or goes to (phase 0) this group's slot
-  const bool sweep_prepare = SWEEP && args.sweep_phase == 0, sweep_given = SWEEP && args.sweep_phase != 0;
-  double *const sweep_m = SWEEP ? args.sweep_m + (size_t)(inst / (SWEEP ? args.sweep_k : 1)) * (size_t)(GS * GS * NT) : nullptr;
-  if (!ASM_ONLY && args.cls) {  // uniform: this instance belongs to another variant's launch
-    const int c = args.cls[inst];
-    if (c < args.cls_lo || c > args.cls_hi) return;
-  }
-  PROF_DECL;
-  // Hand-over of a full working set (KernelArgs::spill, SpillLayout): the fast 120-variable variants SAVE their state, the safe
-  // variants of the same shape (working set = variable count, in LDS) RESUME from it -- they assemble the instance again (index
-  // tables, constraint normals, g: cheap and bit-identical), then take M, E and the Goldfarb-Idnani state from the slot instead of
-  // running stages H, S and the start
-  constexpr bool SHAPE_HANDOVER = !ASM_ONLY && NMAX == 120 && NT == 256 && NC == 2 && BPT == 1 && !SM::EGLOBAL;
-  constexpr bool SPILLS = SHAPE_HANDOVER && QCAP < HMPC_QCAP_CONT;      // the fast variants (working set of 64 rows, three per CU)
-  // the continuation variant (96 rows, two per CU): takes over what the fast variants hand over, with block rounds of its own (up to
-  // its 96 rows at once, the Schur matrix as 6 x 6 tiles on the matrix cores), and flags what outgrows it in turn for the safe variant
-  constexpr bool RESUMABLE = SHAPE_HANDOVER && QCAP >= HMPC_QCAP_CONT && QCAP < NMAX;
-  constexpr bool CONT = RESUMABLE;
-  using SPL = SpillLayout<SM, NT, BPT>;
-  bool resumed = false;
-  if constexpr (RESUMABLE) {
-    // (the slot must be this instance's own and its status word must still say "working set full": both are written by the fast
-    //  variant in the same solve; anything else -- a stale entry of an earlier batch -- starts cold)
-    if (args.resume) resumed = ub(args.spill_slot[inst] == inst && inst < args.spill_cap && (args.status[inst] & 0xffu) == (uint32_t)S_WORKSET);
-    if (args.resume == 2 && !resumed) return;  // a continuation-only launch: everything else on the list is the safe variant's
-  }
-  if constexpr (!ASM_ONLY && (SM::EGLOBAL || (QCAP >= NMAX && NMAX >= 120))) {  // (the safe-pass variants)
-    if (args.skip_ok) {  // second pass over a list of flagged instances: what the pass before it solved is left alone
-      const uint32_t c0 = args.status[inst] & 0xffu;
-      if (c0 == (uint32_t)S_OK || c0 == (uint32_t)S_OK_RELAXED) return;
-    }
-  }
-
-  // ---------------- A0: one coalesced burst brings the instance's record into LDS ----------------
-  {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(args.records + (size_t)inst * args.stride);
-    const int nwords = args.stride >> 2;
-    for (int t = tid; t < nwords; t += NT) A.rec[t] = src[t];
-  }
-  if constexpr (SWEEP) {
-    if (sweep_given) {
-      // every word of the record but the trajectory must equal the group's first record's (whose M this solve uses)
-      const int first = (inst / args.sweep_k) * args.sweep_k;
-      const uint32_t *base = reinterpret_cast<const uint32_t *>(args.records + (size_t)first * args.stride);
-      const int nfix = RL::NF, ntraj = 12 * args.horizon, ngw = (NC * args.horizon + 3) >> 2;
-      const uint32_t *own = reinterpret_cast<const uint32_t *>(args.records + (size_t)inst * args.stride);
-      int bad = 0;
-      for (int t = tid; t < nfix + ngw; t += NT) {
-        const int w = t < nfix ? t : t + ntraj;
-        bad |= (own[w] != base[w]) ? 1 : 0;
-      }
-      if (__syncthreads_or(bad)) {  // uniform
-        for (int t = tid; t < 6 * NC * args.horizon; t += NT) args.forces[(size_t)inst * 6 * NC * args.horizon + t] = 0.0f;
-        if (tid == 0) args.status[inst] = S_SWEEP_MISMATCH;
-        return;
-      }
-    }
-  }
-  __syncthreads();
-  PROF_MARK(P_A0);
-  const float *rf = reinterpret_cast<const float *>(A.rec);
-  const unsigned char *gait = reinterpret_cast<const unsigned char *>(A.rec + RL::NF + 12 * h);
-  const float *in_al = rf + RL::AL;  // (alpha: the diagonal of H, stage A5)
-  // Fz cap of a contact: f_max for the feet; the hand's own cap travels in the extension record (the assembly-only dump's bounds)
-  auto fz_cap = [&](int c) __attribute__((always_inline)) -> float { return (NC == 3 && c == 2) ? rf[RL::FMH] : args.f_max; };
-
-  // ---------------- A1 + A2: trigonometry, scalar algebra, constraint block, elimination tables (stage_a_scalars above)
-  stage_a_scalars<NMAX, HMAX, NT, QCAP, NC, BPT>(S, args, inst, h, prof);
-  PROF_MARK(P_A2);
-
-  const int n = uni(S.n), m = uni(S.m), ng = uni(S.nls);
-  if (ng > NG) {  // uniform
-    if (!ASM_ONLY) {
-      for (int t = tid; t < U * h; t += NT) args.forces[(size_t)inst * U * h + t] = 0.0f;
-      if (args.wset)  // nothing to carry to the next tick from an instance that was not solved
-        for (int t = tid; t < C8 * h; t += NT) args.wset[(size_t)inst * C8 * h + t] = 0;
-      if (tid == 0) args.status[inst] = S_TOO_LARGE;
-    } else if (tid == 0) {
-      args.dbg_i[0] = n;
-      args.dbg_i[1] = m;
-    }
-    return;
-  }
-
-  // ---------------- A3/A4 + g: powers of Acd, Phi_k, tracking error, gradient (stage_a_chains above)
-  stage_a_chains<NMAX, HMAX, NT, QCAP, NC, BPT>(S, args, inst, h, n, prof);
-  // ---- register blocks of the sweeps (stage S): thread t owns the 6x6 blocks number t, t + NT, ... (< NG(NG+1)/2) of the
-  // symmetric matrix in sweep order, block-row-major: (e0, e1), e0 <= e1.  Declared here because the blocks are filled
-  // straight from the staging area of H, pass by pass where that area holds only part of the block-diagonals at a time.
-  // Matrix-core sweeps: the FAST 120-variable variants only.  The safe-pass variants (working set = variable count) keep the
-  // scalar sweeps: 4 x 4 block pivots apply an explicitly inverted pivot block, whose forward error carries cond(D) -- at 10x
-  // the nominal input ranges that showed as forces up to 9e-5 from qpOASES in the safe pass (7e-8 with scalar pivots), while
-  // nominal inputs are unaffected (5.8e-8 either way) and whatever the fast variants get wrong beyond 2e-6 is caught by
-  // their KKT check and handed to the safe pass anyway.
-  constexpr bool MFMA_SWEEP = !ASM_ONLY && QCAP != 0 && (SM::MFS2 && QCAP < NMAX);
-  // (the 60-variable variants are fast-pass only: the safe pass of two-contact batches runs on the 120-variable safe variants)
-  // ... and the fast three-contact variant (180 variables, two blocks per thread): 78 tiles, 20 per wave.  Its staging of H holds
-  // the block-diagonals in two passes, so the register blocks are filled as for the scalar sweeps and turned into tiles in stage S.
-  constexpr bool MFMA_SWEEP3 = SM::MFS3 && !ASM_ONLY && QCAP != 0 && QCAP < NMAX;
-  constexpr int MFS3_NTG = (NMAX + 15) / 16;
-  constexpr int NTILE = NG * (NG + 1) / 2;
-  static_assert(NTILE <= BPT * NT && SM::MMAX <= NT && NMAX <= NT, "threads per block / constraint row / variable");
-  // BPT == 1: plain registers.  BPT == 2 (256 VGPRs, 144 of them the two blocks): the coordinates of a slot travel PACKED in
-  // one register (bits 0-5 e0, 6-11 e1, 12 owner) and are unpacked where they are used, behind an opaque copy so that the
-  // compiler cannot hoist the unpacked values back into registers that live -- and spill -- for the rest of the kernel.
-  int e0_r[BPT], e1_r[BPT], i0_r[BPT], j0_r[BPT];
-  bool owner_r[BPT], diag_r[BPT];
-  unsigned pk[BPT];
-  auto PK = [&](const int s) __attribute__((always_inline)) -> unsigned { return pk[s]; };
-  // ... "behind an opaque copy": pk_fence() makes the packed words opaque at the head of a phase, so that what a phase unpacks
-  // lives in registers for that phase only (inside the sweeps that is what one wants; across the whole solve it is not)
-  auto pk_fence = [&]() __attribute__((always_inline)) {
-    if constexpr (BPT == 2) {
-#pragma unroll
-      for (int s = 0; s < BPT; ++s) asm volatile("" : "+v"(pk[s]));
-    }
-  };
-  auto E0 = [&](const int s) __attribute__((always_inline)) -> int { if constexpr (BPT == 1) return e0_r[s]; else return (int)(PK(s) & 63u); };
-  auto E1 = [&](const int s) __attribute__((always_inline)) -> int { if constexpr (BPT == 1) return e1_r[s]; else return (int)((PK(s) >> 6) & 63u); };
-  auto I0 = [&](const int s) __attribute__((always_inline)) -> int { if constexpr (BPT == 1) return i0_r[s]; else return GS * (int)(PK(s) & 63u); };
-  auto J0 = [&](const int s) __attribute__((always_inline)) -> int { if constexpr (BPT == 1) return j0_r[s]; else return GS * (int)((PK(s) >> 6) & 63u); };
-  auto OWN = [&](const int s) __attribute__((always_inline)) -> bool { if constexpr (BPT == 1) return owner_r[s]; else return ((PK(s) >> 12) & 1u) != 0; };
-  auto DIAG = [&](const int s) __attribute__((always_inline)) -> bool {
-    if constexpr (BPT == 1) return diag_r[s];
-    else { const unsigned v = PK(s); return (v & 63u) == ((v >> 6) & 63u); }
-  };
-  auto own_blocks = [&]() __attribute__((always_inline)) {  // (called right before the first load: nothing of it is live during the chains)
-#pragma unroll
-    for (int s = 0; s < BPT; ++s) {
-      const int t = tid + s * NT;
-      int ea = 0;
-      while (ea < NG - 1 && (ea + 1) * NG - (ea + 1) * ea / 2 <= t) ++ea;
-      const bool ow = t < NTILE;
-      const int eb = ow ? ea + (t - (ea * NG - ea * (ea - 1) / 2)) : 0;
-      ea = ow ? ea : 0;
-      if constexpr (BPT == 1) {
-        owner_r[s] = ow, e1_r[s] = eb, e0_r[s] = ea;
-        diag_r[s] = (ea == eb);
-        i0_r[s] = GS * ea, j0_r[s] = GS * eb;
-      } else {
-        pk[s] = (unsigned)ea | ((unsigned)eb << 6) | (ow ? 4096u : 0u);
-      }
-    }
-  };
-  double a[BPT][GS][GS];
-  if (!((RESUMABLE && resumed) || sweep_given)) {  // (a resumed solve takes M from its hand-over slot, a command-sweep solve from its group's: no H, no sweeps)
+  const auto ln = lazy_int<(BPT == 2)>([](int t) { return t & 63; });
+  const float *in_al = reinterpret_cast<const float *>(A.rec) + RL::AL;  // alpha: the diagonal of H
+  auto E0 = [&](const int s) __attribute__((always_inline)) -> int { return bo.E0(s); };
+  auto E1 = [&](const int s) __attribute__((always_inline)) -> int { return bo.E1(s); };
+  auto I0 = [&](const int s) __attribute__((always_inline)) -> int { return bo.I0(s); };
+  auto J0 = [&](const int s) __attribute__((always_inline)) -> int { return bo.J0(s); };
+  auto OWN = [&](const int s) __attribute__((always_inline)) -> bool { return bo.OWN(s); };
+  auto DIAG = [&](const int s) __attribute__((always_inline)) -> bool { return bo.DIAG(s); };
+  auto own_blocks = [&]() __attribute__((always_inline)) { bo.assign(); };
   if constexpr (SM::FULLBLK) {
     // H on the matrix cores, through the block-Toeplitz structure of B_qp.  With Phi_k = Acd^k Bcd,
     //     H(a,b) = 2 [ sum_{i >= b} Phi_{i-a}' S Phi_{i-b} + alpha delta_ab ]          (U x U block, steps a <= b)
@@ -1833,6 +1716,167 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         }
     }
   }
+}
+
+// MODE 0: the product path, one workgroup = one independent instance.
+// MODE 1: COMMAND SWEEPS (hmpc_solve_command_sweep).  The batch is groups of args.sweep_k consecutive records that share
+// everything but the reference trajectory -- state, feet, joints, weights, gait table (ConvexMPCLocomotion.cpp:351-406 builds the
+// trajectory from the commands; SolverMPC.cpp:398-447, 488-570 builds A_qp, B_qp, H and the constraint block from the state and
+// the gait alone) -- so H and its inverse M are a property of the GROUP.  Two launches of this kernel:
+//   phase 0 (args.sweep_phase == 0), one workgroup per group: stages A, H, S on the group's first record, M written to the
+//     group's slot in HBM (36 x NT doubles, the register blocks' own layout, coalesced), nothing else;
+//   phase 1, one workgroup per INSTANCE (the chip stays as full as for independent solves): stage A on the instance's own
+//     record (its own g, the same chains), M read from its group's slot instead of stages H and S (55 % of an independent solve),
+//     then stages W and Q as they stand.  Same operands, same instructions: forces and status words are bit-identical to MODE 0's.
+//   A record that differs from its group's first one anywhere but in the trajectory is not solved (HMPC_S_SWEEP_MISMATCH).
+template <int NMAX, int HMAX, int NT, int QCAP, bool ASM_ONLY, int NC = 2, int BPT = 1, int MODE = 0>
+__global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, QCAP, NC, BPT>()) ? (NT == 128 ? WAVES_PER_EU_128 : WAVES_PER_EU_256) : 2) void hmpc_kernel(KernelArgs args) {
+  using SM = Smem<NMAX, HMAX, NT, QCAP, NC, BPT>;
+  constexpr bool SWEEP = (MODE == 1);
+  static_assert(!SWEEP || (!ASM_ONLY && BPT == 1 && NC == 2 && QCAP != 0), "command sweeps: the fast two-contact variants");
+  using RL = RecLayout<NC>;
+  constexpr int NG = SM::NG, NW = SM::NW, U = SM::U, PS = SM::PS, C8 = 8 * NC;
+  static_assert(NC == 2 || (NC == 3 && NT * BPT >= 512), "contacts: two feet (reference) or two feet + hand (extension)");
+  static_assert(BPT == 1 || BPT == 2, "register blocks per thread");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  SM &S = *reinterpret_cast<SM *>(smem_raw);
+  auto &A = S.u.a;
+  auto &Q = S.u.s;
+  // the packed Schur inverse: LDS, or this workgroup's slice of the global scratch
+  double *const Ep = [&]() __attribute__((always_inline)) -> double * {
+    if constexpr (SM::EGLOBAL) return args.e_scratch + (size_t)blockIdx.x * (size_t)(NMAX * (NMAX + 1) / 2);
+    else return S.u.s.Ep;
+  }();
+  auto Eat = [&](int i, int j) __attribute__((always_inline)) -> double & {
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    return Ep[(unsigned)(hi * (hi + 1) / 2 + lo)];  // (unsigned: a scalar base + 32-bit lane offset when E is in global memory)
+  };
+
+  const int tid = threadIdx.x, wv = uni(tid >> 6);
+  const auto ln = lazy_int<(BPT == 2)>([](int t) { return t & 63; });  // lane (recomputed at every use in the two-block variants)
+  if (!ASM_ONLY && args.list_count && blockIdx.x >= *args.list_count) return;  // device-side safe pass: nothing (more) flagged
+  // (uniform by construction -- but when it comes from the index list it arrives through a vector load: told to the compiler, so
+  //  that the instance's base addresses are scalar arithmetic instead of register pairs that live for the whole kernel)
+  const int inst = uni(ASM_ONLY ? args.dbg_index
+                                : ((SWEEP && args.sweep_phase == 0) ? (int)blockIdx.x * args.sweep_k  // the group's first record
+                                                                    : (args.index_list ? args.index_list[blockIdx.x] : (int)blockIdx.x)));
+  const int h = args.horizon;
+  if (inst >= args.batch) return;
+  // command sweeps: M comes from (phase 1) or goes to (phase 0) this group's slot
+  const bool sweep_prepare = SWEEP && args.sweep_phase == 0, sweep_given = SWEEP && args.sweep_phase != 0;
+  double *const sweep_m = SWEEP ? args.sweep_m + (size_t)(inst / (SWEEP ? args.sweep_k : 1)) * (size_t)(GS * GS * NT) : nullptr;
+  if (!ASM_ONLY && args.cls) {  // uniform: this instance belongs to another variant's launch
+    const int c = args.cls[inst];
+    if (c < args.cls_lo || c > args.cls_hi) return;
+  }
+  PROF_DECL;
+  // Hand-over of a full working set (KernelArgs::spill, SpillLayout): the fast 120-variable variants SAVE their state, the safe
+  // variants of the same shape (working set = variable count, in LDS) RESUME from it -- they assemble the instance again (index
+  // tables, constraint normals, g: cheap and bit-identical), then take M, E and the Goldfarb-Idnani state from the slot instead of
+  // running stages H, S and the start
+  constexpr bool SHAPE_HANDOVER = !ASM_ONLY && NMAX == 120 && NT == 256 && NC == 2 && BPT == 1 && !SM::EGLOBAL;
+  constexpr bool SPILLS = SHAPE_HANDOVER && QCAP < HMPC_QCAP_CONT;      // the fast variants (working set of 64 rows, three per CU)
+  // the continuation variant (96 rows, two per CU): takes over what the fast variants hand over, with block rounds of its own (up to
+  // its 96 rows at once, the Schur matrix as 6 x 6 tiles on the matrix cores), and flags what outgrows it in turn for the safe variant
+  constexpr bool RESUMABLE = SHAPE_HANDOVER && QCAP >= HMPC_QCAP_CONT && QCAP < NMAX;
+  constexpr bool CONT = RESUMABLE;
+  using SPL = SpillLayout<SM, NT, BPT>;
+  bool resumed = false;
+  if constexpr (RESUMABLE) {
+    // (the slot must be this instance's own and its status word must still say "working set full": both are written by the fast
+    //  variant in the same solve; anything else -- a stale entry of an earlier batch -- starts cold)
+    if (args.resume) resumed = ub(args.spill_slot[inst] == inst && inst < args.spill_cap && (args.status[inst] & 0xffu) == (uint32_t)S_WORKSET);
+    if (args.resume == 2 && !resumed) return;  // a continuation-only launch: everything else on the list is the safe variant's
+  }
+  if constexpr (!ASM_ONLY && (SM::EGLOBAL || (QCAP >= NMAX && NMAX >= 120))) {  // (the safe-pass variants)
+    if (args.skip_ok) {  // second pass over a list of flagged instances: what the pass before it solved is left alone
+      const uint32_t c0 = args.status[inst] & 0xffu;
+      if (c0 == (uint32_t)S_OK || c0 == (uint32_t)S_OK_RELAXED) return;
+    }
+  }
+
+  // ---------------- A0: one coalesced burst brings the instance's record into LDS ----------------
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(args.records + (size_t)inst * args.stride);
+    const int nwords = args.stride >> 2;
+    for (int t = tid; t < nwords; t += NT) A.rec[t] = src[t];
+  }
+  if constexpr (SWEEP) {
+    if (sweep_given) {
+      // every word of the record but the trajectory must equal the group's first record's (whose M this solve uses)
+      const int first = (inst / args.sweep_k) * args.sweep_k;
+      const uint32_t *base = reinterpret_cast<const uint32_t *>(args.records + (size_t)first * args.stride);
+      const int nfix = RL::NF, ntraj = 12 * args.horizon, ngw = (NC * args.horizon + 3) >> 2;
+      const uint32_t *own = reinterpret_cast<const uint32_t *>(args.records + (size_t)inst * args.stride);
+      int bad = 0;
+      for (int t = tid; t < nfix + ngw; t += NT) {
+        const int w = t < nfix ? t : t + ntraj;
+        bad |= (own[w] != base[w]) ? 1 : 0;
+      }
+      if (__syncthreads_or(bad)) {  // uniform
+        for (int t = tid; t < 6 * NC * args.horizon; t += NT) args.forces[(size_t)inst * 6 * NC * args.horizon + t] = 0.0f;
+        if (tid == 0) args.status[inst] = S_SWEEP_MISMATCH;
+        return;
+      }
+    }
+  }
+  __syncthreads();
+  PROF_MARK(P_A0);
+  const float *rf = reinterpret_cast<const float *>(A.rec);
+  const unsigned char *gait = reinterpret_cast<const unsigned char *>(A.rec + RL::NF + 12 * h);
+  // Fz cap of a contact: f_max for the feet; the hand's own cap travels in the extension record (the assembly-only dump's bounds)
+  auto fz_cap = [&](int c) __attribute__((always_inline)) -> float { return (NC == 3 && c == 2) ? rf[RL::FMH] : args.f_max; };
+
+  // ---------------- A1 + A2: trigonometry, scalar algebra, constraint block, elimination tables (stage_a_scalars above)
+  stage_a_scalars<NMAX, HMAX, NT, QCAP, NC, BPT>(S, args, inst, h, prof);
+  PROF_MARK(P_A2);
+
+  const int n = uni(S.n), m = uni(S.m), ng = uni(S.nls);
+  if (ng > NG) {  // uniform
+    if (!ASM_ONLY) {
+      for (int t = tid; t < U * h; t += NT) args.forces[(size_t)inst * U * h + t] = 0.0f;
+      if (args.wset)  // nothing to carry to the next tick from an instance that was not solved
+        for (int t = tid; t < C8 * h; t += NT) args.wset[(size_t)inst * C8 * h + t] = 0;
+      if (tid == 0) args.status[inst] = S_TOO_LARGE;
+    } else if (tid == 0) {
+      args.dbg_i[0] = n;
+      args.dbg_i[1] = m;
+    }
+    return;
+  }
+
+  // ---------------- A3/A4 + g: powers of Acd, Phi_k, tracking error, gradient (stage_a_chains above)
+  stage_a_chains<NMAX, HMAX, NT, QCAP, NC, BPT>(S, args, inst, h, n, prof);
+  // ---- register blocks of the sweeps (stage S): thread t owns the 6x6 blocks number t, t + NT, ... (< NG(NG+1)/2) of the
+  // symmetric matrix in sweep order, block-row-major: (e0, e1), e0 <= e1.  Declared here because the blocks are filled
+  // straight from the staging area of H, pass by pass where that area holds only part of the block-diagonals at a time.
+  // Matrix-core sweeps: the FAST 120-variable variants only.  The safe-pass variants (working set = variable count) keep the
+  // scalar sweeps: 4 x 4 block pivots apply an explicitly inverted pivot block, whose forward error carries cond(D) -- at 10x
+  // the nominal input ranges that showed as forces up to 9e-5 from qpOASES in the safe pass (7e-8 with scalar pivots), while
+  // nominal inputs are unaffected (5.8e-8 either way) and whatever the fast variants get wrong beyond 2e-6 is caught by
+  // their KKT check and handed to the safe pass anyway.
+  constexpr bool MFMA_SWEEP = !ASM_ONLY && QCAP != 0 && (SM::MFS2 && QCAP < NMAX);
+  // (the 60-variable variants are fast-pass only: the safe pass of two-contact batches runs on the 120-variable safe variants)
+  // ... and the fast three-contact variant (180 variables, two blocks per thread): 78 tiles, 20 per wave.  Its staging of H holds
+  // the block-diagonals in two passes, so the register blocks are filled as for the scalar sweeps and turned into tiles in stage S.
+  constexpr bool MFMA_SWEEP3 = SM::MFS3 && !ASM_ONLY && QCAP != 0 && QCAP < NMAX;
+  constexpr int MFS3_NTG = (NMAX + 15) / 16;
+  constexpr int NTILE = NG * (NG + 1) / 2;
+  static_assert(NTILE <= BPT * NT && SM::MMAX <= NT && NMAX <= NT, "threads per block / constraint row / variable");
+  // which 6 x 6 register blocks this thread holds (BlockOwner above); thin local names for the accessors
+  BlockOwner<NG, NT, BPT> bo;
+  auto pk_fence = [&]() __attribute__((always_inline)) { bo.fence(); };
+  auto E0 = [&](const int s) __attribute__((always_inline)) -> int { return bo.E0(s); };
+  auto E1 = [&](const int s) __attribute__((always_inline)) -> int { return bo.E1(s); };
+  auto I0 = [&](const int s) __attribute__((always_inline)) -> int { return bo.I0(s); };
+  auto J0 = [&](const int s) __attribute__((always_inline)) -> int { return bo.J0(s); };
+  auto OWN = [&](const int s) __attribute__((always_inline)) -> bool { return bo.OWN(s); };
+  auto DIAG = [&](const int s) __attribute__((always_inline)) -> bool { return bo.DIAG(s); };
+  auto own_blocks = [&]() __attribute__((always_inline)) { bo.assign(); };
+  double a[BPT][GS][GS];
+  if (!((RESUMABLE && resumed) || sweep_given)) {  // (a resumed solve takes M from its hand-over slot, a command-sweep solve from its group's: no H, no sweeps)
+    // ---------------- A5: H = 2(B'SB + alpha) on the matrix cores into the staging area, then the register blocks (stage_h above)
+    stage_h<NMAX, HMAX, NT, QCAP, ASM_ONLY, NC, BPT, MFMA_SWEEP>(S, args, inst, h, n, ng, bo, a);
   }  // !resumed
 
   PROF_MARK(P_HG);
@@ -1931,13 +1975,13 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     MfsPanel<NTG1> &PN = *reinterpret_cast<MfsPanel<NTG1> *>(&Q.ST[0][0]);
     double *stage = reinterpret_cast<double *>(&S.u);
     static_assert(sizeof(S.u) / sizeof(double) >= 48 * (NMAX + 1), "re-layout staging of the matrix-core sweeps: 48 rows of M at stride NMAX + 1");
-    const bool live0 = owner_r[0] && e1_r[0] < ng;
+    const bool live0 = bo.owner_r[0] && bo.e1_r[0] < ng;
     static_assert(NW == 4, "per-wave code of the matrix-core sweeps: four waves");
     switch (wv) {  // uniform: per-wave specialised code
-      case 0: mfma_sweeps<NTG1, 4, 0, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
-      case 1: mfma_sweeps<NTG1, 4, 1, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
-      case 2: mfma_sweeps<NTG1, 4, 2, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
-      default: mfma_sweeps<NTG1, 4, 3, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, e0_r[0], e1_r[0], live0, a); break;
+      case 0: mfma_sweeps<NTG1, 4, 0, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, bo.e0_r[0], bo.e1_r[0], live0, a); break;
+      case 1: mfma_sweeps<NTG1, 4, 1, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, bo.e0_r[0], bo.e1_r[0], live0, a); break;
+      case 2: mfma_sweeps<NTG1, 4, 2, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, bo.e0_r[0], bo.e1_r[0], live0, a); break;
+      default: mfma_sweeps<NTG1, 4, 3, NMAX, NT>(PN, stage, n, hinfo, hval, S.kexp, bo.e0_r[0], bo.e1_r[0], live0, a); break;
     }
   } else if constexpr (MFMA_SWEEP3) {
     // ---- the same on the tiles filled in stage A5
