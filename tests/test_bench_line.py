@@ -245,3 +245,19 @@ def test_rank_bring_up_fails_with_diagnostics_within_its_timeout(tmp_path):
     assert "device(s) visible" in err or "device query failed" in err
     assert "NCCL_DEBUG=WARN" in err and "HSA_ENABLE_IPC_MODE_LEGACY=0" in err and f"MASTER_PORT={port}" in err and "WORLD_SIZE=2" in err
     assert "--exchange none" in err  # (the hint at the diagnostic mode)
+
+
+@pytest.mark.gpu
+def test_bench_exchange_none_is_a_diagnosable_line_without_any_collective():
+    """`--exchange none`: N ranks, NO data-path collective, control plane on gloo -- what to run when the RCCL
+    exchange of the default mode cannot be brought up.  Two ranks on the one GPU of the test box: the line carries both ranks' kernel
+    times and parity blocks, and says that nothing was gathered."""
+    d = _torchrun(2, 29547, "--steps", "4", "--warmup", "1", "--batch", "1024", "--check", "16", "--backend", "gloo", "--exchange", "none",
+                  "--windows", "3")
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2048
+    assert "NO exchange" in d["config"]["parallelism"] and d["config"]["exchange_backend"].startswith("none")
+    assert "exchange_selfcheck_ok" not in d["config"]
+    assert len(d["solver"]["kernel_ms_per_rank"]) == 2 and d["parity"]["ranks_checked"] == 2
+    assert d["parity"]["max_rel_force_err_vs_qpoases"] < 1e-4 and d["solver"]["failed_over_all_ranks"] == 0
+    assert d["windows"]["n"] == 3 and len(d["windows"]["values"]) == 3
+    assert d["windows"]["value_min"] <= d["value"] <= d["windows"]["value_max"]
