@@ -143,6 +143,7 @@ struct hmpc_handle {
 // than the ~512-1536 workgroup slots of the chip -- and not beyond what the one-workgroup sort handles in a few microseconds
 constexpr int DISPATCH_ORDER_MIN_BATCH = 512, DISPATCH_ORDER_MAX_BATCH = 32768;
 constexpr int REPAIR_GRID_CAP = 65536;  // workgroups of the device-side safe launch = most instances it can repair per solve (until round 6: 2 048; workgroups beyond the flagged count leave at once)
+constexpr double SAFE_PASS_RELAX = 1e-6;  // first safe pass (device- and host-driven): bounds moved outward by this, exact re-solve + exact KKT check at its end
 constexpr int SPILL_SLOT_CAP = 32768;   // hand-over slots per handle at most (101 KB each for 120 variables: 3.3 GB of the 288 GB); instances beyond it are re-solved cold
 constexpr int EGLOBAL_CHUNK = 512;         // host-driven safe pass of the global-E variants: instances per launch (118 MB of scratch at 240 variables)
 constexpr int REPAIR_GRID_CAP_WIDE = 256;  // ... of the wide variant's, whose safe pass keeps 231 KB per workgroup in global memory
@@ -215,7 +216,7 @@ struct LaunchOpt {
   int safe_variant = -1;   // safe pass over an index list: this entry of variants() instead of the one derived from pick_variant
   bool resume = false;     // safe pass over an index list: instances whose fast solve left its state in a hand-over slot continue from it
   bool continuation = false;  // list launch of the CONTINUATION variant (V2_CONT): only instances with a hand-over slot, everything else on the list is left alone
-  bool skip_ok = false;    // list launch: instances an earlier pass over the same list solved are left alone
+  int skip_ok = 0;         // list launch: instances an earlier pass over the same list solved are left alone (1: ok / ok-relaxed, 2: ok only)
   int sweep_k = 0, sweep_phase = 0;  // command sweep: group size; phase 0 = one workgroup per group forms M, 1 = one per instance solves with it (variant = a MODE 1 entry)
 };
 
@@ -318,7 +319,7 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   } else if (o.continuation) {
     return HMPC_OK;  // nothing was handed over (hand-over off / no slots): the continuation pass has nothing to do
   }
-  a.skip_ok = o.skip_ok ? 1 : 0;
+  a.skip_ok = o.skip_ok;
   a.sweep_k = o.sweep_k > 0 ? o.sweep_k : 1, a.sweep_phase = o.sweep_phase, a.sweep_m = h->d_sweep_m;
   a.inv_mass = 1.0f / h->params.mass;  // (binary32 division, correctly rounded: the value the reference's 1.f / 9.f folds to for the default)
   a.Ib[0] = h->params.inertia[0], a.Ib[1] = h->params.inertia[1], a.Ib[2] = h->params.inertia[2];
@@ -433,11 +434,21 @@ static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
     c.continuation = true, c.resume = true;
     rc = launch(h, stream, c);
     if (rc != HMPC_OK) return rc;
-    s.skip_ok = true;
+    s.skip_ok = 1;
     static const bool cont_only = getenv("HMPC_DEBUG_CONT_ONLY") && getenv("HMPC_DEBUG_CONT_ONLY")[0] == '1';  // developer switch: what the continuation pass alone leaves
     if (cont_only) return HMPC_OK;
   }
-  if (h->device_repair == 2) return HMPC_OK;  // continuation only: the cold safe pass is left to hmpc_resolve_failed / hmpc_download
+  if (h->device_repair == 2) return HMPC_OK;  // continuation only: the safe pass is left to hmpc_resolve_failed / hmpc_download
+  // The safe pass over what is still flagged: cold, with every bound moved outward by SAFE_PASS_RELAX (1 + frac(0.618 row)) from the start.
+  // What reaches it are the instances that cycle at degenerate vertices (the continuation's budget, a KKT check): perturbed, they
+  // take ~150 iterations instead of up to 480, and the kernel's epilogue re-solves on the final working set with the EXACT bounds and
+  // repeats the exact KKT check -- measured at 6x the input ranges: 8.8 -> 6.9 ms for the whole chain AND 3 -> 0 of 8 192 left flagged
+  // (10x: 19.5 -> 14.6 ms, 10 -> 1); every one of them HMPC_S_OK, exact (profiles/r06/range_scale.txt).
+  s.relax = SAFE_PASS_RELAX, s.warm = 0;
+  {
+    static const char *dbg_relax = getenv("HMPC_DEBUG_SAFE_RELAX");  // developer A/B: another perturbation (0 = the exact, warm pass of before)
+    if (dbg_relax && *dbg_relax) s.relax = atof(dbg_relax), s.warm = (s.relax == 0.0) ? 1 : 0;
+  }
   return launch_safe(h, stream, s);
 }
 
@@ -883,10 +894,16 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
     c.continuation = true, c.resume = true;
     rc = launch(h, h->last_stream, c);
     if (rc != HMPC_OK) return rc;
-    so.skip_ok = true;
+    so.skip_ok = 1;
   }
+  // (the same launch as the device-side chain's: cold, bounds perturbed by SAFE_PASS_RELAX, exact re-solve at its end -- see enqueue_solve)
+  so.relax = SAFE_PASS_RELAX, so.warm = 0;
   rc = launch_safe(h, h->last_stream, so);
-  so.skip_ok = false;
+  if (rc != HMPC_OK) return rc;
+  // ... then, for what is still flagged, the exact pass with the block start (the first safe pass of rounds 4-6a)
+  so.relax = 0.0, so.warm = 1, so.skip_ok = 2;  // (an answer that is only ok-relaxed gets the exact attempt as well)
+  rc = launch_safe(h, h->last_stream, so);
+  so.skip_ok = 0;
   if (rc != HMPC_OK) return rc;
   HIP_TRY(hipStreamSynchronize(h->last_stream));
   if (n_resolved) *n_resolved = (int)idx.size();

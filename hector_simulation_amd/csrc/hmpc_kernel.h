@@ -1791,7 +1791,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
   if constexpr (!ASM_ONLY && (SM::EGLOBAL || (QCAP >= NMAX && NMAX >= 120))) {  // (the safe-pass variants)
     if (args.skip_ok) {  // second pass over a list of flagged instances: what the pass before it solved is left alone
       const uint32_t c0 = args.status[inst] & 0xffu;
-      if (c0 == (uint32_t)S_OK || c0 == (uint32_t)S_OK_RELAXED) return;
+      if (c0 == (uint32_t)S_OK || (args.skip_ok == 1 && c0 == (uint32_t)S_OK_RELAXED)) return;  // (2: a relaxed answer gets this pass as well)
     }
   }
 

@@ -88,7 +88,7 @@ struct KernelArgs {
   int sweep_k, sweep_phase;
   double *sweep_m;
   int resume;       // continuation launch: 1 = instances with a valid slot resume from it, the others start cold; 2 = ... the others are left alone
-  int skip_ok;      // list launch: instances whose status word says ok (an earlier pass over the same list solved them) are left alone
+  int skip_ok;      // list launch: instances whose status word says ok (an earlier pass over the same list solved them) are left alone; 1: ok and ok-relaxed, 2: ok only
 };
 constexpr int NPROF = 32;
 enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A, P_A0, P_A1, P_A2, P_G };
