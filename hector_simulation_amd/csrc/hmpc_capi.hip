@@ -136,6 +136,7 @@ struct hmpc_handle {
   int handover;  // hmpc_set_handover (default on)
   hmpc_params params;  // robot / contact constants (hmpc_set_params; defaults = the reference's literals)
   const float *d_mu_inst;  // hmpc_set_instance_mu: per-instance friction parameter in HBM (caller-owned), nullptr = params.mu for all
+  double *d_reg_rho;  // regularisation steps of hmpc_resolve_failed: rho per instance (allocated with the first instance that needs them)
   double *d_sweep_m;  // command sweeps: every group's M = H^-1, [groups][36][threads per workgroup] doubles (grown on demand)
   size_t sweep_m_bytes;
 };
@@ -218,6 +219,7 @@ struct LaunchOpt {
   bool continuation = false;  // list launch of the CONTINUATION variant (V2_CONT): only instances with a hand-over slot, everything else on the list is left alone
   int skip_ok = 0;         // list launch: instances an earlier pass over the same list solved are left alone (1: ok / ok-relaxed, 2: ok only)
   int sweep_k = 0, sweep_phase = 0;  // command sweep: group size; phase 0 = one workgroup per group forms M, 1 = one per instance solves with it (variant = a MODE 1 entry)
+  int reg_step = 0;        // safe pass over an index list: regularisation step 1 / 2 for instances whose Hessian is not positive definite (KernelArgs::reg_step)
 };
 
 static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
@@ -320,6 +322,7 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
     return HMPC_OK;  // nothing was handed over (hand-over off / no slots): the continuation pass has nothing to do
   }
   a.skip_ok = o.skip_ok;
+  a.reg_step = o.reg_step, a.reg_rho = h->d_reg_rho;
   a.sweep_k = o.sweep_k > 0 ? o.sweep_k : 1, a.sweep_phase = o.sweep_phase, a.sweep_m = h->d_sweep_m;
   a.inv_mass = 1.0f / h->params.mass;  // (binary32 division, correctly rounded: the value the reference's 1.f / 9.f folds to for the default)
   a.Ib[0] = h->params.inertia[0], a.Ib[1] = h->params.inertia[1], a.Ib[2] = h->params.inertia[2];
@@ -588,6 +591,7 @@ int hmpc_destroy(hmpc_handle *h) {
   if (h->d_order) hipFree(h->d_order);
   if (h->d_escratch) hipFree(h->d_escratch);
   if (h->d_sweep_m) hipFree(h->d_sweep_m);
+  if (h->d_reg_rho) hipFree(h->d_reg_rho);
   if (h->d_spill) hipFree(h->d_spill);
   if (h->d_spill_slot) hipFree(h->d_spill_slot);
   delete h;
@@ -872,7 +876,8 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
     // (a solve that ran into the caller's own iteration cap, hmpc_set_max_iterations, is the caller's answer: not re-solved --
     //  the kernel's rule: the cap counts only when it is below the variant's own bound, i.e. when the iteration count of the
     //  status word reached it; a solve that hit the VARIANT's bound under a generous cap is re-solved like any other)
-    if (c == HMPC_S_WORKSET || (c == HMPC_S_MAXITER && !capped_by_caller(h, st[i])) || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT)
+    if (c == HMPC_S_WORKSET || (c == HMPC_S_MAXITER && !capped_by_caller(h, st[i])) || c == HMPC_S_INFEASIBLE || c == HMPC_S_KKT ||
+        c == HMPC_S_INDEFINITE)
       idx.push_back(i);
   }
   if (idx.empty()) return HMPC_OK;
@@ -907,6 +912,28 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
   if (rc != HMPC_OK) return rc;
   HIP_TRY(hipStreamSynchronize(h->last_stream));
   if (n_resolved) *n_resolved = (int)idx.size();
+  {
+    // A Hessian that is not positive definite (found by the safe variants' sweeps: HMPC_S_INDEFINITE; the fast variants diverge on it
+    // and flag it through their KKT check): the reference's qpOASES run regularises -- H + rho I, then one more QP with the gradient
+    // g - rho x_1 (QProblem.cpp:1753-1860, QProblemB.cpp:1999-2031; KernelArgs::reg_step) -- and so do two more launches here
+    std::vector<int> indef;
+    HIP_TRY(hipMemcpy(st.data(), h->d_status, (size_t)h->batch * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int i : idx)
+      if (HMPC_STATUS_CODE(st[i]) == HMPC_S_INDEFINITE) indef.push_back(i);
+    if (!indef.empty()) {
+      if (!h->d_reg_rho) HIP_TRY(hipMalloc(&h->d_reg_rho, (size_t)h->max_batch * sizeof(double)));
+      HIP_TRY(hipMemcpy(d_idx, indef.data(), indef.size() * sizeof(int), hipMemcpyHostToDevice));
+      LaunchOpt ro = so;
+      ro.n_list = (int)indef.size(), ro.relax = 0.0, ro.warm = 1, ro.skip_ok = 0;
+      for (int step = 1; step <= 2; ++step) {
+        ro.reg_step = step;
+        rc = launch_safe(h, h->last_stream, ro);
+        if (rc != HMPC_OK) return rc;
+      }
+      HIP_TRY(hipStreamSynchronize(h->last_stream));
+      HIP_TRY(hipMemcpy(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));  // (the passes below index into the full list again)
+    }
+  }
   // last resort for instances that cycle at a degenerate vertex even with the full-size working set: bounds moved outward
   // by 1e-7, then 1e-6 (a different amount per row), reported as HMPC_S_OK_RELAXED
   if (h->nc == 3) {

@@ -1788,8 +1788,14 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     if (args.resume) resumed = ub(args.spill_slot[inst] == inst && inst < args.spill_cap && (args.status[inst] & 0xffu) == (uint32_t)S_WORKSET);
     if (args.resume == 2 && !resumed) return;  // a continuation-only launch: everything else on the list is the safe variant's
   }
-  if constexpr (!ASM_ONLY && (SM::EGLOBAL || (QCAP >= NMAX && NMAX >= 120))) {  // (the safe-pass variants)
-    if (args.skip_ok) {  // second pass over a list of flagged instances: what the pass before it solved is left alone
+  // the safe-pass variants (working set = variable count, scalar sweeps): they also answer a Hessian that is not positive definite
+  // the way the reference's qpOASES run does (KernelArgs::reg_step)
+  constexpr bool REGULARISES = !ASM_ONLY && (SM::EGLOBAL || (QCAP >= NMAX && NMAX >= 120));
+  if constexpr (REGULARISES) {
+    if (args.reg_step) {  // a regularisation step: only the instances the step before it left for this one
+      const uint32_t c0 = args.status[inst] & 0xffu;
+      if (c0 != (uint32_t)(args.reg_step == 1 ? S_INDEFINITE : S_REG_STEP)) return;
+    } else if (args.skip_ok) {  // second pass over a list of flagged instances: what the pass before it solved is left alone
       const uint32_t c0 = args.status[inst] & 0xffu;
       if (c0 == (uint32_t)S_OK || (args.skip_ok == 1 && c0 == (uint32_t)S_OK_RELAXED)) return;  // (2: a relaxed answer gets this pass as well)
     }
@@ -2021,7 +2027,62 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     pk_fence();
   } else {
   __syncthreads();  // every block is loaded before the solver state (which aliases the staging area) is written
+  if constexpr (REGULARISES) {
+    if (args.reg_step != 0) {  // uniform
+      // H += rho I as qpOASES does after a failed Cholesky factorisation (KernelArgs::reg_step; QProblemB.cpp:1418-1431, 1999-2031):
+      // |H|_F over the reduced matrix -- this thread's blocks, an off-diagonal block standing for its mirror image too --,
+      // summed in a fixed order (lane partials in LDS, one wave adds them up)
+      double ss = 0.0;
+#pragma unroll
+      for (int s = 0; s < BPT; ++s) {
+        double b = 0.0;
+#pragma unroll
+        for (int ii = 0; ii < GS; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < GS; ++jj) b = dfma(a[s][ii][jj], a[s][ii][jj], b);
+        ss += !OWN(s) ? 0.0 : (DIAG(s) ? b : 2.0 * b);
+      }
+      double *red = &Q.ST[0][0];
+      static_assert(sizeof(Q.ST) >= NT * sizeof(double), "one partial per thread");
+      red[tid] = ss;
+      __syncthreads();
+      if (tid < 64) {
+        double t = 0.0;
+        for (int k = tid; k < NT; k += 64) t += red[k];
+        t += dpp_move<0xB1>(t), t += dpp_move<0x4E>(t), t += dpp_move<0x141>(t), t += dpp_move<0x140>(t);
+        t = (readlane_d(t, 0) + readlane_d(t, 16)) + (readlane_d(t, 32) + readlane_d(t, 48));
+        if (tid == 0) {
+          double rho;
+          if (args.reg_step == 1) {
+            constexpr double EPS_REG = 1.0e3 * 2.221e-16, SQRT_EPS_REG = 4.7127486671792716e-07;  // Options.cpp:144 (epsRegularisation), Constants.hpp:50
+            const double piv = (double)args.forces[(size_t)inst * U * h];  // the pivot that was not positive (reg_step 0 left it here)
+            const double er = (piv < 0.0) ? ((-piv + EPS_REG < SQRT_EPS_REG) ? -piv + EPS_REG : SQRT_EPS_REG) : EPS_REG;
+            rho = __builtin_sqrt(t) * er;
+            args.reg_rho[inst] = rho;
+          } else {
+            rho = args.reg_rho[inst];
+          }
+          Q.redv[0] = rho;
+        }
+      }
+      __syncthreads();
+      const double rho = uni_d(Q.redv[0]);
+#pragma unroll
+      for (int s = 0; s < BPT; ++s)
+        if (OWN(s) && DIAG(s) && E0(s) < ng) {
+#pragma unroll
+          for (int ii = 0; ii < GS; ++ii) a[s][ii][ii] += rho;
+        }
+      if (args.reg_step == 2 && tid < n) {  // the second QP's gradient: g - rho x_1 (QProblem.cpp:1811-1812), x_1 as the force buffer holds it
+        const int o = S.s2o[tid];
+        S.g[tid] -= rho * (double)args.forces[(size_t)inst * U * h + U * S.vstep[o] + S.vcomp[o]];
+      }
+    }
+  }
   if (tid < NMAX) Q.piv[0][tid] = 0.0, Q.piv[1][tid] = 0.0;
+  if constexpr (REGULARISES) {
+    if (tid == 0) Q.gamma = 1.0;  // the first sweep pivot that is not positive (free until the solver starts)
+  }
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < BPT; ++s)
@@ -2052,6 +2113,9 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       const double *pv = Q.piv[k & 1];
       double *pn = Q.piv[(k + 1) & 1];
       const double d = Q.pd[k & 1];
+      if constexpr (REGULARISES) {
+        if (!(d > 0.0) && tid == 0 && Q.gamma > 0.0) Q.gamma = d;  // H is not positive definite (rare branch; thread 0 alone reads and writes the slot)
+      }
       // v_rcp_f64 is good to 2^-24 (scripts/micro/rcp64_accuracy.hip); one Newton step brings 2e-15, a second one would
       // bring the last bit -- not worth two more fp64 instructions per pivot here: the sweeps' own round-off (cond(H) eps
       // ~ 3e-10) is five orders above it and the substituted multipliers stay consistent with whatever invd is used
@@ -2120,6 +2184,24 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     }
   }
   pk_fence();
+  if constexpr (REGULARISES) {
+    const double negp = uni_d(Q.gamma);  // (the last sweep ended with a barrier)
+    if (!(negp > 0.0)) {
+      // Not positive definite: nothing a dual active-set method can start from -- x_u = -H^-1 g is not a minimiser; the fast variants
+      // (whose matrix-core sweeps do not look at their pivots: a test there costs the headline 0.7-2 %, profiles/r06/NOTES.md) diverge
+      // on such an instance and hand it over through their KKT check.  The reference's qpOASES run regularises such a QP
+      // (KernelArgs::reg_step has the story); here the instance ends as S_INDEFINITE, its forces zeroed, the offending pivot in
+      // forces[0] for regularisation step 1, and counts as flagged, so that hmpc_download's repair pass picks it up.
+      for (int t = tid; t < U * h; t += NT) args.forces[(size_t)inst * U * h + t] = (t == 0) ? (float)negp : 0.0f;
+      if (args.wset)
+        for (int t = tid; t < C8 * h; t += NT) args.wset[(size_t)inst * C8 * h + t] = 0;
+      if (tid == 0) {
+        args.status[inst] = (uint32_t)S_INDEFINITE;
+        if (args.flagged) atomicAdd(args.flagged, 1u);
+      }
+      return;
+    }
+  }
   // M = -a.  Diagonal blocks keep the full symmetric 6x6 (their lower triangle is overwritten with the mirror of the upper
   // one, so both halves are bit-identical); off-diagonal blocks hold M(e0,e1) and stand for M(e1,e0) transposed.
 #pragma unroll
@@ -3381,6 +3463,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
     // (an instance that ran into the CALLER'S iteration cap is the caller's answer: it is neither counted nor listed for the
     //  safe pass -- the device-side repair would otherwise re-solve it cold and overwrite its last iterate)
     const bool capped = (code == S_MAXITER) && (args.iter_cap > 0 && args.iter_cap < itmax_v);
+    if constexpr (REGULARISES) code = (args.reg_step == 1 && code == S_OK) ? (int)S_REG_STEP : code;  // x_1 of the regularised QP: one more step to go
     stage_output<NMAX, HMAX, NT, QCAP, NC, BPT>(S, args, inst, h, n, q, iters, code, capped, RESUMABLE && resumed);
 #ifdef HMPC_DEBUG_STATS
     if (tid == 0 && args.obj64) args.obj64[inst] = (dbg_viol > 0.0) ? -dbg_viol : (double)(dbg_bad + 10 * dbg_rounds + 1000 * dbg_norounds_cap + 10000 * dbg_norounds_few + 100000 * dbg_dep);

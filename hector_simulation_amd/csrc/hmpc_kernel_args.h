@@ -89,6 +89,18 @@ struct KernelArgs {
   double *sweep_m;
   int resume;       // continuation launch: 1 = instances with a valid slot resume from it, the others start cold; 2 = ... the others are left alone
   int skip_ok;      // list launch: instances whose status word says ok (an earlier pass over the same list solved them) are left alone; 1: ok and ok-relaxed, 2: ok only
+  // A reduced Hessian that is NOT positive definite (the binary32 assembly of the contract rounds H = 2 (B'SB + alpha) at ~6e-8 |H|;
+  // with a 20-step horizon at 10x the nominal input ranges that exceeds its smallest eigenvalue ~2 alpha in 2 % of the instances).
+  // The reference's qpOASES run answers a failed Cholesky factorisation of H (QProblem.cpp:2107-2121, QProblemB.cpp:1418-1431) by
+  // regularising -- H += rho I, rho = |H|_F min(-pivot + eps, sqrt(eps)), eps = 1e3 * 2.221e-16 (QProblemB.cpp:1999-2031; Options
+  // setToMPC: enableRegularisation, numRegularisationSteps = 1) --, solving that QP, and solving it once more with the gradient
+  // g - rho x_1 (QProblem.cpp:1753-1860).  The safe variants do the same in three launches over the flagged instances:
+  //   reg_step 0 (every safe launch): a sweep pivot <= 0 ends the instance as S_INDEFINITE, the pivot in forces[0];
+  //   reg_step 1: instances whose status is S_INDEFINITE: rho from |H|_F and the pivot, left in reg_rho[inst]; H + rho I; solved:
+  //               x_1 in the force buffer, status S_REG_STEP;
+  //   reg_step 2: instances whose status is S_REG_STEP: H + rho I, g - rho x_1; the answer, status S_OK.
+  int reg_step;
+  double *reg_rho;  // [batch]
 };
 constexpr int NPROF = 32;
 enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A, P_A0, P_A1, P_A2, P_G };
@@ -100,6 +112,6 @@ struct DbgLayout {
                        X0 = UB + 8 * NC * 20, ACD = X0 + 16, BCD = ACD + 176, TOTAL = BCD + 80 * NC;
 };
 
-enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT = 4, S_WORKSET = 5, S_OK_RELAXED = 6, S_SWEEP_MISMATCH = 7 };
+enum : int { S_OK = 0, S_MAXITER = 1, S_INFEASIBLE = 2, S_TOO_LARGE = 3, S_KKT = 4, S_WORKSET = 5, S_OK_RELAXED = 6, S_SWEEP_MISMATCH = 7, S_INDEFINITE = 8, S_REG_STEP = 9 };
 
 }  // namespace hmpc

@@ -18,7 +18,7 @@ TICK_DTYPE = np.dtype([("position", "f8", 3), ("vWorld", "f8", 3), ("omegaWorld"
                        ("world_position_desired", "f8", 2), ("gait_offsets", "i4", 2), ("gait_durations", "i4", 2),
                        ("gait_iteration", "i4"), ("flags", "i4")], align=True)
 
-STATUS_NAMES = {0: "ok", 1: "max_iter", 2: "infeasible", 3: "too_large", 4: "kkt", 5: "working_set_full", 6: "ok_relaxed", 7: "sweep_mismatch"}
+STATUS_NAMES = {0: "ok", 1: "max_iter", 2: "infeasible", 3: "too_large", 4: "kkt", 5: "working_set_full", 6: "ok_relaxed", 7: "sweep_mismatch", 8: "hessian_not_positive_definite", 9: "regularisation_step"}
 
 
 class HmpcError(RuntimeError):

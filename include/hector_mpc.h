@@ -105,6 +105,12 @@ enum hmpc_status_code {
                              with three contacts, 152 in the wide variant).  The safe pass holds as many rows as there are
                              variables -- in LDS for 120 variables, in global memory for 180 / 240 -- and cannot overflow */
   HMPC_S_SWEEP_MISMATCH = 7, /* hmpc_solve_command_sweep: the record differs from its chunk's first record outside the trajectory; not solved */
+  HMPC_S_INDEFINITE = 8,  /* the reduced Hessian, assembled in binary32 as the reference assembles it (SolverMPC.cpp:560-570), is NOT
+                             positive definite: a sweep pivot of the safe pass came out <= 0 (seen with 20-step horizons at 10x the
+                             nominal input ranges: rounding at 6e-8 |H| against a smallest eigenvalue of ~2 alpha).  Left by the
+                             device-side safe pass; hmpc_resolve_failed / hmpc_download answer it the way the reference's qpOASES run
+                             does (H + rho I, then one step with g - rho x_1: QProblem.cpp:1753-1860) and report HMPC_S_OK */
+  HMPC_S_REG_STEP = 9,    /* (internal to hmpc_resolve_failed: between the two regularised QPs of an HMPC_S_INDEFINITE instance) */
   HMPC_S_OK_RELAXED = 6   /* solved only after every bound was moved outward by <= 2e-5 (relative for the Fz cap) AND the exact
                              re-solve on the working set so found did not pass the exact KKT check: the last-resort pass of
                              hmpc_resolve_failed for instances cycling at a degenerate vertex.  (When the exact re-solve passes --
@@ -208,14 +214,20 @@ int hmpc_set_warm_start(hmpc_handle *h, int on);
 int hmpc_set_tick_warm_start(hmpc_handle *h, int on, int horizon_shift);
 int hmpc_reset_tick_warm_start(hmpc_handle *h);
 /* Safe pass: waits for the last solve, then re-solves every instance whose status is working-set-full / max-iter /
- * infeasible / KKT with the large-working-set kernel variant (capacity = number of variables: cannot overflow; cold
- * start; the Schur inverse is rebuilt from scratch every 48 working-set changes, so that hundreds of them do not add up
- * round-off) and overwrites its forces and status in place.  Instances still flagged after that get up to three
- * last-resort passes with every bound moved outward by 1e-7, 1e-6, 1e-5 (a different amount per row: separates
- * coinciding vertices), each ending with an exact re-solve on the working set it found -- HMPC_S_OK when that passes the
- * exact KKT check, HMPC_S_OK_RELAXED otherwise.  Measured at 1x .. 10x the nominal input ranges (scripts/stress.py,
- * profiles/r04/stress.txt): every instance qpOASES solves ends HMPC_S_OK.  *n_resolved (may be NULL) = how many were
- * re-solved.  hmpc_download does this automatically unless hmpc_set_auto_resolve(h, 0). */
+ * infeasible / KKT and overwrites its forces and status in place.  The passes, each over what the one before left flagged
+ * (round 6): (1) instances that handed their state over (hmpc_set_handover) are CONTINUED on the 96-row variant; (2) the
+ * large-working-set variant (capacity = number of variables: cannot overflow; the Schur inverse is rebuilt from scratch every
+ * 48 working-set changes, so that hundreds of them do not add up round-off), cold, with every bound moved outward by a relative
+ * 1e-6 (a different amount per row: separates the coinciding vertices at which the exact problem makes Goldfarb-Idnani cycle --
+ * the instances that reach this pass are the degenerate ones), ending with an exact re-solve on the working set it found:
+ * HMPC_S_OK when that passes the exact KKT check -- every one of the 8 192 at 6x the nominal input ranges --, HMPC_S_OK_RELAXED
+ * otherwise; (3) the same variant on the EXACT bounds from the working set (2) left, for relaxed and flagged instances alike;
+ * (4) instances whose reduced Hessian is not positive definite (HMPC_S_INDEFINITE, found by the sweeps of (2)): the reference's
+ * regularisation, two more launches -- H + rho I with rho = |H|_F sqrt(1e3 * 2.221e-16), then the same QP with the gradient
+ * g - rho x_1 (qpOASES QProblem.cpp:1753-1860, QProblemB.cpp:1418-1431, 1999-2031 under Options::setToMPC) -- within 6e-8 of what
+ * the reference returns for them; (5) up to three last-resort passes with the bounds moved by 1e-7, 1e-6, 1e-5, cold.  Measured at 1x .. 10x the nominal input
+ * ranges (scripts/stress.py, profiles/r06/stress.txt): every instance qpOASES solves ends HMPC_S_OK.  *n_resolved (may be NULL) =
+ * how many were re-solved.  hmpc_download does this automatically unless hmpc_set_auto_resolve(h, 0). */
 int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved);
 /* Dispatch order of the workgroups of a solve.  mode 1 (default), longest first: the instances are started in the order of
  * the active-set iterations their PREVIOUS solve took (most first; read on the device from the status words the previous
@@ -267,7 +279,9 @@ int hmpc_set_handover(hmpc_handle *h, int on);
  * <= 120-variable instances of an unsized h > 10 batch, so fewer than 256 wide ones may be reached), the rest stay flagged for
  * hmpc_resolve_failed / hmpc_download.  Instances whose working set merely outgrew the fast variant are CONTINUED, not
  * re-solved (hmpc_set_handover): first the continuation variant over the flagged list (96-row working set, two workgroups per
- * CU), then the safe variant, cold, over what is still flagged.  on = 2: the continuation pass only -- what it does not finish
+ * CU), then the safe variant over what is still flagged: cold, bounds moved outward by a relative 1e-6 and an exact re-solve
+ * on the working set found (pass (2) of hmpc_resolve_failed: HMPC_S_OK, or HMPC_S_OK_RELAXED when the exact KKT check fails
+ * on that set: a solved instance whose bounds were off by <= 2e-6 relative; not seen on any measured set).  on = 2: the continuation pass only -- what it does not finish
  * (~0.5 % of the instances at 6x the nominal input ranges: degenerate vertices, working sets beyond 96 rows) stays FLAGGED in
  * the status word for hmpc_resolve_failed / hmpc_download; a cold re-solve of such an instance takes hundreds of iterations on a
  * single workgroup, milliseconds at the tail of the stream, which a device-resident pipeline may prefer not to wait for. */

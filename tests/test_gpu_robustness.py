@@ -53,8 +53,7 @@ def test_hard_inputs(oracle, gait, h, scale, min_ok):
 def test_ok_iff_qpoases_ok_on_the_stress_rows(gait, h, nc, scale):
     """The 10x rows of scripts/stress.py (profiles/r05/stress.txt) as assertions, 256 instances per shape against the qpOASES
     pool: on the set where the reference has an answer at all (its failures masked out and counted separately, VERDICT round 4
-    item 7) every instance the kernel reports solved agrees with it, and "ok <=> qpOASES ok" holds -- with the one documented
-    exception, double support over h = 20 at 10x, where up to 3 % end flagged HMPC_S_KKT (never silently wrong)."""
+    item 7) every instance the kernel reports solved agrees with it, and "ok <=> qpOASES ok" holds."""
     from oracle import pool
 
     nb = 256
@@ -79,12 +78,11 @@ def test_ok_iff_qpoases_ok_on_the_stress_rows(gait, h, nc, scale):
     err = np.abs(forces - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
     both = ok & ~rbad
     assert both.any() and err[both].max() < 1e-4, (err[both].max(), int(np.argmax(np.where(both, err, 0))))
-    assert np.isin(code[~ok], (1, 4, 5)).all()  # whatever is not solved is FLAGGED
+    assert np.isin(code[~ok], (1, 4, 5, 8)).all()  # whatever is not solved is FLAGGED
     n_gpu_only_fails = int((~ok & ~rbad).sum())
-    if gait == "standing" and h == 20 and scale == 10:
-        assert n_gpu_only_fails <= 0.03 * nb, n_gpu_only_fails  # (24 of 1 024 in profiles/r04/stress.txt)
-    else:
-        assert n_gpu_only_fails == 0, (n_gpu_only_fails, np.unique(code, return_counts=True))
+    # (round 6: no exception left -- double support over h = 20 at 10x used to end 2-3 % flagged HMPC_S_KKT: instances whose
+    #  binary32 Hessian is not positive definite, which qpOASES regularises; see test_indefinite_hessian_is_regularised_like_qpoases)
+    assert n_gpu_only_fails == 0, (n_gpu_only_fails, np.unique(code, return_counts=True))
 
 
 @pytest.mark.parametrize("gait,h,nb", [("standing", 10, 4096), ("mixed", 10, 2048), ("single", 20, 1024)])
@@ -358,3 +356,45 @@ def test_a_stale_handover_slot_is_never_resumed(oracle):
         assert (interface.status_code(st) == 0).all()
         err = np.abs(f - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
         assert err.max() < 2e-6, (second_mode, err.max())
+
+
+def test_indefinite_hessian_is_regularised_like_qpoases():
+    """Double support over h = 20 at 10x the nominal input ranges: in ~2 % of the instances the reduced Hessian, assembled in binary32
+    as the contract demands (SolverMPC.cpp:560-570), is NOT positive definite (smallest eigenvalue ~ -5e-5 against entries of 1e3).
+    qpOASES answers the failed Cholesky factorisation by regularising -- H + rho I, rho = |H|_F sqrt(1e3 eps), then one more QP with
+    the gradient g - rho x_1 (QProblem.cpp:1753-1860, QProblemB.cpp:1418-1431, 1999-2031; Options::setToMPC) -- and reports success;
+    the fast variants diverge on such an instance and flag it (KKT), the safe variants find the non-positive sweep pivot
+    (HMPC_S_INDEFINITE) and hmpc_resolve_failed runs the same two regularised QPs: every instance ends HMPC_S_OK within 1e-6 of qpOASES
+    (until round 6: 24 of 1 024 ended flagged).  The device-side chain leaves them flagged as HMPC_S_INDEFINITE for the host."""
+    from oracle import oracle_py, pool
+
+    nb, h = 96, 20
+    rec = records.pack_records(hard_batch(nb, h, "standing", 17, 10), h)
+    # which instances are indefinite: eigenvalues of the oracle's reduced Hessian (binary32 assembly, widened)
+    indef = np.zeros(nb, dtype=bool)
+    for i in range(nb):
+        a = oracle_py.assemble_record(rec[i], h, synthetic.DT_MPC, synthetic.F_MAX)
+        indef[i] = np.linalg.eigvalsh(a["H_red"])[0] < -1e-7
+    assert 2 <= indef.sum() <= 12, int(indef.sum())
+    ref = pool.solve_records_parallel(rec, h, synthetic.DT_MPC, synthetic.F_MAX)
+    rbad = np.asarray(ref["bad"], dtype=bool)
+    q = ref["q_soln"]
+    # device-side chain: found, reported, not solved
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, nb)
+    mpc.set_auto_resolve(False)
+    mpc.set_device_repair(True)
+    mpc.upload(rec)
+    mpc.solve()
+    _, st_dev = mpc.download()
+    c_dev = interface.status_code(st_dev)
+    assert (c_dev[indef] == 8).all() and (c_dev[~indef] != 8).all(), (c_dev[indef], np.unique(c_dev, return_counts=True))
+    # host-driven repair: the reference's regularisation steps
+    assert mpc.resolve_failed() >= int(indef.sum())
+    forces, status = mpc.download()
+    mpc.close()
+    code = interface.status_code(status)
+    assert (code == 0).all(), np.unique(code, return_counts=True)
+    err = np.abs(forces - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+    both = indef & ~rbad
+    assert both.sum() >= 2 and err[both].max() < 1e-6, err[indef]
+    assert err[~rbad].max() < 1e-4
