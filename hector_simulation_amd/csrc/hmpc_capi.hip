@@ -147,7 +147,7 @@ constexpr int REPAIR_GRID_CAP = 65536;  // workgroups of the device-side safe la
 constexpr double SAFE_PASS_RELAX = 1e-6;  // first safe pass (device- and host-driven): bounds moved outward by this, exact re-solve + exact KKT check at its end
 constexpr int SPILL_SLOT_CAP = 32768;   // hand-over slots per handle at most (101 KB each for 120 variables: 3.3 GB of the 288 GB); instances beyond it are re-solved cold
 constexpr int EGLOBAL_CHUNK = 512;         // host-driven safe pass of the global-E variants: instances per launch (118 MB of scratch at 240 variables)
-constexpr int REPAIR_GRID_CAP_WIDE = 256;  // ... of the wide variant's, whose safe pass keeps 231 KB per workgroup in global memory
+constexpr int REPAIR_GRID_CAP_WIDE = 4096;  // ... of the wide variant's, whose safe pass keeps 231 KB per workgroup in global memory (0.95 GB of 288: the list mixes size classes, so a small cap could leave a wide instance behind 256 others unrepaired -- ADVICE round 5)
 
 // returns a device buffer of at least `bytes` owned by the handle (contents undefined)
 static int scratch(hmpc_handle *h, size_t bytes, void **out) {

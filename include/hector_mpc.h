@@ -275,8 +275,8 @@ int hmpc_set_handover(hmpc_handle *h, int on);
  * device; workgroups beyond the length leave at once) -- device-resident outputs, hmpc_download_async and the group
  * exchange then see repaired forces/status without any host involvement.  Costs one 4-byte memset and one (normally
  * empty) extra launch per solve; repairs every flagged instance of batches up to 65 536 (the wide variant's instances, whose safe
- * pass keeps 231 KB of global scratch per workgroup: the first 256 positions of the flagged list -- which it shares with the
- * <= 120-variable instances of an unsized h > 10 batch, so fewer than 256 wide ones may be reached), the rest stay flagged for
+ * pass keeps 231 KB of global scratch per workgroup: the first 4 096 positions of the flagged list, 0.95 GB of scratch allocated with
+ * the first such solve), the rest stay flagged for
  * hmpc_resolve_failed / hmpc_download.  Instances whose working set merely outgrew the fast variant are CONTINUED, not
  * re-solved (hmpc_set_handover): first the continuation variant over the flagged list (96-row working set, two workgroups per
  * CU), then the safe variant over what is still flagged: cold, bounds moved outward by a relative 1e-6 and an exact re-solve
