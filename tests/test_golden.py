@@ -138,3 +138,38 @@ def test_hip_matches_tick_golden(name):
     np.testing.assert_allclose(f_ff, g[f"{name}/f_ff"], rtol=0, atol=2e-4 * max(1.0, np.abs(q).max()))
     np.testing.assert_allclose(tau, g[f"{name}/tau"], rtol=0, atol=2e-4 * max(1.0, np.abs(q).max()))
     mpc.close()
+
+
+# ---- Hessians that are not positive definite (tests/golden/make_indefinite_golden.py): what the reference's qpOASES returns for them
+GOLDI = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "indefinite_golden.npz")
+
+
+def test_oracle_reproduces_indefinite_golden(oracle):
+    gi = np.load(GOLDI)
+    rec, h = gi["records"], int(gi["horizon"])
+    sol = oracle.solve_records(rec, h, synthetic.DT_MPC, synthetic.F_MAX)
+    assert sol["n_bad"] == 0
+    np.testing.assert_allclose(sol["q_soln"], gi["q_soln"], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(sol["nwsr"], gi["nwsr"])
+    eig = [np.linalg.eigvalsh(oracle.assemble_record(r, h, synthetic.DT_MPC, synthetic.F_MAX)["H_red"])[0] for r in rec]
+    assert eig[0] > 0 and eig[1] < 0 and eig[2] < 0  # the control instance is positive definite, the other two are not
+
+
+@pytest.mark.gpu
+def test_hip_matches_indefinite_golden():
+    """HMPC_S_INDEFINITE -> the reference's two regularised QPs inside hmpc_download's repair pass: HMPC_S_OK, the
+    reference's forces -- without /root/reference or the oracle on the box."""
+    gi = np.load(GOLDI)
+    rec, h, q = gi["records"], int(gi["horizon"]), gi["q_soln"]
+    mpc = interface.BatchedMPC(synthetic.DT_MPC, h, synthetic.F_MAX, rec.shape[0])
+    mpc.set_auto_resolve(False)
+    mpc.upload(rec)
+    mpc.solve()
+    _, st_fast = mpc.download()
+    assert interface.status_code(st_fast)[0] in (0, 5) and (interface.status_code(st_fast)[1:] != 0).all()  # never silently "ok"
+    mpc.set_auto_resolve(True)
+    forces, status = mpc.download()
+    mpc.close()
+    assert (interface.status_code(status) == 0).all(), interface.status_code(status)
+    err = np.abs(forces - q).max(axis=1) / np.maximum(1.0, np.abs(q).max(axis=1))
+    assert err.max() < 1e-6, err
