@@ -29,6 +29,9 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "indefinite_golden.npz")
     np.savez_compressed(path, records=rec, horizon=np.int32(H), q_soln=sol["q_soln"], nwsr=sol["nwsr"], obj=sol["obj"], min_eig=eig)
     print("wrote", path, os.path.getsize(path), "bytes; min eigenvalues", eig, "nWSR", sol["nwsr"])
+    # the same data as raw arrays for tests/src/host_api_sweep.c (C has no npz reader): records [3][stride] bytes, forces [3][240] doubles
+    rec.tofile(os.path.join(ROOT, "tests", "golden", "indefinite_records.bin"))
+    sol["q_soln"].astype("<f8").tofile(os.path.join(ROOT, "tests", "golden", "indefinite_forces.bin"))
 
 
 if __name__ == "__main__":

@@ -378,6 +378,48 @@ int main(void) {
     CHECK(hmpc_destroy(h6) == HMPC_OK);
   }
 
+  /* round 6: a Hessian that is not positive definite -> HMPC_S_INDEFINITE -> the reference's two regularised QPs inside hmpc_download
+   * (tests/golden/indefinite_*.bin: three h = 20 records, the last two indefinite, and what the reference's qpOASES returns for them;
+   * tests/golden/make_indefinite_golden.py).  Run from the repository root; skipped with a note when the files are not there. */
+  {
+    enum { H20 = 20, NI = 3 };
+    const size_t stride20 = hmpc_record_stride(H20);
+    FILE *fr = fopen("tests/golden/indefinite_records.bin", "rb"), *ff = fopen("tests/golden/indefinite_forces.bin", "rb");
+    if (fr && ff) {
+      unsigned char *r20 = (unsigned char *)malloc(NI * stride20);
+      double *want = (double *)malloc(sizeof(double) * NI * 12 * H20);
+      float *got = (float *)malloc(sizeof(float) * NI * 12 * H20);
+      uint32_t st20[NI];
+      CHECK(fread(r20, stride20, NI, fr) == NI && fread(want, sizeof(double) * 12 * H20, NI, ff) == NI);
+      struct problem_setup s20 = {0.04f, 0.25f, 500.0f, H20};
+      hmpc_handle *h20 = NULL;
+      CHECK(hmpc_create(&h20, &s20, NI, 0) == HMPC_OK);
+      CHECK(hmpc_set_auto_resolve(h20, 0) == HMPC_OK && hmpc_set_device_repair(h20, 1) == HMPC_OK);
+      CHECK(hmpc_upload_records(h20, r20, NI) == HMPC_OK && hmpc_solve(h20, NULL) == HMPC_OK && hmpc_download(h20, got, st20) == HMPC_OK);
+      CHECK(HMPC_STATUS_CODE(st20[1]) == HMPC_S_INDEFINITE && HMPC_STATUS_CODE(st20[2]) == HMPC_S_INDEFINITE); /* the device chain finds them */
+      int nres = -1;
+      CHECK(hmpc_resolve_failed(h20, &nres) == HMPC_OK && nres >= 2 && hmpc_download(h20, got, st20) == HMPC_OK);
+      for (int k = 0; k < NI; ++k) {
+        double fmax = 1.0, err = 0.0;
+        CHECK(HMPC_STATUS_CODE(st20[k]) == HMPC_S_OK);
+        for (int i = 0; i < 12 * H20; ++i) fmax = fmax > fabs(want[k * 12 * H20 + i]) ? fmax : fabs(want[k * 12 * H20 + i]);
+        for (int i = 0; i < 12 * H20; ++i) err = err > fabs((double)got[k * 12 * H20 + i] - want[k * 12 * H20 + i]) ? err : fabs((double)got[k * 12 * H20 + i] - want[k * 12 * H20 + i]);
+        CHECK(err < 1e-6 * fmax);
+      }
+      /* a second batch on the same handle (the rho buffer is reused), then with the repair left to hmpc_download */
+      CHECK(hmpc_set_auto_resolve(h20, 1) == HMPC_OK && hmpc_set_device_repair(h20, 0) == HMPC_OK);
+      CHECK(hmpc_upload_records(h20, r20, NI) == HMPC_OK && hmpc_solve(h20, NULL) == HMPC_OK && hmpc_download(h20, got, st20) == HMPC_OK);
+      for (int k = 0; k < NI; ++k) CHECK(HMPC_STATUS_CODE(st20[k]) == HMPC_S_OK);
+      CHECK(hmpc_destroy(h20) == HMPC_OK);
+      printf("indefinite Hessians: 2 of 3 regularised as the reference does, forces within 1e-6\n");
+      free(r20), free(want), free(got);
+    } else {
+      printf("indefinite Hessians: fixture files not found (run from the repository root) -- skipped\n");
+    }
+    if (fr) fclose(fr);
+    if (ff) fclose(ff);
+  }
+
   free(recs), free(forces), free(forces2), free(st), free(x64), free(obj), free(ticks), free(wpd), free(rb), free(lq), free(fff), free(tau), free(wrench);
   printf("host API sweep ok\n");
   fflush(stdout); /* (so that the line survives a tool that aborts the process during runtime teardown, e.g. a sanitizer) */

@@ -80,6 +80,7 @@ def test_host_api_sweep_on_gpu(tmp_path):
     """tests/src/host_api_sweep.c: every batched entry point from plain C, error paths, scratch reuse, safe pass, f64
     copy-out before/after, tick warm start, device group (also the program scripts/sanitize_host.sh runs under ASan/UBSan)."""
     exe = _compile(tmp_path, "host_api_sweep.c", "gcc", "-std=c11", folder=os.path.join("tests", "src"))
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, cwd=ROOT)  # (reads tests/golden/indefinite_*.bin relative to the root)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "host API sweep ok" in r.stdout
+    assert "indefinite Hessians: 2 of 3 regularised as the reference does" in r.stdout
