@@ -1124,7 +1124,8 @@ int hmpc_debug_phase_cycles(hmpc_handle *h, long long *cycles /*[batch][NPROF = 
   const size_t nb = (size_t)h->max_batch * hmpc::NPROF * sizeof(long long);
   if (!h->d_prof) HIP_TRY(hipMalloc(&h->d_prof, nb));
   HIP_TRY(hipMemset(h->d_prof, 0, nb));
-  int rc = launch(h, h->last_stream, LaunchOpt());
+  // (with the device-side repair on, the whole chain: an instance's slot then holds the numbers of the LAST variant that ran it)
+  int rc = h->device_repair ? enqueue_solve(h, h->last_stream, false) : launch(h, h->last_stream, LaunchOpt());
   if (rc != HMPC_OK) return rc;
   HIP_TRY(hipStreamSynchronize(h->last_stream));
   HIP_TRY(hipMemcpy(cycles, h->d_prof, (size_t)h->batch * hmpc::NPROF * sizeof(long long), hipMemcpyDeviceToHost));
