@@ -50,5 +50,6 @@ ls $O
 # round 6: what an off-nominal batch costs (fast pass, device repair with / without the hand-over), what the continuation pass alone leaves
 python scripts/dev/range_scale.py 2>/dev/null | grep -v amdgpu > $O/range_scale.txt
 python scripts/dev/range_scale.py 4096 single 20 2>/dev/null | grep -v amdgpu >> $O/range_scale.txt
+python scripts/dev/range_scale.py 8192 mixed 10 2>/dev/null | grep -v amdgpu >> $O/range_scale.txt
 ( python scripts/dev/cont_probe.py 3; python scripts/dev/cont_probe.py 6; python scripts/dev/cont_probe.py 10 ) 2>/dev/null | grep -v amdgpu > $O/continuation_pass.txt
 ls $O
