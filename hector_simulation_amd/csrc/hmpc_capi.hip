@@ -136,7 +136,7 @@ struct hmpc_handle {
   int handover;  // hmpc_set_handover (default on)
   hmpc_params params;  // robot / contact constants (hmpc_set_params; defaults = the reference's literals)
   const float *d_mu_inst;  // hmpc_set_instance_mu: per-instance friction parameter in HBM (caller-owned), nullptr = params.mu for all
-  double *d_reg_rho;  // regularisation steps of hmpc_resolve_failed: rho per instance (allocated with the first instance that needs them)
+  double *d_reg_rho;  // Hessians that are not positive definite: the pivot the safe variant found, then rho of hmpc_resolve_failed's regularisation steps, per instance (allocated with the first list launch)
   double *d_sweep_m;  // command sweeps: every group's M = H^-1, [groups][36][threads per workgroup] doubles (grown on demand)
   size_t sweep_m_bytes;
 };
@@ -322,6 +322,7 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
     return HMPC_OK;  // nothing was handed over (hand-over off / no slots): the continuation pass has nothing to do
   }
   a.skip_ok = o.skip_ok;
+  if (o.d_index_list && !h->d_reg_rho) HIP_TRY(hipMalloc(&h->d_reg_rho, (size_t)h->max_batch * sizeof(double)));  // (safe variants: where a pivot that is not positive is left)
   a.reg_step = o.reg_step, a.reg_rho = h->d_reg_rho;
   a.sweep_k = o.sweep_k > 0 ? o.sweep_k : 1, a.sweep_phase = o.sweep_phase, a.sweep_m = h->d_sweep_m;
   a.inv_mass = 1.0f / h->params.mass;  // (binary32 division, correctly rounded: the value the reference's 1.f / 9.f folds to for the default)
@@ -921,7 +922,6 @@ int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved) {
     for (int i : idx)
       if (HMPC_STATUS_CODE(st[i]) == HMPC_S_INDEFINITE) indef.push_back(i);
     if (!indef.empty()) {
-      if (!h->d_reg_rho) HIP_TRY(hipMalloc(&h->d_reg_rho, (size_t)h->max_batch * sizeof(double)));
       HIP_TRY(hipMemcpy(d_idx, indef.data(), indef.size() * sizeof(int), hipMemcpyHostToDevice));
       LaunchOpt ro = so;
       ro.n_list = (int)indef.size(), ro.relax = 0.0, ro.warm = 1, ro.skip_ok = 0;

@@ -2055,7 +2055,7 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
           double rho;
           if (args.reg_step == 1) {
             constexpr double EPS_REG = 1.0e3 * 2.221e-16, SQRT_EPS_REG = 4.7127486671792716e-07;  // Options.cpp:144 (epsRegularisation), Constants.hpp:50
-            const double piv = (double)args.forces[(size_t)inst * U * h];  // the pivot that was not positive (reg_step 0 left it here)
+            const double piv = args.reg_rho[inst];  // the pivot that was not positive (reg_step 0 left it here)
             const double er = (piv < 0.0) ? ((-piv + EPS_REG < SQRT_EPS_REG) ? -piv + EPS_REG : SQRT_EPS_REG) : EPS_REG;
             rho = __builtin_sqrt(t) * er;
             args.reg_rho[inst] = rho;
@@ -2191,11 +2191,12 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
       // (whose matrix-core sweeps do not look at their pivots: a test there costs the headline 0.7-2 %, profiles/r06/NOTES.md) diverge
       // on such an instance and hand it over through their KKT check.  The reference's qpOASES run regularises such a QP
       // (KernelArgs::reg_step has the story); here the instance ends as S_INDEFINITE, its forces zeroed, the offending pivot in
-      // forces[0] for regularisation step 1, and counts as flagged, so that hmpc_download's repair pass picks it up.
-      for (int t = tid; t < U * h; t += NT) args.forces[(size_t)inst * U * h + t] = (t == 0) ? (float)negp : 0.0f;
+      // reg_rho[inst] for regularisation step 1, and counts as flagged, so that hmpc_download's repair pass picks it up.
+      for (int t = tid; t < U * h; t += NT) args.forces[(size_t)inst * U * h + t] = 0.0f;
       if (args.wset)
         for (int t = tid; t < C8 * h; t += NT) args.wset[(size_t)inst * C8 * h + t] = 0;
       if (tid == 0) {
+        if (args.reg_rho) args.reg_rho[inst] = negp;
         args.status[inst] = (uint32_t)S_INDEFINITE;
         if (args.flagged) atomicAdd(args.flagged, 1u);
       }

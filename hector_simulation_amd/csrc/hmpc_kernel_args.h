@@ -95,12 +95,12 @@ struct KernelArgs {
   // regularising -- H += rho I, rho = |H|_F min(-pivot + eps, sqrt(eps)), eps = 1e3 * 2.221e-16 (QProblemB.cpp:1999-2031; Options
   // setToMPC: enableRegularisation, numRegularisationSteps = 1) --, solving that QP, and solving it once more with the gradient
   // g - rho x_1 (QProblem.cpp:1753-1860).  The safe variants do the same in three launches over the flagged instances:
-  //   reg_step 0 (every safe launch): a sweep pivot <= 0 ends the instance as S_INDEFINITE, the pivot in forces[0];
+  //   reg_step 0 (every safe launch): a sweep pivot <= 0 ends the instance as S_INDEFINITE, forces zeroed, the pivot in reg_rho[inst];
   //   reg_step 1: instances whose status is S_INDEFINITE: rho from |H|_F and the pivot, left in reg_rho[inst]; H + rho I; solved:
   //               x_1 in the force buffer, status S_REG_STEP;
   //   reg_step 2: instances whose status is S_REG_STEP: H + rho I, g - rho x_1; the answer, status S_OK.
   int reg_step;
-  double *reg_rho;  // [batch]
+  double *reg_rho;  // [batch]: the pivot (after reg_step 0), then rho; set for every launch over an index list
 };
 constexpr int NPROF = 32;
 enum : int { P_ASM = 0, P_HG, P_SWEEP, P_XU, P_SEL, P_D, P_ED, P_W, P_MV, P_T1, P_UPD, P_POLISH, P_FINAL, P_TOTAL, P_BLOCK, P_B_S0, P_B_INV, P_B_DROP, P_SEL_A, P_A0, P_A1, P_A2, P_G };

@@ -108,7 +108,7 @@ enum hmpc_status_code {
   HMPC_S_INDEFINITE = 8,  /* the reduced Hessian, assembled in binary32 as the reference assembles it (SolverMPC.cpp:560-570), is NOT
                              positive definite: a sweep pivot of the safe pass came out <= 0 (seen with 20-step horizons at 10x the
                              nominal input ranges: rounding at 6e-8 |H| against a smallest eigenvalue of ~2 alpha).  Left by the
-                             device-side safe pass; hmpc_resolve_failed / hmpc_download answer it the way the reference's qpOASES run
+                             device-side safe pass with the instance's forces zeroed; hmpc_resolve_failed / hmpc_download answer it the way the reference's qpOASES run
                              does (H + rho I, then one step with g - rho x_1: QProblem.cpp:1753-1860) and report HMPC_S_OK */
   HMPC_S_REG_STEP = 9,    /* (internal to hmpc_resolve_failed: between the two regularised QPs of an HMPC_S_INDEFINITE instance) */
   HMPC_S_OK_RELAXED = 6   /* solved only after every bound was moved outward by <= 2e-5 (relative for the Fz cap) AND the exact

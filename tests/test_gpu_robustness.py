@@ -385,9 +385,10 @@ def test_indefinite_hessian_is_regularised_like_qpoases():
     mpc.set_device_repair(True)
     mpc.upload(rec)
     mpc.solve()
-    _, st_dev = mpc.download()
+    f_dev, st_dev = mpc.download()
     c_dev = interface.status_code(st_dev)
     assert (c_dev[indef] == 8).all() and (c_dev[~indef] != 8).all(), (c_dev[indef], np.unique(c_dev, return_counts=True))
+    assert (f_dev[indef] == 0).all()  # not solved: the force rows of such an instance are zeroed, never a diverged iterate
     # host-driven repair: the reference's regularisation steps
     assert mpc.resolve_failed() >= int(indef.sum())
     forces, status = mpc.download()
