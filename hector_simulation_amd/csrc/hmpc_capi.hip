@@ -453,7 +453,18 @@ static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
     static const char *dbg_relax = getenv("HMPC_DEBUG_SAFE_RELAX");  // developer A/B: another perturbation (0 = the exact, warm pass of before)
     if (dbg_relax && *dbg_relax) s.relax = atof(dbg_relax), s.warm = (s.relax == 0.0) ? 1 : 0;
   }
-  return launch_safe(h, stream, s);
+  rc = launch_safe(h, stream, s);
+  if (rc != HMPC_OK) return rc;
+  // Instances whose Hessian is not positive definite (the safe launch above found a sweep pivot <= 0: HMPC_S_INDEFINITE): the reference's
+  // two regularised QPs (KernelArgs::reg_step; hmpc_resolve_failed runs the same two launches).  Like the launches above they are
+  // trimmed on the device by the flagged counter -- with nothing flagged every workgroup leaves at once; queued behind the fast
+  // launch they cost a nominal solve nothing measurable (profiles/r06/range_scale.txt, 1x: the chain runs as fast as the fast pass alone).
+  s.relax = 0.0, s.warm = 1, s.skip_ok = 0;
+  for (int step = 1; step <= 2 && rc == HMPC_OK; ++step) {
+    s.reg_step = step;
+    rc = launch_safe(h, stream, s);
+  }
+  return rc;
 }
 
 extern "C" {
