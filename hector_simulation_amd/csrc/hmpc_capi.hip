@@ -147,6 +147,8 @@ constexpr int REPAIR_GRID_CAP = 65536;  // workgroups of the device-side safe la
 constexpr double SAFE_PASS_RELAX = 1e-6;  // first safe pass (device- and host-driven): bounds moved outward by this, exact re-solve + exact KKT check at its end
 constexpr int SPILL_SLOT_CAP = 32768;   // hand-over slots per handle at most (101 KB each for 120 variables: 3.3 GB of the 288 GB); instances beyond it are re-solved cold
 constexpr int EGLOBAL_CHUNK = 512;         // host-driven safe pass of the global-E variants: instances per launch (118 MB of scratch at 240 variables)
+constexpr int DEVICE_REG_MIN_HORIZON = 10;  // device-side chain: the regularisation launches are enqueued for longer horizons only (enqueue_reg_steps)
+constexpr int REG_LIST_CAP = 256;  // device-side chain: instances per solve whose Hessian is not positive definite that get the regularisation launches (the rest: hmpc_resolve_failed)
 constexpr int REPAIR_GRID_CAP_WIDE = 4096;  // ... of the wide variant's, whose safe pass keeps 231 KB per workgroup in global memory (0.95 GB of 288: the list mixes size classes, so a small cap could leave a wide instance behind 256 others unrepaired -- ADVICE round 5)
 
 // returns a device buffer of at least `bytes` owned by the handle (contents undefined)
@@ -219,8 +221,13 @@ struct LaunchOpt {
   bool continuation = false;  // list launch of the CONTINUATION variant (V2_CONT): only instances with a hand-over slot, everything else on the list is left alone
   int skip_ok = 0;         // list launch: instances an earlier pass over the same list solved are left alone (1: ok / ok-relaxed, 2: ok only)
   int sweep_k = 0, sweep_phase = 0;  // command sweep: group size; phase 0 = one workgroup per group forms M, 1 = one per instance solves with it (variant = a MODE 1 entry)
+  bool list_indefinite = false;  // device-side chain, safe launch: instances ended as HMPC_S_INDEFINITE are appended to the handle's short list
   int reg_step = 0;        // safe pass over an index list: regularisation step 1 / 2 for instances whose Hessian is not positive definite (KernelArgs::reg_step)
 };
+
+// the flagged list of the device-side chain: flag_list_cap entries, then REG_LIST_CAP more for the instances the safe launch ends as
+// HMPC_S_INDEFINITE; the two counters sit next to each other (one memset clears both)
+static int flag_list_cap(const hmpc_handle *h) { return h->max_batch < REPAIR_GRID_CAP ? h->max_batch : REPAIR_GRID_CAP; }
 
 static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   int vi = 0;
@@ -304,7 +311,7 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   a.relax = o.relax;
   a.flag_list = o.record_flagged ? h->d_flag_list : nullptr;
   a.flag_count = o.record_flagged ? h->d_flag_count : nullptr;
-  a.flag_cap = o.record_flagged ? (h->max_batch < REPAIR_GRID_CAP ? h->max_batch : REPAIR_GRID_CAP) : 0;
+  a.flag_cap = o.record_flagged ? flag_list_cap(h) : 0;
   a.list_count = o.d_list_count;
   a.ext_H = h->d_ext_H, a.ext_g = h->d_ext_g, a.ext_Fc = h->d_ext_Fc, a.ext_ld = h->ext_ld;
   a.iter_cap = h->iter_cap;
@@ -324,6 +331,9 @@ static int launch(hmpc_handle *h, hipStream_t stream, const LaunchOpt &o) {
   a.skip_ok = o.skip_ok;
   if (o.d_index_list && !h->d_reg_rho) HIP_TRY(hipMalloc(&h->d_reg_rho, (size_t)h->max_batch * sizeof(double)));  // (safe variants: where a pivot that is not positive is left)
   a.reg_step = o.reg_step, a.reg_rho = h->d_reg_rho;
+  a.reg_list = nullptr, a.reg_count = nullptr, a.reg_cap = 0;
+  if (o.list_indefinite && h->d_flag_list && h->d_flag_count)
+    a.reg_list = h->d_flag_list + flag_list_cap(h), a.reg_count = h->d_flag_count + 1, a.reg_cap = REG_LIST_CAP;
   a.sweep_k = o.sweep_k > 0 ? o.sweep_k : 1, a.sweep_phase = o.sweep_phase, a.sweep_m = h->d_sweep_m;
   a.inv_mass = 1.0f / h->params.mass;  // (binary32 division, correctly rounded: the value the reference's 1.f / 9.f folds to for the default)
   a.Ib[0] = h->params.inertia[0], a.Ib[1] = h->params.inertia[1], a.Ib[2] = h->params.inertia[2];
@@ -366,9 +376,32 @@ static int launch_safe(hmpc_handle *h, hipStream_t stream, LaunchOpt s) {
 //  * device repair: the fast launches list what they flag, the safe variant follows over that list (trimmed on the
 //    device by the counter: workgroups beyond it leave at once).  One stream per handle at a time: the list and its
 //    counter belong to the handle, two solves of one handle in flight on two streams would race on them.
+// Device-side chain, behind the safe launch: instances whose Hessian is not positive definite (that launch found a sweep pivot <= 0,
+// ended them as HMPC_S_INDEFINITE and listed them) get the reference's two regularised QPs (KernelArgs::reg_step; hmpc_resolve_failed
+// runs the same two launches from the status words).  The list is a short one of its own (REG_LIST_CAP entries, its counter next to
+// the flagged counter), so the two launches are a few hundred workgroups that leave at once when it is empty (over the flagged list's
+// grid -- 8 192 workgroups of the 91 KB-LDS safe variant -- an empty launch takes 10 us).
+static int enqueue_reg_steps(hmpc_handle *h, hipStream_t stream, LaunchOpt s) {
+  // Two launches = ~4 us of dispatch latency per solve even when their list is empty (scripts/dev/chain_overhead.py: the whole chain
+  // 11 -> 15 us at b8192, 6 -> 10 us at b1024), so only where such Hessians occur: horizons beyond 10 steps (binary32 round-off in H
+  // grows with the horizon; 107 of 4 096 double-support h = 20 instances at 10x the input ranges, none in any h <= 10 stress row up to
+  // 10x -- 20 000 instances).  A shorter-horizon handle would leave such an instance HMPC_S_INDEFINITE for hmpc_resolve_failed.
+  if (h->setup.horizon <= DEVICE_REG_MIN_HORIZON) return HMPC_OK;
+  s.d_index_list = h->d_flag_list + flag_list_cap(h);
+  s.d_list_count = h->d_flag_count + 1;
+  s.n_list = h->batch < REG_LIST_CAP ? h->batch : REG_LIST_CAP;
+  s.relax = 0.0, s.warm = 1, s.skip_ok = 0, s.list_indefinite = false;
+  int rc = HMPC_OK;
+  for (int step = 1; step <= 2 && rc == HMPC_OK; ++step) {
+    s.reg_step = step;
+    rc = launch_safe(h, stream, s);
+  }
+  return rc;
+}
+
 static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
   const bool repair = h->device_repair != 0;
-  if (repair) HIP_TRY(hipMemsetAsync(h->d_flag_count, 0, sizeof(unsigned int), stream));
+  if (repair) HIP_TRY(hipMemsetAsync(h->d_flag_count, 0, 2 * sizeof(unsigned int), stream));
   // longest-first dispatch: only where the tail of a launch matters (small and medium batches).  Keyed by the iteration counts
   // of the previous solve when that was of a batch of this size (the caller's contract: instance i of this tick is instance i
   // of the last one); otherwise -- a cold handle, another batch size, mode 2 -- by the cost predicted from the records themselves
@@ -453,18 +486,10 @@ static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
     static const char *dbg_relax = getenv("HMPC_DEBUG_SAFE_RELAX");  // developer A/B: another perturbation (0 = the exact, warm pass of before)
     if (dbg_relax && *dbg_relax) s.relax = atof(dbg_relax), s.warm = (s.relax == 0.0) ? 1 : 0;
   }
+  s.list_indefinite = true;
   rc = launch_safe(h, stream, s);
   if (rc != HMPC_OK) return rc;
-  // Instances whose Hessian is not positive definite (the safe launch above found a sweep pivot <= 0: HMPC_S_INDEFINITE): the reference's
-  // two regularised QPs (KernelArgs::reg_step; hmpc_resolve_failed runs the same two launches).  Like the launches above they are
-  // trimmed on the device by the flagged counter -- with nothing flagged every workgroup leaves at once; queued behind the fast
-  // launch they cost a nominal solve nothing measurable (profiles/r06/range_scale.txt, 1x: the chain runs as fast as the fast pass alone).
-  s.relax = 0.0, s.warm = 1, s.skip_ok = 0;
-  for (int step = 1; step <= 2 && rc == HMPC_OK; ++step) {
-    s.reg_step = step;
-    rc = launch_safe(h, stream, s);
-  }
-  return rc;
+  return enqueue_reg_steps(h, stream, s);
 }
 
 extern "C" {
@@ -826,7 +851,7 @@ int hmpc_solve_command_sweep(hmpc_handle *h, int group_size, void *stream) {
     h->sweep_m_bytes = need;
   }
   const bool repair = h->device_repair != 0;
-  if (repair) HIP_TRY(hipMemsetAsync(h->d_flag_count, 0, sizeof(unsigned int), st));
+  if (repair) HIP_TRY(hipMemsetAsync(h->d_flag_count, 0, 2 * sizeof(unsigned int), st));
   h->order_valid = false, h->order_batch = 0;  // (natural order inside a sweep; the next ordinary solve starts from the predictor)
   LaunchOpt o;
   o.variant = vi, o.sweep_k = group_size, o.sweep_phase = 0;
@@ -842,7 +867,10 @@ int hmpc_solve_command_sweep(hmpc_handle *h, int group_size, void *stream) {
   s.n_list = h->batch < REPAIR_GRID_CAP ? h->batch : REPAIR_GRID_CAP;
   s.warm = 0;
   s.d_list_count = h->d_flag_count;
-  return launch_safe(h, st, s);
+  s.list_indefinite = true;
+  rc = launch_safe(h, st, s);
+  if (rc != HMPC_OK) return rc;
+  return enqueue_reg_steps(h, st, s);
 }
 
 int hmpc_set_device_repair(hmpc_handle *h, int on) {
@@ -850,11 +878,11 @@ int hmpc_set_device_repair(hmpc_handle *h, int on) {
   HIP_TRY(hipSetDevice(h->device));
   if (on && (!h->d_flag_list || !h->d_flag_count)) {
     // both buffers or neither: they are committed to the handle only once both exist and are cleared
-    const int cap = h->max_batch < REPAIR_GRID_CAP ? h->max_batch : REPAIR_GRID_CAP;
+    const int cap = flag_list_cap(h);
     int *list = nullptr;
     unsigned int *count = nullptr;
-    if (hipMalloc(&list, (size_t)cap * sizeof(int)) != hipSuccess || hipMalloc(&count, sizeof(unsigned int)) != hipSuccess ||
-        hipMemset(list, 0, (size_t)cap * sizeof(int)) != hipSuccess || hipMemset(count, 0, sizeof(unsigned int)) != hipSuccess) {
+    if (hipMalloc(&list, (size_t)(cap + REG_LIST_CAP) * sizeof(int)) != hipSuccess || hipMalloc(&count, 2 * sizeof(unsigned int)) != hipSuccess ||
+        hipMemset(list, 0, (size_t)(cap + REG_LIST_CAP) * sizeof(int)) != hipSuccess || hipMemset(count, 0, 2 * sizeof(unsigned int)) != hipSuccess) {
       if (list) (void)hipFree(list);
       if (count) (void)hipFree(count);
       g_hip_err = "hipMalloc failed in hmpc_set_device_repair";

@@ -2197,6 +2197,10 @@ __global__ __launch_bounds__(NT, (NT < 512 && fits_three_waves<NMAX, HMAX, NT, Q
         for (int t = tid; t < C8 * h; t += NT) args.wset[(size_t)inst * C8 * h + t] = 0;
       if (tid == 0) {
         if (args.reg_rho) args.reg_rho[inst] = negp;
+        if (args.reg_count) {  // device-side chain: listed for the regularisation launches that follow
+          const unsigned int k = atomicAdd(args.reg_count, 1u);
+          if ((int)k < args.reg_cap) args.reg_list[k] = inst;
+        }
         args.status[inst] = (uint32_t)S_INDEFINITE;
         if (args.flagged) atomicAdd(args.flagged, 1u);
       }

@@ -100,6 +100,12 @@ struct KernelArgs {
   //               x_1 in the force buffer, status S_REG_STEP;
   //   reg_step 2: instances whose status is S_REG_STEP: H + rho I, g - rho x_1; the answer, status S_OK.
   int reg_step;
+  // device-side chain: the safe launch (reg_step 0) appends the instances it ends as S_INDEFINITE to this list, which the two
+  // regularisation launches then run over (a short list of its own: their grids stay small).  nullptr = off (host-driven repair
+  // builds its list from the status words)
+  int *reg_list;
+  unsigned int *reg_count;
+  int reg_cap;
   double *reg_rho;  // [batch]: the pivot (after reg_step 0), then rho; set for every launch over an index list
 };
 constexpr int NPROF = 32;

@@ -108,7 +108,7 @@ enum hmpc_status_code {
   HMPC_S_INDEFINITE = 8,  /* the reduced Hessian, assembled in binary32 as the reference assembles it (SolverMPC.cpp:560-570), is NOT
                              positive definite: a sweep pivot of the safe pass came out <= 0 (seen with 20-step horizons at 10x the
                              nominal input ranges: rounding at 6e-8 |H| against a smallest eigenvalue of ~2 alpha).  An intermediate
-                             state: the safe pass -- hmpc_resolve_failed / hmpc_download, or the device-side chain of
+                             state: the safe pass -- hmpc_resolve_failed / hmpc_download, or (horizons > 10) the device-side chain of
                              hmpc_set_device_repair(h, 1) -- answers it the way the reference's qpOASES run does (H + rho I, then one
                              step with g - rho x_1: QProblem.cpp:1753-1860) and reports HMPC_S_OK; seen by a caller only where those
                              two QPs fail as well (forces zeroed) */
@@ -283,9 +283,11 @@ int hmpc_set_handover(hmpc_handle *h, int on);
  * re-solved (hmpc_set_handover): first the continuation variant over the flagged list (96-row working set, two workgroups per
  * CU), then the safe variant over what is still flagged: cold, bounds moved outward by a relative 1e-6 and an exact re-solve
  * on the working set found (pass (2) of hmpc_resolve_failed: HMPC_S_OK, or HMPC_S_OK_RELAXED when the exact KKT check fails
- * on that set: a solved instance whose bounds were off by <= 2e-6 relative; not seen on any measured set), and two more launches
- * over the same list for instances whose Hessian is not positive definite (pass (4) of hmpc_resolve_failed; all four are trimmed on
- * the device by the flagged counter: with nothing flagged their workgroups leave at once).  on = 2: the continuation pass only -- what it does not finish
+ * on that set: a solved instance whose bounds were off by <= 2e-6 relative; not seen on any measured set), and -- for horizons beyond
+ * 10 steps, where such Hessians occur -- two more short launches for the instances whose Hessian is not positive definite (pass (4)
+ * of hmpc_resolve_failed; up to 256 per solve, the rest and any such instance of a shorter-horizon handle stay HMPC_S_INDEFINITE for
+ * hmpc_resolve_failed).  Every launch of the chain is trimmed on the device by a counter: with nothing flagged their workgroups leave
+ * at once, and a nominal solve pays 11-15 us of dispatch latency for the chain (scripts/dev/chain_overhead.py).  on = 2: the continuation pass only -- what it does not finish
  * (~0.5 % of the instances at 6x the nominal input ranges: degenerate vertices, working sets beyond 96 rows) stays FLAGGED in
  * the status word for hmpc_resolve_failed / hmpc_download; a cold re-solve of such an instance takes hundreds of iterations on a
  * single workgroup, milliseconds at the tail of the stream, which a device-resident pipeline may prefer not to wait for. */
