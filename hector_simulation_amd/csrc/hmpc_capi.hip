@@ -366,21 +366,10 @@ static int launch_safe(hmpc_handle *h, hipStream_t stream, LaunchOpt s) {
   return launch(h, stream, s);
 }
 
-// One solve of the current batch, enqueued on `stream` -- what hmpc_solve does and what hmpc_time_solve times:
-//  * widest reduced QP known (host-uploaded records, or hmpc_set_max_reduced_vars >= 0): one launch of the variant
-//    that holds it;
-//  * unknown (records built on the device or handed in by device pointer; two contacts): the instances' size classes are
-//    on the device (from the record builder, else counted here from the gait bytes) and EVERY variant of the family is
-//    launched over the whole batch -- a workgroup whose instance belongs to another variant leaves at once -- so that a
-//    walking sweep built on the device runs on the 60-variable kernel without the host ever seeing a gait table;
-//  * device repair: the fast launches list what they flag, the safe variant follows over that list (trimmed on the
-//    device by the counter: workgroups beyond it leave at once).  One stream per handle at a time: the list and its
-//    counter belong to the handle, two solves of one handle in flight on two streams would race on them.
 // Device-side chain, behind the safe launch: instances whose Hessian is not positive definite (that launch found a sweep pivot <= 0,
 // ended them as HMPC_S_INDEFINITE and listed them) get the reference's two regularised QPs (KernelArgs::reg_step; hmpc_resolve_failed
 // runs the same two launches from the status words).  The list is a short one of its own (REG_LIST_CAP entries, its counter next to
-// the flagged counter), so the two launches are a few hundred workgroups that leave at once when it is empty (over the flagged list's
-// grid -- 8 192 workgroups of the 91 KB-LDS safe variant -- an empty launch takes 10 us).
+// the flagged counter), so the two launches are a few hundred workgroups that leave at once when it is empty.
 static int enqueue_reg_steps(hmpc_handle *h, hipStream_t stream, LaunchOpt s) {
   // Two launches = ~4 us of dispatch latency per solve even when their list is empty (scripts/dev/chain_overhead.py: the whole chain
   // 11 -> 15 us at b8192, 6 -> 10 us at b1024), so only where such Hessians occur: horizons beyond 10 steps (binary32 round-off in H
@@ -399,6 +388,16 @@ static int enqueue_reg_steps(hmpc_handle *h, hipStream_t stream, LaunchOpt s) {
   return rc;
 }
 
+// One solve of the current batch, enqueued on `stream` -- what hmpc_solve does and what hmpc_time_solve times:
+//  * widest reduced QP known (host-uploaded records, or hmpc_set_max_reduced_vars >= 0): one launch of the variant
+//    that holds it;
+//  * unknown (records built on the device or handed in by device pointer; two contacts): the instances' size classes are
+//    on the device (from the record builder, else counted here from the gait bytes) and EVERY variant of the family is
+//    launched over the whole batch -- a workgroup whose instance belongs to another variant leaves at once -- so that a
+//    walking sweep built on the device runs on the 60-variable kernel without the host ever seeing a gait table;
+//  * device repair: the fast launches list what they flag, the safe variant follows over that list (trimmed on the
+//    device by the counter: workgroups beyond it leave at once).  One stream per handle at a time: the list and its
+//    counter belong to the handle, two solves of one handle in flight on two streams would race on them.
 static int enqueue_solve(hmpc_handle *h, hipStream_t stream, bool carry_wset) {
   const bool repair = h->device_repair != 0;
   if (repair) HIP_TRY(hipMemsetAsync(h->d_flag_count, 0, 2 * sizeof(unsigned int), stream));
