@@ -12,6 +12,7 @@ torch.zeros(1, device="cuda")
 from hector_simulation_amd import interface, records, synthetic  # noqa: E402
 
 print(f"{'batch':>6s} {'natural':>22s} {'predicted order':>24s} {'previous-solve order':>24s}   active-set iterations of the batch")
+one_round = {}  # batch -> (natural-order ms, largest iteration count), batches that are one round of resident workgroups (<= 768)
 for nb in (64, 256, 512, 768, 1024, 1536, 2304):
     f = synthetic.make_batch(nb, 10, "standing", seed=2, phase="random")
     rec = records.pack_records(f, 10)
@@ -28,3 +29,13 @@ for nb in (64, 256, 512, 768, 1024, 1536, 2304):
     # (up to 768 instances are ONE round of workgroups: the launch lasts as long as its slowest instance's dependency chain, i.e. it
     #  follows the batch's LARGEST iteration count -- every batch size is its own random draw -- not the batch size)
     print(f"b{nb:5d} " + "   ".join(f"{ms:.4f} ms {nb / ms / 1e3:6.3f} M/s" for ms in row) + f"   iterations mean {itmean:.2f} max {itmax}", flush=True)
+    if nb <= 768:
+        one_round[nb] = (row[0], itmax)
+# Why a smaller batch can be slower than a larger one (b256 vs b512), from this run's own numbers
+(t64, i64), (t512, i512), (t256, i256) = one_round[64], one_round[512], one_round[256]
+slope = (t512 - t64) / max(i512 - i64, 1)
+print(f"\n# Up to 768 instances are ONE round of resident workgroups, so a launch lasts as long as the dependency chain of its slowest instance, and that")
+print(f"# follows the LARGEST active-set iteration count in the batch -- every batch size here is its own random draw -- not the batch size:")
+print("# " + ", ".join(f"b{nb} (max {it} iterations) {ms:.3f} ms" for nb, (ms, it) in sorted(one_round.items())) + ".")
+print(f"# The line through b64 and b512: {1e3 * slope:.1f} us per iteration of the slowest instance on top of {t64 - slope * i64:.3f} ms of assembly + inverse + block start;")
+print(f"# it predicts {t64 + slope * (i256 - i64):.3f} ms for b256's {i256} iterations (measured {t256:.3f} ms).")
