@@ -223,12 +223,16 @@ int hmpc_reset_tick_warm_start(hmpc_handle *h);
  * 1e-6 (a different amount per row: separates the coinciding vertices at which the exact problem makes Goldfarb-Idnani cycle --
  * the instances that reach this pass are the degenerate ones), ending with an exact re-solve on the working set it found:
  * HMPC_S_OK when that passes the exact KKT check -- every one of the 8 192 at 6x the nominal input ranges --, HMPC_S_OK_RELAXED
- * otherwise; (3) the same variant on the EXACT bounds from the working set (2) left, for relaxed and flagged instances alike;
+ * otherwise; (3) the same variant on the EXACT bounds, started by the block start, for relaxed and flagged instances alike;
  * (4) instances whose reduced Hessian is not positive definite (HMPC_S_INDEFINITE, found by the sweeps of (2)): the reference's
  * regularisation, two more launches -- H + rho I with rho = |H|_F sqrt(1e3 * 2.221e-16), then the same QP with the gradient
  * g - rho x_1 (qpOASES QProblem.cpp:1753-1860, QProblemB.cpp:1418-1431, 1999-2031 under Options::setToMPC) -- within 6e-8 of what
  * the reference returns for them; (5) up to three last-resort passes with the bounds moved by 1e-7, 1e-6, 1e-5, cold.  Measured at 1x .. 10x the nominal input
- * ranges (scripts/stress.py, profiles/r06/stress.txt): every instance qpOASES solves ends HMPC_S_OK.  *n_resolved (may be NULL) =
+ * ranges (scripts/stress.py, profiles/r06/stress.txt, 28 shapes x ranges of 1 024 instances): every instance qpOASES solves ends
+ * HMPC_S_OK.  On 4 096 per row (stress_4096.txt): the same up to 6x; at 10x five rows keep ONE instance flagged KKT, and two
+ * instances end HMPC_S_OK_RELAXED 3e-3 / 8e-3 from qpOASES' forces (7 of 114 688; an ok-relaxed answer satisfies the bounds to 2e-5
+ * but need not be close to the exact optimum where the problem is that degenerate: check for the code where that matters).
+ * *n_resolved (may be NULL) =
  * how many were re-solved.  hmpc_download does this automatically unless hmpc_set_auto_resolve(h, 0). */
 int hmpc_resolve_failed(hmpc_handle *h, int *n_resolved);
 /* Dispatch order of the workgroups of a solve.  mode 1 (default), longest first: the instances are started in the order of
